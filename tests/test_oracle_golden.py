@@ -1,0 +1,154 @@
+"""The CPU oracle (oracle/ref_cpu.py) against golden vectors produced by the reference's own code
+(tools/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from ishapediting_amd import synthetic
+from ishapediting_amd.unet_spec import build_spec, full_config, param_shapes, tiny_config, is_torso_conv
+
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("steps", [10, 40, 200, 256, 1000])
+def test_schedule_tables(gold, steps):
+    g = gold("g1_schedules")
+    tb = O.Tables(str(steps))
+    assert tb.timestep_map == g[f"T{steps}_timestep_map"].tolist()
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+              "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+              "posterior_mean_coef1", "posterior_mean_coef2"):
+        np.testing.assert_array_equal(getattr(tb, k), g[f"T{steps}_{k}"])   # float64, bit-exact
+
+
+def test_step_arithmetic(gold):
+    g = gold("g2_steps")
+    d = O.DiffusionOracle(O.Tables("40"))
+    x, mo, noise, vn = (T(g[k]) for k in ("x", "model_output", "noise", "variance_noise"))
+    for t in (0, 1, 17, 39):
+        assert int(g[f"t{t}_ts"][0]) == d.tb.timestep_map[t]
+        o = d.mean_variance_from_output(mo, x, t, True)
+        nz = 0.0 if t == 0 else 1.0
+        close(o["mean"], g[f"t{t}_mean"])
+        close(o["variance"], g[f"t{t}_variance"])
+        close(o["pred_xstart"], g[f"t{t}_pred_xstart"])
+        close(o["mean"] + nz * torch.sqrt(o["variance"]) * noise, g[f"t{t}_sample"])
+        o2 = d.mean_variance_from_output(mo, x, t, False)
+        close(o2["mean"] + nz * torch.sqrt(o2["variance"]) * noise, g[f"t{t}_sample_noclip"], atol=1e-5)
+        close(o["mean"] + vn, g[f"t{t}_sample_vn"])
+        close(o["mean"] + nz * torch.exp(0.5 * o["log_variance"]) * T(g["psample_noise"]), g[f"t{t}_psample"])
+
+
+def test_primitives(gold):
+    g = gold("g3_primitives")
+    t = T(g["temb_t"])
+    close(O.timestep_embedding(t, 32), g["temb_32"])
+    close(O.timestep_embedding(t, 256), g["temb_256"])
+    for c in (512, 64, 96):
+        out = O.resize_feat_align(T(g[f"rfa_in_{c}"]))
+        np.testing.assert_array_equal(out.numpy(), g[f"rfa_out_{c}"])
+    np.testing.assert_array_equal(O.make_offsets(2).numpy(), g["offsets_r2"])
+
+
+@pytest.mark.parametrize("nrb", [1, 2])
+def test_tiny_unet_forward_and_input_grad(gold, nrb):
+    g = gold("g4_tiny_unet")
+    cfg = tiny_config(nrb)
+    spec = build_spec(cfg)
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 100 + nrb))
+    net = O.UNetOracle(spec, sd, fp16=False)
+    x = T(g[f"nrb{nrb}_x"])
+    ts = T(g[f"nrb{nrb}_ts"])
+    xx = x.clone().requires_grad_(True)
+    out, taps = net.forward(xx, ts, all_taps=True)
+    close(out, g[f"nrb{nrb}_out"], rtol=1e-4, atol=1e-5)
+    gx, = torch.autograd.grad((out * T(g[f"nrb{nrb}_out_ct"])).sum(), xx, retain_graph=True)
+    close(gx, g[f"nrb{nrb}_out_gx"], rtol=1e-3, atol=1e-5)
+    for k, tap in enumerate(taps):
+        close(tap, g[f"nrb{nrb}_tap{k}"], rtol=1e-4, atol=1e-5)
+        gx, = torch.autograd.grad((tap * T(g[f"nrb{nrb}_tap{k}_ct"])).sum(), xx, retain_graph=True)
+        close(gx, g[f"nrb{nrb}_tap{k}_gx"], rtol=1e-3, atol=1e-5)
+    # fp16 torso: same precision contract as convert_to_fp16 (unet.py:618-624)
+    net16 = O.UNetOracle(spec, sd, fp16=True)
+    k = int(g[f"nrb{nrb}_tap_fp16_idx"])
+    with torch.no_grad():
+        o16, f16 = net16.forward(x, ts, feat_layer=k)
+    close(o16, g[f"nrb{nrb}_out_fp16"], rtol=1e-3, atol=1e-3)
+    close(f16.float(), g[f"nrb{nrb}_tap_fp16"], rtol=1e-3, atol=1e-3)
+
+
+def test_decoder(gold):
+    g = gold("g6_decoder")
+    net = synthetic.decoder_state_dict()
+    logits = O.decoder_forward(net, T(g["planes"]), T(g["coords"]))
+    close(logits, g["logits"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("loss_type", ["l2", "l1"])
+@pytest.mark.parametrize("cof", [0.0, 0.4])
+def test_drag_loss_gradient(gold, loss_type, cof):
+    g = gold("g7_drag")
+    setup = O.DragSetup(g["sources"], g["targets"], int(g["r1"]), float(g["voxel_size"]), 16)
+    edit = T(g["edit"]).clone().requires_grad_(True)
+    loss = O.drag_loss(edit, T(g["orig"]), setup, cof, loss_type)
+    gr, = torch.autograd.grad(loss, edit)
+    close(gr, g[f"{loss_type}_cof{cof}_grad"], rtol=1e-4, atol=1e-8)
+    assert g[f"{loss_type}_cof{cof}_progress"].tolist() == [0.0]
+
+
+def _tiny_loop_objects():
+    cfg = tiny_config(1)
+    spec = build_spec(cfg)
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 101))
+    return spec, O.UNetOracle(spec, sd, fp16=False)
+
+
+def test_ddpm_inversion(gold):
+    g = gold("g8_g9_tiny_loops")
+    Tn, w_time, feat_layer, r1, B = g["meta"].tolist()
+    _, net = _tiny_loop_objects()
+    d = O.DiffusionOracle(O.Tables(str(Tn)))
+    with torch.no_grad():
+        inv = d.ddpm_inversion(net, T(g["inv_x0"]), w_time, list(T(g["inv_fwd_noise"])), feat_layer=feat_layer)
+    close(inv["latent"], g["inv_latent"], rtol=1e-5, atol=1e-6)
+    close(inv["sample"], g["inv_sample"], rtol=1e-4, atol=1e-5)
+    # round-trip identity by construction (gaussian_diffusion.py:530-531): sample == x_0 up to rounding
+    close(inv["sample"], g["inv_x0"], rtol=0, atol=1e-5)
+    close(torch.stack(inv["variance_noise"]), g["inv_variance_noise"], rtol=1e-3, atol=1e-5)
+    close(torch.stack(inv["variance"]), g["inv_variance"], rtol=1e-4, atol=1e-7)
+    close(torch.stack(inv["inter_feat"]), g["inv_inter_feat"], rtol=1e-3, atol=1e-5)
+
+
+def test_sampling_and_drag_loops(gold):
+    g = gold("g8_g9_tiny_loops")
+    Tn, w_time, feat_layer, r1, B = g["meta"].tolist()
+    _, net = _tiny_loop_objects()
+    d = O.DiffusionOracle(O.Tables(str(Tn)))
+    ns = T(g["loop_noise_sampling"])
+    noises = {Tn - 1 - k: ns[k] for k in range(Tn)}
+    img, w, cache = O.sample_with_guidance_cache(d, net, T(g["loop_latent0"]), Tn, w_time, feat_layer, noises)
+    close(w, g["loop_w"], rtol=1e-4, atol=1e-5)
+    close(img, g["loop_final_unguided"], rtol=1e-3, atol=1e-4)
+    close(torch.stack(cache), g["loop_guidance"], rtol=1e-3, atol=1e-4)
+    setup = O.DragSetup(g["drag_sources"], g["drag_targets"], r1, 2.0 / 32, cache[0].shape[-1])
+    dn = T(g["drag_noise"])
+    dnoise = {w_time - 1 - k: dn[k] for k in range(w_time)}
+    final, losses = O.drag_loop(d, net, T(g["loop_w"]), list(T(g["loop_guidance"])), setup, w_time, feat_layer,
+                                50.0, 0.4, dnoise)
+    close(final, g["drag_final"], rtol=1e-3, atol=1e-4)
+    assert int(g["drag_stop_time"]) == 0
+    np.testing.assert_allclose(g["drag_progress"], [1 - i / (w_time - 1.0) for i in range(w_time - 1, -1, -1)])
+
+
+def test_full_model_key_table(gold):
+    g = gold("g10_full_keys")
+    shapes = param_shapes(full_config())
+    assert sorted(shapes) == g["keys"].tolist()
+    assert sum(int(np.prod(s)) for s in shapes.values()) == int(g["n_params"])
+    assert sorted(k for k in shapes if is_torso_conv(k)) == g["halved"].tolist()
