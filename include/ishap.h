@@ -1,0 +1,158 @@
+/* libishap_hip.so -- C ABI of the MI355X (gfx950) denoise-and-drag core.
+ *
+ * The reference (jinli99/iShapEditing) has no native boundary: its hot path is reached through
+ * Python calls into stock torch ops.  Each entry point below names the reference function whose
+ * arithmetic it replaces (paths relative to the reference root; gd = neural_field_diffusion/
+ * guided_diffusion).  Conventions:
+ *   - every function returns 0 on success, non-zero on failure; ishap_last_error() gives the
+ *     thread-local message; nothing throws across this boundary;
+ *   - all tensors are caller-allocated DEVICE buffers (torch owns memory); dims are explicit;
+ *   - `stream` is a hipStream_t (0 = default stream); calls only enqueue work, they never sync;
+ *   - torch-visible tensors use the reference's layouts (NCHW, fp32 unless noted).
+ */
+#ifndef ISHAP_H
+#define ISHAP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* ishap_last_error(void);
+int ishap_version(void);
+
+/* ---------------------------------------------------------------- UNet (gd/unet.py:396-671) */
+typedef struct ishap_unet ishap_unet;
+
+typedef struct {
+  int image_size;          /* 128 */
+  int in_channels;         /* 96 */
+  int model_channels;      /* 256 */
+  int out_channels;        /* 192 (learn_sigma) */
+  int num_res_blocks;      /* 2 */
+  int n_mult;              /* length of channel_mult */
+  int channel_mult[8];     /* (1,1,2,3,4) for image_size 128, gd/script_util.py:151-161 */
+  int n_att;
+  int attention_ds[8];     /* downsample rates with attention: image_size // res, script_util.py:163-165 */
+  int num_head_channels;   /* 64 */
+  int max_batch;           /* largest N a forward may be called with */
+} ishap_unet_config;
+
+/* UNetModel.__init__ with use_scale_shift_norm, resblock_updown, use_fp16 (drag_utils.py:44-57):
+ * builds the block graph, sizes the activation arena and workspaces on `device`. */
+int ishap_unet_create(const ishap_unet_config* cfg, int device, ishap_unet** out);
+void ishap_unet_destroy(ishap_unet* u);
+
+/* state_dict key table (same names/shapes torch gives the reference model; drag_utils.py:229-230
+ * loads with strict=True).  shape has up to 4 entries. */
+int ishap_unet_num_params(const ishap_unet* u);
+int ishap_unet_param_info(const ishap_unet* u, int index, char* name, int name_cap, int* ndim, long long* shape);
+/* model.load_state_dict + convert_to_fp16 (gd/unet.py:618-624, gd/fp16_util.py:14-21) for one tensor:
+ * `data` = fp32 device buffer of `numel` values in the reference's layout.  Conv weights are re-packed
+ * to fp16 MFMA operands (forward and input-gradient forms); torso conv biases are rounded through fp16. */
+int ishap_unet_load_param(ishap_unet* u, const char* name, const float* data, long long numel, void* stream);
+int ishap_unet_params_loaded(const ishap_unet* u);   /* number of distinct tensors loaded so far */
+
+/* UNetModel.forward(x, timesteps, feat_layer) (gd/unet.py:634-671) with timesteps already mapped to the
+ * original 0..999 index (gd/respace.py:122-127).
+ *   x            [N][in_channels][S][S] fp32
+ *   timesteps    HOST array of N floats
+ *   feat_layer   output-block index whose activation is tapped (h.clone() at unet.py:665-666), or -1
+ *   out          [N][out_channels][S][S] fp32
+ *   inter_feat   optional [N][C_tap][S_tap][S_tap] fp16 copy of the tap in the reference layout (may be NULL;
+ *                the tap always stays resident inside the context for ishap_drag_* / backward)
+ *   keep_for_backward  non-zero: keep every intermediate needed by ishap_unet_backward_input */
+int ishap_unet_forward(ishap_unet* u, const float* x, const float* timesteps, int N, int feat_layer,
+                       float* out, void* inter_feat, int keep_for_backward, void* stream);
+int ishap_unet_tap_shape(const ishap_unet* u, int feat_layer, int* channels, int* size);
+/* device pointer of the resident tap of the last forward: NHWC fp16 [N][S_tap*S_tap][C_tap] */
+const void* ishap_unet_tap_ptr(const ishap_unet* u);
+/* copy it into a caller buffer of N*S_tap^2*C_tap halfs (the guidance cache of drag_utils.py:275-276, kept
+ * on the device in the tap's own layout instead of resized fp32 copies on the host) */
+int ishap_unet_copy_tap(const ishap_unet* u, void* dst, void* stream);
+
+/* d(sum(tap * cot)) / dx through output block feat_layer ... input block 0: what loss.backward()
+ * computes for img.grad at drag_utils.py:383, without the weight gradients the reference discards.
+ *   cot_nhwc   fp16 cotangent of the tap in the tap's resident layout [N][S_tap^2][C_tap], already
+ *              multiplied by the loss scale *scale2[0] (see ishap_grad_to_scaled_f16)
+ *   scale2     device float[2] = {scale, 1/scale} or NULL for scale 1
+ *   dx         [N][in_channels][S][S] fp32 = gradient w.r.t. x (loss scale removed) */
+int ishap_unet_backward_input(ishap_unet* u, const void* cot_nhwc, const float* scale2, float* dx, void* stream);
+/* same, from a cotangent of the model output [N][out_channels][S][S] fp32 (full-depth backward,
+ * drag_utils.py:458 in train_triplane) */
+int ishap_unet_backward_from_output(ishap_unet* u, const float* cot_out, float* dx, void* stream);
+
+/* ------------------------------------------- diffusion step (gd/gaussian_diffusion.py:232-331, 400-510) */
+typedef struct {
+  float min_log;        /* posterior_log_variance_clipped[t]  (float64 table cast to fp32, :1035-1048) */
+  float max_log;        /* log(betas[t]) */
+  float sqrt_recip;     /* sqrt_recip_alphas_cumprod[t] */
+  float sqrt_recipm1;   /* sqrt_recipm1_alphas_cumprod[t] */
+  float coef1, coef2;   /* posterior_mean_coef1/2[t] */
+  float nonzero;        /* 0 when t == 0 else 1 */
+  int clip_denoised;
+  int mode;             /* 0: mean + sqrt(var)*noise (p_sample_guidance :503/:508)
+                           1: mean + exp(0.5*logvar)*noise (p_sample :443)
+                           2: mean + variance_noise (:498-499; `noise` holds variance_noise) */
+} ishap_step_coefs;
+/* any of sample / pred_xstart / variance / mean may be NULL; noise NULL = zeros; variance_in optional */
+int ishap_ddpm_step(const float* x, const float* model_out, const float* noise, const float* variance_in,
+                    const ishap_step_coefs* k, int N, int C, int HW,
+                    float* sample, float* pred_xstart, float* variance, float* mean, void* stream);
+/* img = sample + variance * (scale * grad)   (drag_utils.py:384-392); grad_mul_dev: optional device scalar */
+int ishap_guided_update(const float* sample, const float* variance, const float* grad, float scale,
+                        const float* grad_mul_dev, long long numel, float* out, void* stream);
+/* out = a*x + b*y  (forward-noising chain of ddpm_inversion, gd/gaussian_diffusion.py:520-522) */
+int ishap_axpby(const float* x, const float* y, float a, float b, long long numel, float* out, void* stream);
+
+/* ---------------------------------------------------------- drag loss (drag_utils.py:141-159, 309-382) */
+typedef struct {
+  int W;                /* side of the tap feature map (64) */
+  int ld;               /* channels of the tap (512) */
+  int Cc;               /* channels per plane after resize_feat_align (170) */
+  const int* chmap;     /* device int[3*Cc]: (plane, c) -> tap channel (resize_feat_align's mapping) */
+  const float* sources; /* device [B][3] */
+  const float* targets; /* device [B][3] */
+  int B;
+  int r;                /* lattice radius r1 (12) */
+  float voxel;          /* 2 / shape_resolution */
+  float cof;
+  int l1;               /* loss_type == 'l1' */
+  unsigned char* touched; /* device scratch [3*W*W] */
+  int* nmask;             /* device scratch [1] */
+  float* acc;             /* device scratch [2] */
+} ishap_drag_args;
+/* once per edit: rounded-texel bitmap and complement count (drag_utils.py:322-334) */
+int ishap_drag_setup(const ishap_drag_args* a, void* stream);
+/* per step: loss (device float[1]) and d loss / d tap as fp32 NHWC [W*W][ld] (drag_utils.py:355-383) */
+int ishap_drag_loss_grad(const ishap_drag_args* a, const void* edit_nhwc_f16, const void* orig_nhwc_f16,
+                         float* grad_nhwc, float* loss, void* stream);
+/* fp32 gradient -> fp16 cotangent times a power-of-two loss scale picked from max|g| on the device;
+ * bits: device scratch uint32[1]; scale2: device float[2] = {scale, 1/scale} */
+int ishap_grad_to_scaled_f16(const float* grad, void* out_f16, unsigned* bits, float* scale2, long long numel,
+                             void* stream);
+
+/* ------------------------------------- decoder (triplane_decoder/axisnetworks.py:517-562, visualize.py:76-97) */
+typedef struct {
+  const float* B;       /* net.0._B      [32][64] */
+  const float* W1;      /* net.1.weight  [128][128] */
+  const float* b1;
+  const float* W2;      /* net.3.weight  [128][128] */
+  const float* b2;
+  const float* w3;      /* net.5.weight  [1][128] */
+  const float* b3;      /* net.5.bias    [1] */
+} ishap_decoder_weights;
+/* (latent * range + middle).reshape(3,32,S,S) (drag_utils.py:295) into channels-last planes [3][S][S][32];
+ * range/middle: device float[96] or NULL for 1/0 */
+int ishap_planes_prepare(const float* latent, const float* range, const float* middle, int S, float* planes,
+                         void* stream);
+/* MultiTriplane.forward: logits for explicit coords [npts][3] */
+int ishap_triplane_decode_points(const float* planes, int S, const ishap_decoder_weights* w, const float* coords,
+                                 long long npts, float* logits, void* stream);
+/* create_obj_o3d's dense grid (visualize.py:79-97): axis = device float[res] (torch.linspace(-1,1,res)),
+ * volume[res][res][res] with x slowest, no host round trips */
+int ishap_triplane_decode_grid(const float* planes, int S, const ishap_decoder_weights* w, const float* axis, int res,
+                               float* volume, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,101 @@
+// C-ABI wrappers for the step / drag / decode kernels (declarations and reference citations: include/ishap.h).
+#include "../../include/ishap.h"
+#include "common.h"
+#include "ddpm.h"
+#include "decode.h"
+#include "drag.h"
+
+static thread_local std::string g_err;
+void ishap_set_error(const std::string& msg) { g_err = msg; }
+
+extern "C" {
+
+const char* ishap_last_error(void) { return g_err.c_str(); }
+
+int ishap_ddpm_step(const float* x, const float* model_out, const float* noise, const float* variance_in,
+                    const ishap_step_coefs* k, int N, int C, int HW, float* sample, float* pred_xstart,
+                    float* variance, float* mean, void* stream) {
+  ISHAP_REQUIRE(x && model_out && k, "null argument");
+  ISHAP_REQUIRE(k->mode >= 0 && k->mode <= 2, "mode");
+  ISHAP_REQUIRE(k->mode != 2 || noise, "mode 2 needs variance_noise in `noise`");
+  DdpmStepArgs a;
+  a.x = x; a.model_out = model_out; a.noise = noise; a.variance_in = variance_in;
+  a.sample = sample; a.pred_xstart = pred_xstart; a.variance = variance; a.mean = mean;
+  a.N = N; a.C = C; a.HW = HW;
+  a.min_log = k->min_log; a.max_log = k->max_log; a.sqrt_recip = k->sqrt_recip; a.sqrt_recipm1 = k->sqrt_recipm1;
+  a.coef1 = k->coef1; a.coef2 = k->coef2; a.nonzero = k->nonzero; a.clip = k->clip_denoised; a.mode = k->mode;
+  return ddpm_step_launch(a, (hipStream_t)stream);
+}
+
+int ishap_guided_update(const float* sample, const float* variance, const float* grad, float scale,
+                        const float* grad_mul_dev, long long numel, float* out, void* stream) {
+  ISHAP_REQUIRE(sample && variance && grad && out, "null argument");
+  return guided_update_launch(sample, variance, grad, out, scale, grad_mul_dev, numel, (hipStream_t)stream);
+}
+
+int ishap_axpby(const float* x, const float* y, float a, float b, long long numel, float* out, void* stream) {
+  ISHAP_REQUIRE(x && y && out, "null argument");
+  return axpby_launch(x, y, out, a, b, numel, (hipStream_t)stream);
+}
+
+static int fill_drag(const ishap_drag_args* a, DragArgs& d) {
+  ISHAP_REQUIRE(a && a->chmap && a->sources && a->targets && a->touched && a->nmask && a->acc, "null argument");
+  ISHAP_REQUIRE(a->W > 1 && a->B >= 1 && a->r >= 0 && a->Cc >= 1 && a->ld >= 1, "drag dims");
+  d.W = a->W; d.ld = a->ld; d.Cc = a->Cc; d.chmap = a->chmap; d.sources = a->sources; d.targets = a->targets;
+  d.B = a->B; d.r = a->r; d.voxel = a->voxel; d.cof = a->cof; d.l1 = a->l1;
+  d.touched = a->touched; d.nmask = a->nmask; d.acc = a->acc;
+  return 0;
+}
+
+int ishap_drag_setup(const ishap_drag_args* a, void* stream) {
+  DragArgs d;
+  ISHAP_TRY(fill_drag(a, d));
+  return drag_setup_launch(d, (hipStream_t)stream);
+}
+
+int ishap_drag_loss_grad(const ishap_drag_args* a, const void* edit, const void* orig, float* grad, float* loss,
+                         void* stream) {
+  DragArgs d;
+  ISHAP_TRY(fill_drag(a, d));
+  ISHAP_REQUIRE(edit && orig && grad && loss, "null argument");
+  d.edit = (const half_t*)edit; d.orig = (const half_t*)orig; d.grad = grad; d.loss = loss;
+  return drag_loss_grad_launch(d, (hipStream_t)stream);
+}
+
+int ishap_grad_to_scaled_f16(const float* grad, void* out_f16, unsigned* bits, float* scale2, long long numel,
+                             void* stream) {
+  ISHAP_REQUIRE(grad && out_f16 && bits && scale2, "null argument");
+  return grad_to_scaled_f16_launch(grad, (half_t*)out_f16, bits, scale2, numel, (hipStream_t)stream);
+}
+
+int ishap_planes_prepare(const float* latent, const float* range, const float* middle, int S, float* planes,
+                         void* stream) {
+  ISHAP_REQUIRE(latent && planes, "null argument");
+  return planes_prepare_launch(latent, range, middle, planes, S, (hipStream_t)stream);
+}
+
+static int fill_dec(const ishap_decoder_weights* w, DecodeArgs& d) {
+  ISHAP_REQUIRE(w && w->B && w->W1 && w->b1 && w->W2 && w->b2 && w->w3 && w->b3, "null decoder weights");
+  d.B = w->B; d.W1 = w->W1; d.b1 = w->b1; d.W2 = w->W2; d.b2 = w->b2; d.w3 = w->w3; d.b3 = w->b3;
+  return 0;
+}
+
+int ishap_triplane_decode_points(const float* planes, int S, const ishap_decoder_weights* w, const float* coords,
+                                 long long npts, float* logits, void* stream) {
+  DecodeArgs d;
+  ISHAP_TRY(fill_dec(w, d));
+  ISHAP_REQUIRE(planes && coords && logits, "null argument");
+  d.planes = planes; d.S = S; d.coords = coords; d.npts = npts; d.out = logits;
+  return triplane_decode_launch(d, (hipStream_t)stream);
+}
+
+int ishap_triplane_decode_grid(const float* planes, int S, const ishap_decoder_weights* w, const float* axis, int res,
+                               float* volume, void* stream) {
+  DecodeArgs d;
+  ISHAP_TRY(fill_dec(w, d));
+  ISHAP_REQUIRE(planes && axis && volume && res > 0, "null argument");
+  d.planes = planes; d.S = S; d.lin = axis; d.res = res; d.npts = (long long)res * res * res; d.out = volume;
+  return triplane_decode_launch(d, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// Shared declarations for libishap_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// thread-local last error, never throw across the C ABI
+void ishap_set_error(const std::string& msg);
+
+#define ISHAP_CHECK_HIP(expr)                                                              \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      ishap_set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " at " +         \
+                      __FILE__ + ":" + std::to_string(__LINE__));                          \
+      return -1;                                                                           \
+    }                                                                                      \
+  } while (0)
+
+#define ISHAP_REQUIRE(cond, msg)                                                           \
+  do {                                                                                     \
+    if (!(cond)) {                                                                         \
+      ishap_set_error(std::string("requirement failed: ") + #cond + " -- " + (msg) +       \
+                      " at " + __FILE__ + ":" + std::to_string(__LINE__));                 \
+      return -2;                                                                           \
+    }                                                                                      \
+  } while (0)
+
+#define ISHAP_TRY(expr)        \
+  do {                         \
+    int _r = (expr);           \
+    if (_r != 0) return _r;    \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------
+// implicit GEMM (igemm.hip):  out[m][n] = alpha * sum_k X(m,k) * Wt[n][k]  (+bias[n]) (+res[m][n])
+//   X is either a row-major matrix (MODE_GEMM) or an NHWC feature map gathered as 3x3 patches
+//   with zero padding (MODE_CONV3, k = tap*Cin + c).  fp16 operands, fp32 accumulation on MFMA.
+// ---------------------------------------------------------------------------------------
+enum { IG_OUT_F16 = 0, IG_OUT_F32 = 1, IG_OUT_NCHW_F32 = 2 };
+
+struct IgemmArgs {
+  const half_t* X = nullptr;   // activations
+  const half_t* Wt = nullptr;  // [Npad][K] (K contiguous), rows >= N are zero
+  void* out = nullptr;
+  const float* bias = nullptr;   // [N] or null
+  const half_t* res = nullptr;   // residual [M][ldr] or null (may alias out)
+  float* ws = nullptr;           // split-K workspace [ksplit][nbatch][M][N] fp32
+  int M = 0, N = 0, K = 0;
+  int conv3 = 0;                 // 0: plain rows, 1: 3x3 gather
+  int Cin = 0;                   // channels per tap (conv3) -- K = 9*Cin
+  int ldx = 0, ldw = 0, ldo = 0, ldr = 0;
+  long long bsx = 0, bsw = 0, bso = 0;   // per-batch strides (elements)
+  int nbatch = 1;
+  int H = 0, W = 0;              // OUTPUT spatial size (conv3)
+  int ups = 0;                   // conv3 source map is (H/2, W/2): nearest-neighbour upsample on the fly
+  int res_ups = 0;               // residual map is (H/2, W/2)
+  int ksplit = 1;
+  float alpha = 1.f;
+  int out_mode = IG_OUT_F16;
+};
+int igemm_launch(const IgemmArgs& a, hipStream_t s);
+// picks a split so the grid fills the chip; returns workspace floats needed
+int igemm_pick_ksplit(int M, int N, int K, int nbatch);

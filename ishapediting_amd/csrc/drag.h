@@ -1,0 +1,24 @@
+#pragma once
+#include "common.h"
+#include <algorithm>
+
+struct DragArgs {
+  const half_t* edit = nullptr;    // current tap, NHWC fp16 [W*W][ld]
+  const half_t* orig = nullptr;    // cached guidance tap, same layout
+  int W = 0, ld = 0;               // feature-map side, channels of the tap
+  int Cc = 0;                      // channels per plane after resize_feat_align (170 for a 512-ch tap)
+  const int* chmap = nullptr;      // [3][Cc] -> channel of the tap
+  const float* sources = nullptr;  // [B][3]
+  const float* targets = nullptr;  // [B][3]
+  int B = 0, r = 0;
+  float voxel = 0.f, cof = 0.f;
+  int l1 = 0;
+  unsigned char* touched = nullptr;  // [3][W][W]
+  int* nmask = nullptr;              // [1]
+  float* grad = nullptr;             // fp32 [W*W][ld] (d loss / d tap)
+  float* acc = nullptr;              // [2] scratch sums
+  float* loss = nullptr;             // [1]
+};
+int drag_setup_launch(const DragArgs& a, hipStream_t s);        // touched bitmap + mask count (once per edit)
+int drag_loss_grad_launch(const DragArgs& a, hipStream_t s);
+int grad_to_scaled_f16_launch(const float* g, half_t* o, unsigned* bits, float* scale2, long long n, hipStream_t s);

@@ -1,0 +1,291 @@
+// Implicit-GEMM on the CDNA4 matrix cores: every 3x3 / 1x1 convolution of the UNet
+// (reference: guided_diffusion/unet.py:185,211,222,286,294,482,615 -- all stock
+// torch conv ops there) and every attention matmul (unet.py:349-353) runs through
+// this one kernel family.
+//
+//   D[n][m] = sum_k Wt[n][k] * X(m,k)        (fp16 operands, fp32 accumulate)
+//
+// m = output pixel (NHWC row), n = output channel, k = tap*Cin + c.  The weight tile is
+// the MFMA "A" operand and the pixel tile the "B" operand, so each lane ends up holding
+// 4 consecutive output channels of one pixel: an 8-byte NHWC store, no shuffle.
+//
+// Block = 256 threads = 4 waves (WM x WN).  Tiles are staged global -> registers -> LDS
+// (double-buffered, one barrier per K-step); the 16-byte chunk index is XOR-swizzled with
+// (row>>1) so both the ds_write_b128 and the ds_read_b128 fragment reads are
+// bank-conflict free (lane-group table of the gfx950 LDS).
+#include "common.h"
+
+template <int BM, int BN, int BK, int WM, int WN, bool CONV3>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
+  constexpr int CPR = BK / 8;               // 16-byte chunks per tile row
+  constexpr int XL = BM * CPR / 256;        // chunks per thread, X tile
+  constexpr int WL = BN * CPR / 256;
+  constexpr int TMW = BM / WM, TNW = BN / WN;
+  constexpr int MT = TMW / 16, NT = TNW / 16;
+  static_assert(XL >= 1 && WL >= 1, "tile too small for 256 threads");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  half_t* sX = reinterpret_cast<half_t*>(smem_raw);          // [2][BM*BK]
+  half_t* sW = sX + 2 * BM * BK;                             // [2][BN*BK]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int batch = blockIdx.z / a.ksplit;
+  const int ks_id = blockIdx.z % a.ksplit;
+
+  const half_t* X = a.X + (long long)batch * a.bsx;
+  const half_t* Wt = a.Wt + (long long)batch * a.bsw;
+
+  const int KS = a.K / BK;
+  const int per = (KS + a.ksplit - 1) / a.ksplit;
+  const int ks0 = ks_id * per;
+  const int ks1 = min(KS, ks0 + per);
+  const int steps_per_tap = CONV3 ? a.Cin / BK : KS;
+  const int HW = a.H * a.W;
+
+  // per-thread loader coordinates
+  int xrow[XL], xch[XL], xn[XL], xy[XL], xx[XL];
+#pragma unroll
+  for (int i = 0; i < XL; ++i) {
+    int idx = tid + i * 256;
+    xrow[i] = idx / CPR;
+    xch[i] = idx % CPR;
+    int m = m0 + xrow[i];
+    if (CONV3) {
+      xn[i] = m / HW;
+      int p = m - xn[i] * HW;
+      xy[i] = p / a.W;
+      xx[i] = p - xy[i] * a.W;
+    } else {
+      xn[i] = m; xy[i] = 0; xx[i] = 0;
+    }
+  }
+  int wrow[WL], wch[WL];
+#pragma unroll
+  for (int i = 0; i < WL; ++i) {
+    int idx = tid + i * 256;
+    wrow[i] = idx / CPR;
+    wch[i] = idx % CPR;
+  }
+
+  half8 rx[XL], rw[WL];
+  auto load_tiles = [&](int ks) {
+    int tap = 0, c0;
+    if (CONV3) { tap = ks / steps_per_tap; c0 = (ks - tap * steps_per_tap) * BK; }
+    else c0 = ks * BK;
+    const int dy = CONV3 ? tap / 3 - 1 : 0;
+    const int dx = CONV3 ? tap % 3 - 1 : 0;
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (CONV3) {
+        int yy = xy[i] + dy, xc = xx[i] + dx;
+        if (yy >= 0 && yy < a.H && xc >= 0 && xc < a.W) {
+          long long src;
+          if (a.ups) src = (long long)xn[i] * (HW >> 2) + (yy >> 1) * (a.W >> 1) + (xc >> 1);
+          else src = (long long)xn[i] * HW + yy * a.W + xc;
+          v = *reinterpret_cast<const half8*>(X + src * a.ldx + c0 + xch[i] * 8);
+        }
+      } else {
+        v = *reinterpret_cast<const half8*>(X + (long long)xn[i] * a.ldx + c0 + xch[i] * 8);
+      }
+      rx[i] = v;
+    }
+    const int kofs = CONV3 ? tap * a.Cin + c0 : c0;
+#pragma unroll
+    for (int i = 0; i < WL; ++i)
+      rw[i] = *reinterpret_cast<const half8*>(Wt + (long long)(n0 + wrow[i]) * a.ldw + kofs + wch[i] * 8);
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      int ph = xch[i] ^ ((xrow[i] >> 1) & (CPR - 1));
+      *reinterpret_cast<half8*>(sX + buf * BM * BK + xrow[i] * BK + ph * 8) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      int ph = wch[i] ^ ((wrow[i] >> 1) & (CPR - 1));
+      *reinterpret_cast<half8*>(sW + buf * BN * BK + wrow[i] * BK + ph * 8) = rw[i];
+    }
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (ks0 < ks1) {
+    load_tiles(ks0);
+    store_tiles(0);
+    __syncthreads();
+    int buf = 0;
+    for (int ks = ks0; ks < ks1; ++ks) {
+      const bool more = ks + 1 < ks1;
+      if (more) load_tiles(ks + 1);
+      const half_t* bx = sX + buf * BM * BK;
+      const half_t* bw = sW + buf * BN * BK;
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        half8 xf[MT], wf[NT];
+        const int ch = (lane >> 4) + 4 * kk;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          int row = wm * TMW + j * 16 + (lane & 15);
+          xf[j] = *reinterpret_cast<const half8*>(bx + row * BK + ((ch ^ ((row >> 1) & (CPR - 1))) * 8));
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          int row = wn * TNW + i * 16 + (lane & 15);
+          wf[i] = *reinterpret_cast<const half8*>(bw + row * BK + ((ch ^ ((row >> 1) & (CPR - 1))) * 8));
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < MT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) store_tiles(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // ---- epilogue: lane holds channels n..n+3 of pixel m ----
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int m = m0 + wm * TMW + j * 16 + (lane & 15);
+    int n_img = 0, py = 0, px = 0;
+    if (a.res_ups || a.out_mode == IG_OUT_NCHW_F32) {
+      n_img = m / HW;
+      int p = m - n_img * HW;
+      py = p / a.W;
+      px = p - py * a.W;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = n0 + wn * TNW + i * 16 + (lane >> 4) * 4;
+      if (n >= a.N) continue;
+      f32x4 v = acc[i][j];
+      if (a.ksplit > 1) {
+        float* dst = a.ws + (((long long)ks_id * a.nbatch + batch) * a.M + m) * a.N + n;
+        *reinterpret_cast<f32x4*>(dst) = v;
+        continue;
+      }
+      v *= a.alpha;
+      if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+      if (a.res) {
+        long long rrow = a.res_ups ? ((long long)n_img * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1)) : m;
+        half4 r = *reinterpret_cast<const half4*>(a.res + rrow * a.ldr + n);
+        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+      }
+      if (a.out_mode == IG_OUT_F16) {
+        half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<half4*>((half_t*)a.out + (long long)batch * a.bso + (long long)m * a.ldo + n) = o;
+      } else if (a.out_mode == IG_OUT_F32) {
+        *reinterpret_cast<f32x4*>((float*)a.out + (long long)batch * a.bso + (long long)m * a.ldo + n) = v;
+      } else {
+        float* o = (float*)a.out + ((long long)n_img * a.N + n) * HW + (py * a.W + px);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(long long)r * HW] = v[r];
+      }
+    }
+  }
+}
+
+// out = alpha * sum_z ws[z] (+bias)(+res); one thread per 4 channels
+__global__ void igemm_splitk_reduce(IgemmArgs a) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nq = a.N >> 2;
+  const long long total = (long long)a.nbatch * a.M * nq;
+  if (q >= total) return;
+  const int n = (int)(q % nq) * 4;
+  const long long bm = q / nq;
+  const int m = (int)(bm % a.M);
+  const int batch = (int)(bm / a.M);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < a.ksplit; ++z)
+    v += *reinterpret_cast<const f32x4*>(a.ws + (((long long)z * a.nbatch + batch) * a.M + m) * a.N + n);
+  v *= a.alpha;
+  if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+  const int HW = a.H * a.W;
+  int n_img = 0, py = 0, px = 0;
+  if (a.res_ups || a.out_mode == IG_OUT_NCHW_F32) {
+    n_img = m / HW;
+    int p = m - n_img * HW;
+    py = p / a.W;
+    px = p - py * a.W;
+  }
+  if (a.res) {
+    long long rrow = a.res_ups ? ((long long)n_img * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1)) : m;
+    half4 r = *reinterpret_cast<const half4*>(a.res + rrow * a.ldr + n);
+    v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+  }
+  if (a.out_mode == IG_OUT_F16) {
+    half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    *reinterpret_cast<half4*>((half_t*)a.out + (long long)batch * a.bso + (long long)m * a.ldo + n) = o;
+  } else if (a.out_mode == IG_OUT_F32) {
+    *reinterpret_cast<f32x4*>((float*)a.out + (long long)batch * a.bso + (long long)m * a.ldo + n) = v;
+  } else {
+    float* o = (float*)a.out + ((long long)n_img * a.N + n) * HW + (py * a.W + px);
+    for (int r = 0; r < 4; ++r) o[(long long)r * HW] = v[r];
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool CONV3>
+static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
+  constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(half_t);
+  auto kern = igemm_kernel<BM, BN, BK, WM, WN, CONV3>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ISHAP_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  if (a.ksplit > 1) {
+    long long total = (long long)a.nbatch * a.M * (a.N >> 2);
+    hipLaunchKernelGGL(igemm_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    ISHAP_CHECK_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+int igemm_pick_ksplit(int M, int N, int K, int nbatch) {
+  // aim for >= ~512 workgroups (2 per CU) while keeping >= 4 K-steps of 64 per slice
+  int bm = (M % 128 == 0 && M >= 1024) ? 128 : 64;
+  int bn = (N >= 128 && bm == 128) ? 128 : 64;
+  long long blocks = (long long)(M / bm) * ceil_div(N, bn) * nbatch;
+  int ks = K / 64;
+  int split = 1;
+  while (blocks * split < 512 && ks / (split * 2) >= 4 && split < 32) split *= 2;
+  return split;
+}
+
+int igemm_launch(const IgemmArgs& a, hipStream_t s) {
+  ISHAP_REQUIRE(a.M % 64 == 0, "M must be a multiple of 64");
+  ISHAP_REQUIRE(a.N % 4 == 0, "N must be a multiple of 4");
+  ISHAP_REQUIRE(a.K % 32 == 0, "K must be a multiple of 32");
+  ISHAP_REQUIRE(!a.conv3 || (a.Cin % 32 == 0 && a.K == 9 * a.Cin), "conv3: K = 9*Cin, Cin % 32 == 0");
+  ISHAP_REQUIRE(a.ksplit == 1 || a.ws != nullptr, "split-K needs a workspace");
+  ISHAP_REQUIRE(a.ldx % 8 == 0 && a.ldw % 8 == 0, "row strides must keep 16-byte alignment");
+  const bool k64 = a.conv3 ? (a.Cin % 64 == 0) : (a.K % 64 == 0);
+  const bool big = (a.M % 128 == 0) && a.M >= 1024 && a.N >= 128;
+#define IG_DISPATCH(BM, BN, WM_, WN_)                                                          \
+  do {                                                                                         \
+    if (a.conv3) {                                                                             \
+      if (k64) return launch_cfg<BM, BN, 64, WM_, WN_, true>(a, s);                            \
+      return launch_cfg<BM, BN, 32, WM_, WN_, true>(a, s);                                     \
+    } else {                                                                                   \
+      if (k64) return launch_cfg<BM, BN, 64, WM_, WN_, false>(a, s);                           \
+      return launch_cfg<BM, BN, 32, WM_, WN_, false>(a, s);                                    \
+    }                                                                                          \
+  } while (0)
+  if (big) IG_DISPATCH(128, 128, 2, 2);
+  IG_DISPATCH(64, 64, 2, 2);
+#undef IG_DISPATCH
+}

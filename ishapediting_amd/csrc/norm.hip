@@ -1,0 +1,205 @@
+// GroupNorm(32) over NHWC fp16 maps, statistics in fp32/fp64, and the fused
+// normalise -> (FiLM) -> (SiLU) -> (2x2 average pool) pass that feeds each convolution.
+// Reference: guided_diffusion/nn.py:16-18,92-99 (GroupNorm32 computes on x.float() and casts
+// back), unet.py:236-252 (ResBlock: in_layers / h_upd / FiLM `gn(h)*(1+scale)+shift` / SiLU),
+// unet.py:129-140 (AvgPool2d(2,2) used by resblock_updown).
+//
+// HBM-bound elementwise work: every thread moves 16-byte vectors of 8 channels; statistics are a
+// two-stage deterministic reduction (per-row-chunk partial sums per channel, then one block per
+// (image, group) combining them in double) -- no float atomics, bitwise reproducible.
+#include "norm.h"
+
+// ---------------------------------------------------------------------------------------------
+// statistics
+// ---------------------------------------------------------------------------------------------
+// partial[n][blk][C][2]  (sum, sum of squares) over this block's rows
+__global__ __launch_bounds__(256) void gn_partial_kernel(const half_t* __restrict__ x, float* __restrict__ partial,
+                                                         int HW, int C, int rows_per_block) {
+  extern __shared__ float red[];                 // [rpi][C][2]
+  const int CV = C >> 3;
+  const int rpi = 256 / CV > 0 ? 256 / CV : 1;   // rows handled per iteration
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y;
+  const int blk = blockIdx.x;
+  const int row0 = blk * rows_per_block;
+  const bool active = tid < rpi * CV;
+  const int cv = tid % CV, r0 = tid / CV;
+  float s[8], q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
+  if (active) {
+    const half_t* base = x + ((long long)n * HW + row0) * C + cv * 8;
+    for (int r = r0; r < rows_per_block; r += rpi) {
+      half8 v = *reinterpret_cast<const half8*>(base + (long long)r * C);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { float f = (float)v[i]; s[i] += f; q[i] += f * f; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      red[((r0 * C) + cv * 8 + i) * 2 + 0] = s[i];
+      red[((r0 * C) + cv * 8 + i) * 2 + 1] = q[i];
+    }
+  }
+  __syncthreads();
+  float* out = partial + ((long long)n * gridDim.x + blk) * C * 2;
+  for (int c = tid; c < C * 2; c += 256) {
+    float acc = 0.f;
+    for (int r = 0; r < rpi; ++r) acc += red[r * C * 2 + c];
+    out[c] = acc;
+  }
+}
+
+// stats[n][32][2] = (mean, rstd)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+                                                          int nblk, int C, int HW, float eps) {
+  __shared__ double sh[2][256];
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int cpg = C / 32;
+  const int tid = threadIdx.x;
+  double s = 0.0, q = 0.0;
+  const int total = nblk * cpg;
+  for (int i = tid; i < total; i += 256) {
+    int b = i / cpg, c = g * cpg + i % cpg;
+    const float* p = partial + (((long long)n * nblk + b) * C + c) * 2;
+    s += (double)p[0];
+    q += (double)p[1];
+  }
+  sh[0][tid] = s; sh[1][tid] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double cnt = (double)HW * cpg;
+    double mean = sh[0][0] / cnt;
+    double var = sh[1][0] / cnt - mean * mean;
+    if (var < 0) var = 0;
+    stats[(n * 32 + g) * 2 + 0] = (float)mean;
+    stats[(n * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+int gn_stats_launch(const half_t* x, float* partial, float* stats, int N, int HW, int C, hipStream_t s) {
+  ISHAP_REQUIRE(C % 32 == 0 && C / 8 <= 256, "GroupNorm channels: multiple of 32, at most 2048");
+  int rpb = gn_rows_per_block(HW);
+  int nblk = HW / rpb;
+  int CV = C / 8;
+  int rpi = 256 / CV > 0 ? 256 / CV : 1;
+  size_t smem = (size_t)rpi * C * 2 * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    ISHAP_CHECK_HIP(hipFuncSetAttribute((const void*)gn_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    attr = true;
+  }
+  ISHAP_REQUIRE(smem <= 65536, "gn_partial LDS");
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, N), dim3(256), smem, s, x, partial, HW, C, rpb);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, N), dim3(256), 0, s, partial, stats, nblk, C, HW, 1e-5f);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// apply
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+__device__ __forceinline__ float rh(float v) { return (float)(half_t)v; }   // round through fp16
+
+// One thread = 8 channels of one OUTPUT pixel.
+//  FILM: y = fp16(fp16(gn)*fp16(1+scale)) + shift   (fp16 arithmetic like the reference's half tensors)
+//  ACT : SiLU
+//  POOL: output pixel = mean of the 2x2 activated input pixels; also writes pooled raw x to xpool
+//  SPLIT: fp32-grade output for the fp32 head: writes [hi | lo | hi] fp16 channel blocks (3*C wide)
+template <bool FILM, bool ACT, bool POOL, bool SPLIT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
+  const int CV = a.C >> 3;
+  const int HWo = POOL ? (a.H >> 1) * (a.W >> 1) : a.H * a.W;
+  const long long total = (long long)a.N * HWo * CV;
+  const int cpg = a.C / 32;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % CV);
+    const long long pix = idx / CV;
+    const int n = (int)(pix / HWo);
+    const int p = (int)(pix % HWo);
+    const int c0 = cv * 8;
+    float gam[8], bet[8], mu[8], rs[8], sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int c = c0 + i;
+      int g = c / cpg;
+      gam[i] = a.gamma[c];
+      bet[i] = a.beta[c];
+      mu[i] = a.stats[(n * 32 + g) * 2];
+      rs[i] = a.stats[(n * 32 + g) * 2 + 1];
+      if (FILM) {
+        sc[i] = rh(1.f + rh(a.emb[(long long)n * a.emb_ld + c]));
+        sh[i] = rh(a.emb[(long long)n * a.emb_ld + a.C + c]);
+      }
+    }
+    auto one = [&](const half8& v, float* o) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float y = ((float)v[i] - mu[i]) * rs[i] * gam[i] + bet[i];
+        if (!SPLIT) y = rh(y);
+        if (FILM) y = rh(rh(y * sc[i]) + sh[i]);
+        if (ACT) { y = silu_f(y); if (!SPLIT) y = rh(y); }
+        o[i] = y;
+      }
+    };
+    float o[8];
+    if (POOL) {
+      const int Wo = a.W >> 1;
+      const int yo = p / Wo, xo = p % Wo;
+      float acc[8], xacc[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { acc[i] = 0.f; xacc[i] = 0.f; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        long long src = (long long)n * a.H * a.W + (2 * yo + (q >> 1)) * a.W + 2 * xo + (q & 1);
+        half8 v = *reinterpret_cast<const half8*>(a.x + src * a.C + c0);
+        float t[8];
+        one(v, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[i] += t[i]; xacc[i] += (float)v[i]; }
+      }
+      half8 ov, xv;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { ov[i] = (half_t)(acc[i] * 0.25f); xv[i] = (half_t)(xacc[i] * 0.25f); }
+      *reinterpret_cast<half8*>(a.out + pix * a.C + c0) = ov;
+      if (a.xpool) *reinterpret_cast<half8*>(a.xpool + pix * a.C + c0) = xv;
+    } else {
+      half8 v = *reinterpret_cast<const half8*>(a.x + pix * a.C + c0);
+      one(v, o);
+      if (SPLIT) {
+        half8 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { hi[i] = (half_t)o[i]; lo[i] = (half_t)(o[i] - (float)hi[i]); }
+        half_t* dst = a.out + pix * (3LL * a.C);
+        *reinterpret_cast<half8*>(dst + c0) = hi;
+        *reinterpret_cast<half8*>(dst + a.C + c0) = lo;
+        *reinterpret_cast<half8*>(dst + 2 * a.C + c0) = hi;
+      } else {
+        half8 ov;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ov[i] = (half_t)o[i];
+        *reinterpret_cast<half8*>(a.out + pix * a.C + c0) = ov;
+      }
+    }
+  }
+}
+
+int gn_apply_launch(const GnApplyArgs& a, hipStream_t s) {
+  const int HWo = a.pool ? (a.H / 2) * (a.W / 2) : a.H * a.W;
+  long long total = (long long)a.N * HWo * (a.C / 8);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  dim3 g(blocks), b(256);
+  if (a.split) hipLaunchKernelGGL((gn_apply_kernel<false, true, false, true>), g, b, 0, s, a);
+  else if (a.pool) hipLaunchKernelGGL((gn_apply_kernel<false, true, true, false>), g, b, 0, s, a);
+  else if (a.film) hipLaunchKernelGGL((gn_apply_kernel<true, true, false, false>), g, b, 0, s, a);
+  else if (a.act) hipLaunchKernelGGL((gn_apply_kernel<false, true, false, false>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((gn_apply_kernel<false, false, false, false>), g, b, 0, s, a);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,142 @@
+// UNet graph + executor (host side).  Structure mirrors guided_diffusion/unet.py:427-616.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ishap.h"
+#include "common.h"
+
+struct Tensor {
+  half_t* p = nullptr;
+  int N = 0, H = 0, W = 0, C = 0;
+  long long rows() const { return (long long)N * H * W; }
+  long long numel() const { return rows() * C; }
+};
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, high = 0;
+  bool dry = false;
+  void reset() { off = 0; }
+  void* alloc(size_t bytes) {
+    size_t o = align_up(off, 256);
+    off = o + bytes;
+    if (off > high) high = off;
+    if (dry) return (void*)(uintptr_t)(0x1000 + o);
+    if (off > cap) return nullptr;
+    return base + o;
+  }
+};
+
+struct ConvW {
+  std::string path;
+  int cin = 0, cout = 0, taps = 9;
+  int kpad = 0;        // channels per tap in the packed forward operand
+  half_t* w = nullptr;   // [rows_pad(cout)][taps*kpad]
+  half_t* wT = nullptr;  // [rows_pad(cin)][taps*cout_pad]  (input-gradient operand)
+  int cout_pad = 0;
+  float* bias = nullptr;
+  bool split = false;    // fp32 head: [hi|hi|lo] packing, kpad = 3*cin
+};
+struct NormW {
+  float* gamma = nullptr;
+  float* beta = nullptr;
+  int C = 0;
+};
+
+struct ResSaved {   // what the backward pass re-reads
+  Tensor x, h1, xs;     // block input, conv1 output, (pooled / plain) skip input
+  float* stats1 = nullptr;
+  float* stats2 = nullptr;
+};
+struct AttnSaved {
+  Tensor x, qkv, a;
+  float* stats = nullptr;
+  float* lse = nullptr;
+};
+
+struct ResL {
+  std::string path;
+  int cin = 0, cout = 0;
+  bool up = false, down = false;
+  NormW n1, n2;
+  ConvW c1, c2, skip;
+  bool has_skip = false;
+  int emb_off = 0;     // row offset into the concatenated emb_layers matrix (2*cout rows)
+  ResSaved sv;
+};
+struct AttnL {
+  std::string path;
+  int C = 0, heads = 0;
+  NormW n;
+  ConvW qkv, proj;
+  AttnSaved sv;
+};
+struct LayerRef { int kind; int idx; };   // 0 conv(stem) 1 res 2 attn
+struct BlockL {
+  std::string name;
+  std::vector<LayerRef> layers;
+  int cin = 0, cout = 0, res_in = 0, res_out = 0, skip_ch = 0;
+  Tensor out;       // block output of the last forward
+  Tensor cat;       // concat input (output blocks)
+};
+
+struct ParamSlot {
+  std::string name;
+  int ndim = 0;
+  long long shape[4] = {0, 0, 0, 0};
+  int kind = 0;     // 0 conv weight, 1 conv bias, 2 plain fp32 vector/matrix copy, 3 emb weight, 4 emb bias
+  ConvW* conv = nullptr;
+  float* dst = nullptr;
+  long long dst_off = 0;
+  bool loaded = false;
+  long long numel() const {
+    long long n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    return n;
+  }
+};
+
+struct ishap_unet {
+  ishap_unet_config cfg;
+  int device = 0;
+  int ted = 0;                 // time_embed_dim
+  int in_pad = 0;              // padded input channels of the stem
+  ConvW stem, head;
+  NormW head_norm;
+  std::vector<ResL> res;
+  std::vector<AttnL> attn;
+  std::vector<BlockL> in_blocks, out_blocks;
+  BlockL mid;
+  int final_ch = 0;
+  // embeddings
+  float *te_w0 = nullptr, *te_b0 = nullptr, *te_w2 = nullptr, *te_b2 = nullptr;
+  float *emb_w = nullptr, *emb_b = nullptr;   // concatenated emb_layers [film_rows][ted]
+  int film_rows = 0;
+  float *d_temb = nullptr, *d_e1 = nullptr, *d_emb = nullptr, *d_film = nullptr;
+  // parameter table
+  std::vector<ParamSlot> params;
+  std::map<std::string, int> param_index;
+  int n_loaded = 0;
+  // memory
+  Arena arena;
+  float* ws = nullptr;          size_t ws_floats = 0;       // split-K partials
+  float* gn_partial = nullptr;  size_t gn_partial_floats = 0;
+  float* attn_S = nullptr;      size_t attn_S_floats = 0;
+  half_t* attn_P = nullptr;
+  half_t* attn_T = nullptr;     size_t attn_T_halfs = 0;    // transposed head operands (4 slots)
+  half_t* attn_dS = nullptr;                                // backward scratch (same size as P), 2 slots
+  // last forward
+  int last_N = 0, last_feat = -1;
+  bool have_saved = false;
+  Tensor tap;
+  Tensor x0, h_final;
+  float* head_stats = nullptr;
+};
+
+int unet_build(ishap_unet* u);
+int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int feat_layer, float* out,
+                      void* inter_feat, int keep, hipStream_t s, bool dry);
+int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const float* cot_out, const float* scale2, float* dx,
+                       hipStream_t s, bool dry);

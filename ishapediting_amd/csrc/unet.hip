@@ -1,0 +1,595 @@
+// UNet graph construction, parameter loading and the forward executor.
+// Reference structure: guided_diffusion/unet.py:427-616 (constructor), :634-671 (forward),
+// :236-256 (ResBlock), :299-305 + :337-354 (AttentionBlock, legacy qkv order).
+// One C call runs the whole network: ~500 kernel launches on the caller's stream, no host sync.
+#include "unet.h"
+
+#include <cstring>
+
+#include "decode.h"
+#include "misc.h"
+#include "norm.h"
+
+static int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ------------------------------------------------------------------------------------------------
+// graph
+// ------------------------------------------------------------------------------------------------
+static void init_conv(ConvW& c, const std::string& path, int cin, int cout, int taps) {
+  c.path = path; c.cin = cin; c.cout = cout; c.taps = taps;
+  c.kpad = round_up(cin, 32);
+  c.cout_pad = round_up(cout, 32);
+}
+
+int unet_build(ishap_unet* u) {
+  const ishap_unet_config& cfg = u->cfg;
+  const int mc = cfg.model_channels;
+  u->ted = mc * 4;
+  u->in_pad = round_up(cfg.in_channels, 32);
+  auto has_att = [&](int ds) {
+    for (int i = 0; i < cfg.n_att; ++i) if (cfg.attention_ds[i] == ds) return true;
+    return false;
+  };
+  auto heads_of = [&](int ch) { return ch / cfg.num_head_channels; };
+  // count layers first so the vectors never reallocate (ParamSlot keeps pointers into them)
+  u->res.reserve(256);
+  u->attn.reserve(64);
+  int film = 0;
+  auto add_res = [&](const std::string& path, int cin, int cout, bool up, bool down) {
+    ResL r;
+    r.path = path; r.cin = cin; r.cout = cout; r.up = up; r.down = down;
+    r.n1.C = cin; r.n2.C = cout;
+    init_conv(r.c1, path + ".in_layers.2", cin, cout, 9);
+    init_conv(r.c2, path + ".out_layers.3", cout, cout, 9);
+    r.has_skip = cin != cout;
+    if (r.has_skip) init_conv(r.skip, path + ".skip_connection", cin, cout, 1);
+    r.emb_off = film;
+    film += 2 * cout;
+    u->res.push_back(r);
+    return (int)u->res.size() - 1;
+  };
+  auto add_attn = [&](const std::string& path, int ch) {
+    AttnL a;
+    a.path = path; a.C = ch; a.heads = heads_of(ch);
+    a.n.C = ch;
+    init_conv(a.qkv, path + ".qkv", ch, 3 * ch, 1);
+    init_conv(a.proj, path + ".proj_out", ch, ch, 1);
+    u->attn.push_back(a);
+    return (int)u->attn.size() - 1;
+  };
+
+  int ch = cfg.channel_mult[0] * mc;
+  int res = cfg.image_size;
+  init_conv(u->stem, "input_blocks.0.0", cfg.in_channels, ch, 9);
+  {
+    BlockL b;
+    b.name = "input_blocks.0";
+    b.layers.push_back({0, 0});
+    b.cin = cfg.in_channels; b.cout = ch; b.res_in = b.res_out = res;
+    u->in_blocks.push_back(b);
+  }
+  std::vector<int> chans{ch};
+  int ds = 1;
+  for (int level = 0; level < cfg.n_mult; ++level) {
+    for (int k = 0; k < cfg.num_res_blocks; ++k) {
+      BlockL b;
+      b.name = "input_blocks." + std::to_string(u->in_blocks.size());
+      int cout = cfg.channel_mult[level] * mc;
+      b.layers.push_back({1, add_res(b.name + ".0", ch, cout, false, false)});
+      b.cin = ch; ch = cout; b.cout = ch; b.res_in = b.res_out = res;
+      if (has_att(ds)) b.layers.push_back({2, add_attn(b.name + ".1", ch)});
+      u->in_blocks.push_back(b);
+      chans.push_back(ch);
+    }
+    if (level != cfg.n_mult - 1) {
+      BlockL b;
+      b.name = "input_blocks." + std::to_string(u->in_blocks.size());
+      b.layers.push_back({1, add_res(b.name + ".0", ch, ch, false, true)});
+      b.cin = b.cout = ch; b.res_in = res; b.res_out = res / 2;
+      u->in_blocks.push_back(b);
+      chans.push_back(ch);
+      ds *= 2;
+      res /= 2;
+    }
+  }
+  u->mid.name = "middle_block";
+  u->mid.layers.push_back({1, add_res("middle_block.0", ch, ch, false, false)});
+  u->mid.layers.push_back({2, add_attn("middle_block.1", ch)});
+  u->mid.layers.push_back({1, add_res("middle_block.2", ch, ch, false, false)});
+  u->mid.cin = u->mid.cout = ch; u->mid.res_in = u->mid.res_out = res;
+  for (int level = cfg.n_mult - 1; level >= 0; --level) {
+    for (int i = 0; i < cfg.num_res_blocks + 1; ++i) {
+      int ich = chans.back();
+      chans.pop_back();
+      BlockL b;
+      b.name = "output_blocks." + std::to_string(u->out_blocks.size());
+      int cout = mc * cfg.channel_mult[level];
+      b.layers.push_back({1, add_res(b.name + ".0", ch + ich, cout, false, false)});
+      b.cin = ch + ich; b.skip_ch = ich; ch = cout; b.cout = ch; b.res_in = res;
+      if (has_att(ds)) b.layers.push_back({2, add_attn(b.name + "." + std::to_string(b.layers.size()), ch)});
+      if (level && i == cfg.num_res_blocks) {
+        b.layers.push_back({1, add_res(b.name + "." + std::to_string(b.layers.size()), ch, ch, true, false)});
+        ds /= 2;
+        res *= 2;
+      }
+      b.res_out = res;
+      u->out_blocks.push_back(b);
+    }
+  }
+  u->final_ch = ch;
+  u->film_rows = film;
+  u->head_norm.C = ch;
+  init_conv(u->head, "out.2", ch, cfg.out_channels, 9);
+  u->head.split = true;
+  u->head.kpad = 3 * ch;
+
+  // ---- parameter table (torch state_dict names, gd/unet.py module tree) ----
+  auto reg = [&](const std::string& name, std::initializer_list<long long> shape, int kind, ConvW* conv, float** dst,
+                 long long off) {
+    ParamSlot p;
+    p.name = name; p.ndim = (int)shape.size();
+    int i = 0;
+    for (long long v : shape) p.shape[i++] = v;
+    p.kind = kind; p.conv = conv; p.dst_off = off;
+    p.dst = dst ? *dst : nullptr;
+    u->param_index[name] = (int)u->params.size();
+    u->params.push_back(p);
+  };
+  // device buffers for plain fp32 parameters
+  auto dalloc = [&](float** p, size_t n) -> int {
+    ISHAP_CHECK_HIP(hipMalloc((void**)p, n * sizeof(float)));
+    ISHAP_CHECK_HIP(hipMemset(*p, 0, n * sizeof(float)));
+    return 0;
+  };
+  auto conv_alloc = [&](ConvW& c) -> int {
+    size_t wn = (size_t)round_up(c.cout, 128) * c.taps * c.kpad;
+    ISHAP_CHECK_HIP(hipMalloc((void**)&c.w, wn * sizeof(half_t)));
+    ISHAP_CHECK_HIP(hipMemset(c.w, 0, wn * sizeof(half_t)));
+    size_t tn = (size_t)round_up(round_up(c.cin, 32), 128) * c.taps * c.cout_pad;
+    ISHAP_CHECK_HIP(hipMalloc((void**)&c.wT, tn * sizeof(half_t)));
+    ISHAP_CHECK_HIP(hipMemset(c.wT, 0, tn * sizeof(half_t)));
+    ISHAP_TRY(dalloc(&c.bias, round_up(c.cout, 4)));
+    return 0;
+  };
+  auto reg_conv = [&](ConvW& c) -> int {
+    ISHAP_TRY(conv_alloc(c));
+    if (c.taps == 9) reg(c.path + ".weight", {c.cout, c.cin, 3, 3}, 0, &c, nullptr, 0);
+    else reg(c.path + ".weight", {c.cout, c.cin, 1}, 0, &c, nullptr, 0);
+    reg(c.path + ".bias", {c.cout}, 1, &c, nullptr, 0);
+    return 0;
+  };
+  auto reg_norm = [&](NormW& n, const std::string& path) -> int {
+    ISHAP_TRY(dalloc(&n.gamma, n.C));
+    ISHAP_TRY(dalloc(&n.beta, n.C));
+    reg(path + ".weight", {n.C}, 2, nullptr, &n.gamma, 0);
+    reg(path + ".bias", {n.C}, 2, nullptr, &n.beta, 0);
+    return 0;
+  };
+  const int ted = u->ted;
+  ISHAP_TRY(dalloc(&u->te_w0, (size_t)ted * mc));
+  ISHAP_TRY(dalloc(&u->te_b0, ted));
+  ISHAP_TRY(dalloc(&u->te_w2, (size_t)ted * ted));
+  ISHAP_TRY(dalloc(&u->te_b2, ted));
+  ISHAP_TRY(dalloc(&u->emb_w, (size_t)film * ted));
+  ISHAP_TRY(dalloc(&u->emb_b, film));
+  reg("time_embed.0.weight", {ted, mc}, 2, nullptr, &u->te_w0, 0);
+  reg("time_embed.0.bias", {ted}, 2, nullptr, &u->te_b0, 0);
+  reg("time_embed.2.weight", {ted, ted}, 2, nullptr, &u->te_w2, 0);
+  reg("time_embed.2.bias", {ted}, 2, nullptr, &u->te_b2, 0);
+  // stem is the only stem conv in the skip-less plain form; the skip 1x1 convs are Conv2d [O,I,1,1]
+  ISHAP_TRY(conv_alloc(u->stem));
+  reg("input_blocks.0.0.weight", {u->stem.cout, u->stem.cin, 3, 3}, 0, &u->stem, nullptr, 0);
+  reg("input_blocks.0.0.bias", {u->stem.cout}, 1, &u->stem, nullptr, 0);
+  for (auto& r : u->res) {
+    ISHAP_TRY(reg_norm(r.n1, r.path + ".in_layers.0"));
+    ISHAP_TRY(reg_conv(r.c1));
+    reg(r.path + ".emb_layers.1.weight", {2 * r.cout, ted}, 2, nullptr, &u->emb_w, (long long)r.emb_off * ted);
+    reg(r.path + ".emb_layers.1.bias", {2 * r.cout}, 2, nullptr, &u->emb_b, r.emb_off);
+    ISHAP_TRY(reg_norm(r.n2, r.path + ".out_layers.0"));
+    ISHAP_TRY(reg_conv(r.c2));
+    if (r.has_skip) {
+      ISHAP_TRY(conv_alloc(r.skip));
+      reg(r.skip.path + ".weight", {r.cout, r.cin, 1, 1}, 0, &r.skip, nullptr, 0);
+      reg(r.skip.path + ".bias", {r.cout}, 1, &r.skip, nullptr, 0);
+    }
+  }
+  for (auto& a : u->attn) {
+    ISHAP_TRY(reg_norm(a.n, a.path + ".norm"));
+    ISHAP_TRY(reg_conv(a.qkv));
+    ISHAP_TRY(reg_conv(a.proj));
+  }
+  ISHAP_TRY(reg_norm(u->head_norm, "out.0"));
+  ISHAP_TRY(conv_alloc(u->head));
+  reg("out.2.weight", {u->head.cout, u->head.cin, 3, 3}, 0, &u->head, nullptr, 0);
+  reg("out.2.bias", {u->head.cout}, 1, &u->head, nullptr, 0);
+
+  const int NB = cfg.max_batch;
+  ISHAP_TRY(dalloc(&u->d_temb, (size_t)NB * mc));
+  ISHAP_TRY(dalloc(&u->d_e1, (size_t)NB * ted));
+  ISHAP_TRY(dalloc(&u->d_emb, (size_t)NB * ted));
+  ISHAP_TRY(dalloc(&u->d_film, (size_t)NB * film));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// parameter loading
+// ------------------------------------------------------------------------------------------------
+static int load_param(ishap_unet* u, ParamSlot& p, const float* data, hipStream_t s) {
+  const long long n = p.numel();
+  if (p.kind == 0) {
+    ConvW& c = *p.conv;
+    if (c.split) {
+      ISHAP_TRY(pack_conv_weight_split(data, c.w, c.cout, c.cin, c.taps, round_up(c.cout, 128), s));
+    } else {
+      ISHAP_TRY(pack_conv_weight(data, c.w, c.cout, c.cin, c.taps, round_up(c.cout, 128), c.kpad, 0, s));
+    }
+    ISHAP_TRY(pack_conv_weight(data, c.wT, c.cout, c.cin, c.taps, round_up(round_up(c.cin, 32), 128), c.cout_pad, 1, s));
+  } else if (p.kind == 1) {
+    ConvW& c = *p.conv;
+    if (c.split) ISHAP_CHECK_HIP(hipMemcpyAsync(c.bias, data, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    else ISHAP_TRY(round_through_f16(data, c.bias, n, s));   // torso conv bias is half in the reference (fp16_util.py:19-21)
+  } else {
+    ISHAP_CHECK_HIP(hipMemcpyAsync(p.dst + p.dst_off, data, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// op helpers
+// ------------------------------------------------------------------------------------------------
+struct Exec {
+  ishap_unet* u;
+  hipStream_t s;
+  bool dry;
+};
+
+template <typename T>
+static T* aalloc(Exec& e, size_t count) { return (T*)e.u->arena.alloc(count * sizeof(T)); }
+
+static int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps,
+                   int cout, const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups,
+                   int res_ups) {
+  IgemmArgs a;
+  a.X = X; a.Wt = Wt; a.out = out; a.bias = bias; a.res = res;
+  a.M = N * H * W; a.N = cout; a.K = taps * kpad;
+  a.conv3 = taps == 9; a.Cin = kpad;
+  a.ldx = ldx; a.ldw = taps * kpad; a.ldo = ldo; a.ldr = ldr;
+  a.H = H; a.W = W; a.ups = ups; a.res_ups = res_ups;
+  a.out_mode = out_mode;
+  a.ksplit = igemm_pick_ksplit(a.M, a.N, a.K, 1);
+  size_t need = a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N : 0;
+  if (e.dry) {
+    if (need > e.u->ws_floats) e.u->ws_floats = need;
+    return 0;
+  }
+  ISHAP_REQUIRE(need <= e.u->ws_floats, "split-K workspace too small");
+  a.ws = e.u->ws;
+  return igemm_launch(a, e.s);
+}
+
+static int gn_stats_op(Exec& e, const Tensor& x, float* stats) {
+  size_t need = gn_partial_floats(x.N, x.H * x.W, x.C);
+  if (e.dry) {
+    if (need > e.u->gn_partial_floats) e.u->gn_partial_floats = need;
+    return 0;
+  }
+  return gn_stats_launch(x.p, e.u->gn_partial, stats, x.N, x.H * x.W, x.C, e.s);
+}
+
+static int res_forward(Exec& e, ResL& L, const Tensor& x, Tensor& y) {
+  ishap_unet* u = e.u;
+  const int N = x.N, H = x.H, W = x.W;
+  const int Ho = L.down ? H / 2 : (L.up ? H * 2 : H), Wo = L.down ? W / 2 : (L.up ? W * 2 : W);
+  ISHAP_REQUIRE(x.C == L.cin, "ResBlock input channels");
+  float* st1 = aalloc<float>(e, (size_t)N * 64);
+  float* st2 = aalloc<float>(e, (size_t)N * 64);
+  ISHAP_TRY(gn_stats_op(e, x, st1));
+  Tensor a{nullptr, N, L.down ? Ho : H, L.down ? Wo : W, L.cin};
+  a.p = aalloc<half_t>(e, a.numel());
+  Tensor xs = x;
+  if (L.down) { xs = a; xs.p = aalloc<half_t>(e, a.numel()); }
+  if (!e.dry) {
+    GnApplyArgs g;
+    g.x = x.p; g.out = a.p; g.xpool = L.down ? xs.p : nullptr;
+    g.stats = st1; g.gamma = L.n1.gamma; g.beta = L.n1.beta;
+    g.N = N; g.H = H; g.W = W; g.C = L.cin; g.act = 1; g.pool = L.down;
+    ISHAP_TRY(gn_apply_launch(g, e.s));
+  }
+  Tensor h1{nullptr, N, Ho, Wo, L.cout};
+  h1.p = aalloc<half_t>(e, h1.numel());
+  ISHAP_TRY(conv_op(e, a.p, N, Ho, Wo, L.cin, L.c1.w, L.c1.kpad, 9, L.cout, L.c1.bias, nullptr, 0, h1.p, L.cout, IG_OUT_F16,
+                    L.up, 0));
+  ISHAP_TRY(gn_stats_op(e, h1, st2));
+  Tensor c = h1;
+  c.p = aalloc<half_t>(e, h1.numel());
+  if (!e.dry) {
+    GnApplyArgs g;
+    g.x = h1.p; g.out = c.p; g.stats = st2; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
+    g.emb = u->d_film + L.emb_off; g.emb_ld = u->film_rows;
+    g.N = N; g.H = Ho; g.W = Wo; g.C = L.cout; g.film = 1; g.act = 1;
+    ISHAP_TRY(gn_apply_launch(g, e.s));
+  }
+  y = h1;
+  y.p = aalloc<half_t>(e, h1.numel());
+  if (L.has_skip) {
+    ISHAP_TRY(conv_op(e, xs.p, N, Ho, Wo, L.cin, L.skip.w, L.skip.kpad, 1, L.cout, L.skip.bias, nullptr, 0, y.p, L.cout,
+                      IG_OUT_F16, 0, 0));
+    ISHAP_TRY(conv_op(e, c.p, N, Ho, Wo, L.cout, L.c2.w, L.c2.kpad, 9, L.cout, L.c2.bias, y.p, L.cout, y.p, L.cout,
+                      IG_OUT_F16, 0, 0));
+  } else {
+    ISHAP_TRY(conv_op(e, c.p, N, Ho, Wo, L.cout, L.c2.w, L.c2.kpad, 9, L.cout, L.c2.bias, xs.p, L.cin, y.p, L.cout,
+                      IG_OUT_F16, 0, L.up));
+  }
+  L.sv.x = x; L.sv.h1 = h1; L.sv.xs = xs; L.sv.stats1 = st1; L.sv.stats2 = st2;
+  return 0;
+}
+
+static int attn_forward(Exec& e, AttnL& L, const Tensor& x, Tensor& y) {
+  ishap_unet* u = e.u;
+  const int N = x.N, T = x.H * x.W, C = L.C, heads = L.heads, d = C / heads;
+  const int dpad = d < 64 ? 64 : d;
+  ISHAP_REQUIRE(x.C == C, "attention channels");
+  ISHAP_REQUIRE(d % 32 == 0, "head width must be a multiple of 32");
+  float* st = aalloc<float>(e, (size_t)N * 64);
+  float* lse = aalloc<float>(e, (size_t)N * heads * T);
+  ISHAP_TRY(gn_stats_op(e, x, st));
+  Tensor nrm = x;
+  nrm.p = aalloc<half_t>(e, x.numel());
+  if (!e.dry) {
+    GnApplyArgs g;
+    g.x = x.p; g.out = nrm.p; g.stats = st; g.gamma = L.n.gamma; g.beta = L.n.beta;
+    g.N = N; g.H = x.H; g.W = x.W; g.C = C; g.act = 0;
+    ISHAP_TRY(gn_apply_launch(g, e.s));
+  }
+  Tensor qkv{nullptr, N, x.H, x.W, 3 * C};
+  qkv.p = aalloc<half_t>(e, qkv.numel());
+  ISHAP_TRY(conv_op(e, nrm.p, N, x.H, x.W, C, L.qkv.w, L.qkv.kpad, 1, 3 * C, L.qkv.bias, nullptr, 0, qkv.p, 3 * C,
+                    IG_OUT_F16, 0, 0));
+  Tensor a = x;
+  a.p = aalloc<half_t>(e, x.numel());
+  const size_t s_need = (size_t)N * heads * T * T;
+  const size_t t_need = (size_t)N * heads * dpad * T;
+  if (e.dry) {
+    if (s_need > u->attn_S_floats) u->attn_S_floats = s_need;
+    if (t_need > u->attn_T_halfs) u->attn_T_halfs = t_need;
+  } else {
+    for (int n = 0; n < N; ++n) {      // S = (q*s)^T (k*s), s = d^-1/4   (unet.py:348-351)
+      IgemmArgs g;
+      g.X = qkv.p + (long long)n * T * 3 * C;       g.ldx = 3 * C; g.bsx = 3 * d;
+      g.Wt = qkv.p + (long long)n * T * 3 * C + d;  g.ldw = 3 * C; g.bsw = 3 * d;
+      g.out = u->attn_S + (long long)n * heads * T * T; g.ldo = T; g.bso = (long long)T * T;
+      g.M = T; g.N = T; g.K = d; g.nbatch = heads; g.alpha = 1.f / sqrtf((float)d);
+      g.out_mode = IG_OUT_F32;
+      ISHAP_TRY(igemm_launch(g, e.s));
+    }
+    ISHAP_TRY(softmax_rows(u->attn_S, u->attn_P, lse, (long long)N * heads * T, T, e.s));
+    ISHAP_TRY(head_transpose(qkv.p, u->attn_T, N, T, 3 * C, heads, d, dpad, 3 * d, 2 * d, e.s));
+    for (int n = 0; n < N; ++n) {      // a = P v   (unet.py:353)
+      IgemmArgs g;
+      g.X = u->attn_P + (long long)n * heads * T * T;      g.ldx = T; g.bsx = (long long)T * T;
+      g.Wt = u->attn_T + (long long)n * heads * dpad * T;  g.ldw = T; g.bsw = (long long)dpad * T;
+      g.out = a.p + (long long)n * T * C; g.ldo = C; g.bso = d;
+      g.M = T; g.N = d; g.K = T; g.nbatch = heads;
+      g.out_mode = IG_OUT_F16;
+      ISHAP_TRY(igemm_launch(g, e.s));
+    }
+  }
+  y = x;
+  y.p = aalloc<half_t>(e, x.numel());
+  ISHAP_TRY(conv_op(e, a.p, N, x.H, x.W, C, L.proj.w, L.proj.kpad, 1, C, L.proj.bias, x.p, C, y.p, C, IG_OUT_F16, 0, 0));
+  L.sv.x = x; L.sv.qkv = qkv; L.sv.a = a; L.sv.stats = st; L.sv.lse = lse;
+  return 0;
+}
+
+static int block_forward(Exec& e, BlockL& b, Tensor h, Tensor& out) {
+  ishap_unet* u = e.u;
+  for (auto& l : b.layers) {
+    Tensor y;
+    if (l.kind == 0) {
+      y = Tensor{nullptr, h.N, h.H, h.W, u->stem.cout};
+      y.p = aalloc<half_t>(e, y.numel());
+      ISHAP_TRY(conv_op(e, h.p, h.N, h.H, h.W, h.C, u->stem.w, u->stem.kpad, 9, u->stem.cout, u->stem.bias, nullptr, 0, y.p,
+                        u->stem.cout, IG_OUT_F16, 0, 0));
+    } else if (l.kind == 1) {
+      ISHAP_TRY(res_forward(e, u->res[l.idx], h, y));
+    } else {
+      ISHAP_TRY(attn_forward(e, u->attn[l.idx], h, y));
+    }
+    h = y;
+  }
+  out = h;
+  b.out = h;
+  return 0;
+}
+
+int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int feat_layer, float* out,
+                      void* inter_feat, int keep, hipStream_t s, bool dry) {
+  const ishap_unet_config& cfg = u->cfg;
+  ISHAP_REQUIRE(N >= 1 && N <= cfg.max_batch && N <= 16, "batch size outside [1, max_batch]");
+  ISHAP_REQUIRE(feat_layer < (int)u->out_blocks.size(), "feat_layer out of range");
+  Exec e{u, s, dry};
+  u->arena.reset();
+  u->have_saved = false;
+  const int S = cfg.image_size, HW = S * S;
+  // ---- timestep embedding -> emb -> every ResBlock's (scale | shift)   (unet.py:651, :245-250) ----
+  if (!dry) {
+    TsArg ta;
+    for (int i = 0; i < 16; ++i) ta.t[i] = i < N ? ts[i] : 0.f;
+    ISHAP_TRY(timestep_embedding(ta, u->d_temb, N, cfg.model_channels, s));
+    ISHAP_TRY(gemv_f32(u->te_w0, u->te_b0, u->d_temb, u->d_e1, u->ted, cfg.model_channels, N, 0, s));
+    ISHAP_TRY(gemv_f32(u->te_w2, u->te_b2, u->d_e1, u->d_emb, u->ted, u->ted, N, 1, s));
+    ISHAP_TRY(gemv_f32(u->emb_w, u->emb_b, u->d_emb, u->d_film, u->film_rows, u->ted, N, 1, s));
+  }
+  // ---- x: NCHW fp32 -> NHWC fp16 (h = x.type(self.dtype), unet.py:657) ----
+  Tensor h{nullptr, N, S, S, u->in_pad};
+  h.p = aalloc<half_t>(e, h.numel());
+  if (!dry) ISHAP_TRY(nchw_f32_to_nhwc_f16(x, h.p, N, cfg.in_channels, HW, u->in_pad, s));
+  u->x0 = h;
+  std::vector<Tensor> hs;
+  for (auto& b : u->in_blocks) {
+    Tensor y;
+    ISHAP_TRY(block_forward(e, b, h, y));
+    h = y;
+    hs.push_back(h);
+  }
+  {
+    Tensor y;
+    ISHAP_TRY(block_forward(e, u->mid, h, y));
+    h = y;
+  }
+  u->tap = Tensor{};
+  for (size_t i = 0; i < u->out_blocks.size(); ++i) {
+    BlockL& b = u->out_blocks[i];
+    Tensor skip = hs.back();
+    hs.pop_back();
+    Tensor cat{nullptr, h.N, h.H, h.W, h.C + skip.C};
+    ISHAP_REQUIRE(skip.H == h.H && cat.C == b.cin, "skip connection shape");
+    cat.p = aalloc<half_t>(e, cat.numel());
+    if (!dry) ISHAP_TRY(concat2(h.p, skip.p, cat.p, cat.rows(), h.C, skip.C, s));
+    b.cat = cat;
+    Tensor y;
+    ISHAP_TRY(block_forward(e, b, cat, y));
+    h = y;
+    if ((int)i == feat_layer) u->tap = h;
+  }
+  u->h_final = h;
+  // ---- head in fp32 (unet.py:667-669): GroupNorm, SiLU, 3x3 conv with fp32 weights.  The fp32 products are
+  //      formed on the fp16 MFMA from hi/lo splits of both operands (3 partial products, fp32 accumulate). ----
+  u->head_stats = aalloc<float>(e, (size_t)N * 64);
+  ISHAP_TRY(gn_stats_op(e, h, u->head_stats));
+  half_t* hsplit = aalloc<half_t>(e, (size_t)h.numel() * 3);
+  if (!dry) {
+    GnApplyArgs g;
+    g.x = h.p; g.out = hsplit; g.stats = u->head_stats; g.gamma = u->head_norm.gamma; g.beta = u->head_norm.beta;
+    g.N = N; g.H = S; g.W = S; g.C = h.C; g.act = 1; g.split = 1;
+    ISHAP_TRY(gn_apply_launch(g, s));
+  }
+  ISHAP_TRY(conv_op(e, hsplit, N, S, S, 3 * h.C, u->head.w, u->head.kpad, 9, cfg.out_channels, u->head.bias, nullptr, 0, out,
+                    0, IG_OUT_NCHW_F32, 0, 0));
+  if (feat_layer >= 0 && inter_feat && !dry)
+    ISHAP_TRY(nhwc_f16_to_nchw(u->tap.p, inter_feat, 0, N, u->tap.C, u->tap.H * u->tap.W, u->tap.C, s));
+  u->last_N = N;
+  u->last_feat = feat_layer;
+  u->have_saved = keep != 0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int ishap_version(void) { return 1; }
+
+int ishap_unet_create(const ishap_unet_config* cfg, int device, ishap_unet** out) {
+  ISHAP_REQUIRE(cfg && out, "null argument");
+  ISHAP_REQUIRE(cfg->n_mult >= 1 && cfg->n_mult <= 8 && cfg->n_att <= 8, "config arrays");
+  ISHAP_REQUIRE(cfg->model_channels % 32 == 0, "model_channels must be a multiple of 32 (GroupNorm32)");
+  ISHAP_REQUIRE(cfg->num_head_channels > 0 && cfg->num_head_channels % 32 == 0, "num_head_channels % 32");
+  ISHAP_REQUIRE(cfg->out_channels % 4 == 0, "out_channels % 4");
+  ISHAP_REQUIRE(cfg->max_batch >= 1 && cfg->max_batch <= 16, "max_batch in [1,16]");
+  int minres = cfg->image_size >> (cfg->n_mult - 1);
+  ISHAP_REQUIRE(minres * minres >= 64 && (cfg->image_size & (cfg->image_size - 1)) == 0,
+                "image_size: power of two with at least 8x8 at the deepest level");
+  ISHAP_CHECK_HIP(hipSetDevice(device));
+  ishap_unet* u = new ishap_unet();
+  u->cfg = *cfg;
+  u->device = device;
+  int r = unet_build(u);
+  if (r) { delete u; return r; }
+  // size the arena / workspaces with a dry run of forward + backward at max batch
+  u->arena.dry = true;
+  std::vector<float> ts(cfg->max_batch, 0.f);
+  r = unet_forward_impl(u, nullptr, ts.data(), cfg->max_batch, (int)u->out_blocks.size() - 1, nullptr, nullptr, 1, 0, true);
+  size_t fwd_high = u->arena.high;
+  if (!r) {
+    u->arena.off = fwd_high;     // backward allocates on top of the kept forward state
+    r = unet_backward_impl(u, nullptr, (const float*)0x1000, nullptr, nullptr, 0, true);
+  }
+  if (r) { delete u; return r; }
+  u->arena.dry = false;
+  u->arena.cap = align_up(u->arena.high + (1 << 20), 1 << 20);
+  ISHAP_CHECK_HIP(hipMalloc((void**)&u->arena.base, u->arena.cap));
+  if (u->ws_floats) ISHAP_CHECK_HIP(hipMalloc((void**)&u->ws, u->ws_floats * sizeof(float)));
+  ISHAP_CHECK_HIP(hipMalloc((void**)&u->gn_partial, std::max<size_t>(u->gn_partial_floats, 64) * sizeof(float)));
+  if (u->attn_S_floats) {
+    ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_S, u->attn_S_floats * sizeof(float)));
+    ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_P, u->attn_S_floats * sizeof(half_t)));
+    ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_dS, 2 * u->attn_S_floats * sizeof(half_t)));
+    ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_T, 4 * u->attn_T_halfs * sizeof(half_t) + 65536));
+  }
+  u->have_saved = false;
+  *out = u;
+  return 0;
+}
+
+void ishap_unet_destroy(ishap_unet* u) {
+  if (!u) return;
+  auto fr = [](void* p) { if (p) (void)hipFree(p); };
+  auto frc = [&](ConvW& c) { fr(c.w); fr(c.wT); fr(c.bias); };
+  frc(u->stem); frc(u->head);
+  fr(u->head_norm.gamma); fr(u->head_norm.beta);
+  for (auto& r : u->res) {
+    frc(r.c1); frc(r.c2); if (r.has_skip) frc(r.skip);
+    fr(r.n1.gamma); fr(r.n1.beta); fr(r.n2.gamma); fr(r.n2.beta);
+  }
+  for (auto& a : u->attn) { frc(a.qkv); frc(a.proj); fr(a.n.gamma); fr(a.n.beta); }
+  fr(u->te_w0); fr(u->te_b0); fr(u->te_w2); fr(u->te_b2); fr(u->emb_w); fr(u->emb_b);
+  fr(u->d_temb); fr(u->d_e1); fr(u->d_emb); fr(u->d_film);
+  fr(u->arena.base); fr(u->ws); fr(u->gn_partial); fr(u->attn_S); fr(u->attn_P); fr(u->attn_T); fr(u->attn_dS);
+  delete u;
+}
+
+int ishap_unet_num_params(const ishap_unet* u) { return u ? (int)u->params.size() : 0; }
+
+int ishap_unet_param_info(const ishap_unet* u, int index, char* name, int name_cap, int* ndim, long long* shape) {
+  ISHAP_REQUIRE(u && index >= 0 && index < (int)u->params.size(), "param index");
+  const ParamSlot& p = u->params[index];
+  if (name && name_cap > 0) {
+    std::strncpy(name, p.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (ndim) *ndim = p.ndim;
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+  return 0;
+}
+
+int ishap_unet_load_param(ishap_unet* u, const char* name, const float* data, long long numel, void* stream) {
+  ISHAP_REQUIRE(u && name && data, "null argument");
+  auto it = u->param_index.find(name);
+  ISHAP_REQUIRE(it != u->param_index.end(), std::string("unexpected key in state_dict: ") + name);
+  ParamSlot& p = u->params[it->second];
+  ISHAP_REQUIRE(p.numel() == numel, std::string("size mismatch for ") + name);
+  ISHAP_CHECK_HIP(hipSetDevice(u->device));
+  ISHAP_TRY(load_param(u, p, data, (hipStream_t)stream));
+  if (!p.loaded) { p.loaded = true; u->n_loaded++; }
+  return 0;
+}
+
+int ishap_unet_params_loaded(const ishap_unet* u) { return u ? u->n_loaded : 0; }
+
+int ishap_unet_forward(ishap_unet* u, const float* x, const float* timesteps, int N, int feat_layer, float* out,
+                       void* inter_feat, int keep_for_backward, void* stream) {
+  ISHAP_REQUIRE(u && x && timesteps && out, "null argument");
+  ISHAP_REQUIRE(u->n_loaded == (int)u->params.size(), "missing keys: not every state_dict tensor has been loaded");
+  ISHAP_CHECK_HIP(hipSetDevice(u->device));
+  return unet_forward_impl(u, x, timesteps, N, feat_layer, out, inter_feat, keep_for_backward, (hipStream_t)stream, false);
+}
+
+int ishap_unet_tap_shape(const ishap_unet* u, int feat_layer, int* channels, int* size) {
+  ISHAP_REQUIRE(u && feat_layer >= 0 && feat_layer < (int)u->out_blocks.size(), "feat_layer out of range");
+  if (channels) *channels = u->out_blocks[feat_layer].cout;
+  if (size) *size = u->out_blocks[feat_layer].res_out;
+  return 0;
+}
+
+const void* ishap_unet_tap_ptr(const ishap_unet* u) { return u ? u->tap.p : nullptr; }
+
+int ishap_unet_copy_tap(const ishap_unet* u, void* dst, void* stream) {
+  ISHAP_REQUIRE(u && dst && u->tap.p, "no resident tap (run a forward with feat_layer >= 0 first)");
+  ISHAP_CHECK_HIP(hipMemcpyAsync(dst, u->tap.p, (size_t)u->tap.numel() * sizeof(half_t), hipMemcpyDeviceToDevice,
+                                 (hipStream_t)stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,228 @@
+"""Host-side mirror of guided_diffusion/{gaussian_diffusion,respace}.py for the sampling path.
+
+Schedule tables are float64 numpy like the reference's (gaussian_diffusion.py:118-169, respace.py:71-85);
+each per-step lookup is cast to fp32 exactly where `_extract_into_tensor` does (:1035-1048).  The step
+arithmetic itself (p_mean_variance :232-331, sample variants :443/:498-510) is one HIP kernel
+(`ishap_ddpm_step`); the model call goes to the HIP UNet.  DDIM, training losses and the VLB are not on
+the path (use_ddim=False, no training) and are not provided.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def get_named_beta_schedule(schedule_name: str, num_diffusion_timesteps: int) -> np.ndarray:
+    if schedule_name != "linear":
+        raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
+    scale = 1000 / num_diffusion_timesteps
+    return np.linspace(scale * 0.0001, scale * 0.02, num_diffusion_timesteps, dtype=np.float64)
+
+
+def space_timesteps(num_timesteps: int, section_counts) -> set:
+    """respace.py:6-59."""
+    if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):
+            desired = int(section_counts[len("ddim"):])
+            for i in range(1, num_timesteps):
+                if len(range(0, num_timesteps, i)) == desired:
+                    return set(range(0, num_timesteps, i))
+            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
+        section_counts = [int(x) for x in section_counts.split(",")]
+    size_per, extra = divmod(num_timesteps, len(section_counts))
+    start_idx, all_steps = 0, []
+    for i, count in enumerate(section_counts):
+        size = size_per + (1 if i < extra else 0)
+        if size < count:
+            raise ValueError(f"cannot divide section of {size} steps into {count}")
+        frac = 1 if count <= 1 else (size - 1) / (count - 1)
+        cur = 0.0
+        for _ in range(count):
+            all_steps.append(start_idx + round(cur))
+            cur += frac
+        start_idx += size
+    return set(all_steps)
+
+
+class SpacedDiffusion:
+    """LEARNED_RANGE variance + EPSILON mean (learn_sigma=True, predict_xstart=False: drag_utils.py:52-56)."""
+
+    def __init__(self, use_timesteps, betas: np.ndarray, rescale_timesteps: bool = False):
+        if rescale_timesteps:
+            raise NotImplementedError("rescale_timesteps=False on the path (drag_utils.py:56)")
+        self.use_timesteps = set(use_timesteps)
+        self.original_num_steps = len(betas)
+        base_ac = np.cumprod(1.0 - np.array(betas, dtype=np.float64), axis=0)
+        last, new_betas, self.timestep_map = 1.0, [], []
+        for i, ac in enumerate(base_ac):
+            if i in self.use_timesteps:
+                new_betas.append(1 - ac / last)
+                last = ac
+                self.timestep_map.append(i)
+        betas = np.array(new_betas, dtype=np.float64)
+        assert (betas > 0).all() and (betas <= 1).all()
+        self.betas = betas
+        self.num_timesteps = int(betas.shape[0])
+        alphas = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.alphas_cumprod_next = np.append(self.alphas_cumprod[1:], 0.0)
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+        self._log_betas = np.log(betas)
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _t_index(t) -> int:
+        if torch.is_tensor(t):
+            v = t.reshape(-1).tolist()
+            assert all(x == v[0] for x in v), "one timestep per call (batch shares t), as every caller on the path does"
+            return int(v[0])
+        if isinstance(t, (list, tuple)):
+            return int(t[0])
+        return int(t)
+
+    def _coefs(self, t: int, clip_denoised: bool, mode: int) -> _lib.StepCoefs:
+        f32 = lambda a: float(np.float32(a[t]))                    # noqa: E731  (float64 table -> fp32, :1045)
+        return _lib.StepCoefs(f32(self.posterior_log_variance_clipped), f32(self._log_betas),
+                              f32(self.sqrt_recip_alphas_cumprod), f32(self.sqrt_recipm1_alphas_cumprod),
+                              f32(self.posterior_mean_coef1), f32(self.posterior_mean_coef2),
+                              0.0 if t == 0 else 1.0, int(bool(clip_denoised)), mode)
+
+    def _model(self, model, x, t: int, feat_layer: int, **model_kwargs):
+        ts = torch.tensor([self.timestep_map[t]] * x.shape[0])      # _WrappedModel, respace.py:122-127
+        if feat_layer < 0:
+            return model(x, ts, **model_kwargs), None
+        return model(x, ts, feat_layer=feat_layer, **model_kwargs)
+
+    def _step(self, x, model_output, t, noise, variance_in, clip_denoised, mode, want=("sample",)):
+        N, Cc = x.shape[:2]
+        HW = int(np.prod(x.shape[2:]))
+        assert model_output.shape[1] == 2 * Cc
+        outs = {k: torch.empty_like(x) for k in want}
+        k = self._coefs(t, clip_denoised, mode)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ishap_ddpm_step(
+                x.data_ptr(), model_output.data_ptr(), _lib.ptr(noise), _lib.ptr(variance_in), C.byref(k), N, Cc, HW,
+                _lib.ptr(outs.get("sample")), _lib.ptr(outs.get("pred_xstart")), _lib.ptr(outs.get("variance")),
+                _lib.ptr(outs.get("mean")), _lib.stream_ptr(x.device)))
+        return outs
+
+    @staticmethod
+    def _prep(x):
+        return x.detach().to(dtype=torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ reference surface
+    def p_sample_guidance(self, model, x, t, noise=None, variance=None, variance_noise=None, clip_denoised=True,
+                          denoised_fn=None, cond_fn=None, model_kwargs=None, feat_layer=-1, keep_for_backward=False,
+                          want_inter_feat=True):
+        """gaussian_diffusion.py:446-510.  Returns the same dict keys."""
+        assert denoised_fn is None and cond_fn is None, "not used on the path"
+        ti = self._t_index(t)
+        x = self._prep(x)
+        kw = dict(model_kwargs or {})
+        if hasattr(model, "tap_ptr"):
+            kw.update(keep_for_backward=keep_for_backward, want_inter_feat=want_inter_feat)
+        mo, inter = self._model(model, x, ti, feat_layer, **kw)
+        if variance_noise is not None:
+            o = self._step(x, mo, ti, self._prep(variance_noise), None, clip_denoised, 2, ("sample", "variance"))
+            return {"sample": o["sample"], "inter_feat": inter, "variance": o["variance"]}
+        noise = noise if noise is not None else torch.randn_like(x)
+        noise = self._prep(noise)
+        vin = None if variance is None else self._prep(variance)
+        o = self._step(x, mo, ti, noise, vin, clip_denoised, 0, ("sample", "pred_xstart", "variance", "mean"))
+        return {"sample": o["sample"], "pred_xstart": o["pred_xstart"], "inter_feat": inter,
+                "model_output": mo[:, :x.shape[1]], "noise": noise,
+                "variance": o["variance"] if variance is None else variance, "mean": o["mean"]}
+
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, noise=None):
+        """gaussian_diffusion.py:400-444 (`noise` injectable for parity runs; default randn_like as there)."""
+        assert denoised_fn is None and cond_fn is None
+        ti = self._t_index(t)
+        x = self._prep(x)
+        mo, _ = self._model(model, x, ti, -1, **(model_kwargs or {}))
+        noise = self._prep(noise if noise is not None else torch.randn_like(x))
+        o = self._step(x, mo, ti, noise, None, clip_denoised, 1, ("sample", "pred_xstart"))
+        return {"sample": o["sample"], "pred_xstart": o["pred_xstart"]}
+
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                  model_kwargs=None, device=None, progress=False, step_noise=None):
+        """gaussian_diffusion.py:604-652."""
+        if device is None:
+            device = next(model.parameters()).device
+        img = noise if noise is not None else torch.randn(*shape, device=device)
+        indices = list(range(self.num_timesteps))[::-1]
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        for i in indices:
+            out = self.p_sample(model, img, i, clip_denoised=clip_denoised, model_kwargs=model_kwargs,
+                                noise=None if step_noise is None else step_noise(i))
+            yield out
+            img = out["sample"]
+
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                      model_kwargs=None, device=None, progress=False, save_intermediate=False,
+                      save_timestep_interval=20, step_noise=None):
+        """gaussian_diffusion.py:534-602 (save_intermediate is a debugging aid there; not provided)."""
+        assert not save_intermediate
+        final = None
+        for sample in self.p_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
+                                                     model_kwargs=model_kwargs, device=device, progress=progress,
+                                                     step_noise=step_noise):
+            final = sample
+        return final["sample"]
+
+    def ddpm_inversion(self, model, x_0, steps, fwd_noise: Optional[Sequence[torch.Tensor]] = None, tap_sink=None,
+                       **kwargs):
+        """gaussian_diffusion.py:512-532.  `fwd_noise[i]` replaces randn_like at :522 for parity runs; `tap_sink()`
+        is called after every reverse step so the caller can keep the resident tap (guidance cache)."""
+        feat, variance_noise, variance = [], [], []
+        x = self._prep(x_0)
+        L = _lib.lib()
+        img_inter = [x]
+        for i in range(steps):
+            cof = np.float32(self.alphas_cumprod[i]) / np.float32(self.alphas_cumprod_prev[i])      # fp32 / fp32, :520
+            a, b = float(np.sqrt(np.float32(cof))), float(np.sqrt(np.float32(1) - cof))
+            eps = self._prep(fwd_noise[i]) if fwd_noise is not None else torch.randn_like(x)
+            nxt = torch.empty_like(x)
+            with torch.cuda.device(x.device):
+                _lib.check(L.ishap_axpby(x.data_ptr(), eps.data_ptr(), a, b, x.numel(), nxt.data_ptr(),
+                                         _lib.stream_ptr(x.device)))
+            x = nxt
+            img_inter.append(x)
+        img = img_inter[-1]
+        zero = torch.zeros_like(img)
+        for i in range(steps - 1, -1, -1):
+            outs = self.p_sample_guidance(model, img, i, noise=zero, **kwargs)
+            if tap_sink is not None:
+                tap_sink()
+            variance.append(outs["variance"])
+            feat.append(outs["inter_feat"])
+            variance_noise.append(img_inter[i] - outs["mean"])
+            img = outs["mean"] + variance_noise[-1]
+        return {"inter_feat": feat, "latent": img_inter[-1], "variance_noise": variance_noise, "variance": variance,
+                "sample": img}
+
+
+def create_gaussian_diffusion(*, steps=1000, learn_sigma=True, sigma_small=False, noise_schedule="linear", use_kl=False,
+                              predict_xstart=False, rescale_timesteps=False, rescale_learned_sigmas=False,
+                              timestep_respacing=""):
+    """script_util.py:389-427."""
+    if not learn_sigma or predict_xstart or use_kl:
+        raise NotImplementedError("the path uses learn_sigma=True, predict_xstart=False, MSE (drag_utils.py:52-56)")
+    betas = get_named_beta_schedule(noise_schedule, steps)
+    if not timestep_respacing:
+        timestep_respacing = [steps]
+    return SpacedDiffusion(space_timesteps(steps, timestep_respacing), betas, rescale_timesteps)

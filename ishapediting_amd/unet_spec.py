@@ -57,7 +57,7 @@ def tiny_config(num_res_blocks: int = 1) -> UNetConfig:
     skip 1x1, concat); used by the golden fixtures."""
     return UNetConfig(image_size=16, in_channels=6, model_channels=32, out_channels=12,
                       num_res_blocks=num_res_blocks, attention_resolutions="8",
-                      channel_mult=(1, 2), num_head_channels=16)
+                      channel_mult=(1, 2), num_head_channels=32)
 
 
 @dataclass

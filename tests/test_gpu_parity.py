@@ -1,0 +1,170 @@
+"""HIP path vs. the CPU oracle and the reference's golden vectors.  Needs an MI355X: -m gpu.
+Every call goes through the C ABI of libishap_hip.so (ctypes); nothing here reads /root/reference."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from ishapediting_amd import synthetic
+from ishapediting_amd.unet_spec import build_spec, tiny_config
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda", 0)
+
+
+def rel_err(a, b):
+    a = a.detach().float().cpu()
+    b = torch.as_tensor(b).float()
+    return float((a - b).norm() / (b.norm() + 1e-30)), float((a - b).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------- UNet forward
+@pytest.mark.parametrize("nrb", [1, 2])
+def test_tiny_unet_forward_vs_reference_golden(gold, nrb):
+    """fp16-torso device path vs the reference's fp16 (CPU) run and its fp32 run of the same weights.
+    Tolerance: relative L2 <= 5e-3 vs the fp16 reference run (both carry fp16 rounding noise),
+    <= 1e-2 vs fp32."""
+    from ishapediting_amd.unet import UNetModel
+    g = gold("g4_tiny_unet")
+    cfg = tiny_config(nrb)
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 100 + nrb))
+    m = UNetModel(cfg, dev())
+    m.load_state_dict(sd, strict=True)
+    x = T(g[f"nrb{nrb}_x"]).to(dev())
+    ts = T(g[f"nrb{nrb}_ts"])
+    k = int(g[f"nrb{nrb}_tap_fp16_idx"])
+    out, feat = m(x, ts, feat_layer=k)
+    torch.cuda.synchronize()
+    assert feat.dtype == torch.float16 and out.dtype == torch.float32
+    r16, a16 = rel_err(out, g[f"nrb{nrb}_out_fp16"])
+    r32, a32 = rel_err(out, g[f"nrb{nrb}_out"])
+    f16, _ = rel_err(feat, g[f"nrb{nrb}_tap_fp16"])
+    f32, _ = rel_err(feat, g[f"nrb{nrb}_tap{k}"])
+    print(f"nrb={nrb}: out rel vs fp16-ref {r16:.2e} (max {a16:.2e}), vs fp32-ref {r32:.2e}; tap {f16:.2e}/{f32:.2e}")
+    assert r16 < 5e-3 and f16 < 5e-3
+    assert r32 < 1e-2 and f32 < 1e-2
+    # every tap index, against the fp32 reference run
+    for kk in range(len(build_spec(cfg).output_blocks)):
+        _, ft = m(x, ts, feat_layer=kk)
+        r, _ = rel_err(ft, g[f"nrb{nrb}_tap{kk}"])
+        assert r < 1e-2, (kk, r)
+    # feat_layer < 0 returns only the output (unet.py:668-669)
+    o2 = m(x, ts)
+    assert torch.is_tensor(o2) and torch.equal(o2, out)
+
+
+def test_tiny_unet_param_table_matches_spec():
+    from ishapediting_amd.unet import UNetModel
+    from ishapediting_amd.unet_spec import param_shapes
+    cfg = tiny_config(2)
+    m = UNetModel(cfg, dev())
+    assert m.param_table() == param_shapes(cfg)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 6, 16, 16, device=dev()), [0])      # weights not loaded -> loud failure
+    sd = synthetic.unet_state_dict(cfg, 1)
+    bad = dict(sd)
+    bad.pop("out.2.bias")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad, strict=True)
+
+
+# ---------------------------------------------------------------------------------------------- diffusion step
+def test_ddpm_step_vs_golden(gold):
+    from ishapediting_amd.gaussian_diffusion import create_gaussian_diffusion
+    g = gold("g2_steps")
+    d = create_gaussian_diffusion(timestep_respacing="40")
+    x, mo, noise, vn = (T(g[k]).to(dev()) for k in ("x", "model_output", "noise", "variance_noise"))
+
+    class Fixed:
+        def __call__(self, x, ts, feat_layer=-1, **kw):
+            self.ts = ts
+            return (mo, None) if feat_layer >= 0 else mo
+    for t in (0, 1, 17, 39):
+        f = Fixed()
+        o = d.p_sample_guidance(f, x, torch.tensor([t]), noise=noise)
+        assert int(f.ts[0]) == int(g[f"t{t}_ts"][0])
+        for k in ("sample", "pred_xstart", "variance", "mean"):
+            np.testing.assert_allclose(o[k].cpu().numpy(), g[f"t{t}_{k}"], rtol=2e-5, atol=2e-6, err_msg=f"{t} {k}")
+        o2 = d.p_sample_guidance(f, x, torch.tensor([t]), noise=noise, clip_denoised=False)
+        np.testing.assert_allclose(o2["sample"].cpu().numpy(), g[f"t{t}_sample_noclip"], rtol=2e-5, atol=1e-5)
+        o3 = d.p_sample_guidance(f, x, torch.tensor([t]), variance_noise=vn)
+        np.testing.assert_allclose(o3["sample"].cpu().numpy(), g[f"t{t}_sample_vn"], rtol=2e-5, atol=2e-6)
+        o4 = d.p_sample(f, x, torch.tensor([t]), noise=T(g["psample_noise"]).to(dev()))
+        np.testing.assert_allclose(o4["sample"].cpu().numpy(), g[f"t{t}_psample"], rtol=2e-5, atol=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------- decoder
+def test_decoder_points_vs_golden(gold):
+    """fp32 MFMA decode vs the reference MultiTriplane (incl. border and out-of-range coords).
+    Tolerance: |logit error| <= 1e-4 + 1e-4*|logit| (fp32 summation-order differences only)."""
+    from ishapediting_amd.triplane_decoder import MultiTriplane
+    g = gold("g6_decoder")
+    dec = MultiTriplane(1, device=dev())
+    dec.net.load_state_dict(synthetic.decoder_state_dict())
+    planes = T(g["planes"]).to(dev())
+    for i in range(3):
+        dec.embeddings[i] = planes[[i]]
+    logits = dec(0, T(g["coords"]).to(dev()).unsqueeze(0))
+    assert logits.shape == (1, 2048, 1)
+    np.testing.assert_allclose(logits.reshape(-1).cpu().numpy(), g["logits"], rtol=1e-4, atol=1e-4)
+
+
+def test_decoder_grid_vs_oracle():
+    from oracle import ref_cpu as O
+    from ishapediting_amd.triplane_decoder import MultiTriplane, decode_volume
+    net = synthetic.decoder_state_dict()
+    gen = torch.Generator().manual_seed(3)
+    latent = torch.randn(1, 96, 32, 32, generator=gen) * 0.5
+    rng = torch.rand(1, 96, 1, 1, generator=gen) + 0.5
+    mid = torch.randn(1, 96, 1, 1, generator=gen) * 0.1
+    want = O.decode_volume(net, latent, rng, mid, 24)
+    dec = MultiTriplane(1, device=dev())
+    dec.net.load_state_dict(net)
+    got = decode_volume(dec, latent.to(dev()), rng.to(dev()), mid.to(dev()), 24)
+    assert got.shape == (24, 24, 24)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------- drag loss
+def _tap_from_planes(feat):
+    """[3,Cc,W,W] fp32 (fp16-representable) -> NHWC fp16 tap [W*W][ld] + chmap, plane p channel c at p*Cc+c."""
+    P, Cc, W, _ = feat.shape
+    ld = ((P * Cc + 31) // 32) * 32
+    tap = torch.zeros(W * W, ld, dtype=torch.float16)
+    tap[:, :P * Cc] = feat.reshape(P * Cc, W * W).t().half()
+    chmap = torch.arange(P * Cc, dtype=torch.int32).reshape(P, Cc)
+    return tap, chmap, ld
+
+
+@pytest.mark.parametrize("loss_type", ["l2", "l1"])
+@pytest.mark.parametrize("cof", [0.0, 0.4])
+def test_drag_loss_gradient_vs_golden(gold, loss_type, cof):
+    """d loss / d feature from the HIP drag kernels vs the gradient the reference's own training()
+    produced (autograd).  Tolerance: 1e-4 relative + 1e-9 absolute (fp32 atomics reorder sums)."""
+    from oracle import ref_cpu as O
+    from ishapediting_amd.drag_utils import DragKernels
+    g = gold("g7_drag")
+    edit, chmap, ld = _tap_from_planes(T(g["edit"]))
+    orig, _, _ = _tap_from_planes(T(g["orig"]))
+    dk = DragKernels(dev(), W=16, ld=ld, chmap=chmap, r=int(g["r1"]), voxel=float(g["voxel_size"]),
+                     loss_type=loss_type)
+    dk.setup(g["sources"], g["targets"], cof)
+    grad, loss = dk.loss_grad(edit.to(dev()), orig.to(dev()))
+    torch.cuda.synchronize()
+    got = grad.cpu()[:, :60].t().reshape(3, 20, 16, 16)
+    want = g[f"{loss_type}_cof{cof}_grad"]
+    np.testing.assert_allclose(got.numpy(), want, rtol=1e-4, atol=1e-9)
+    setup = O.DragSetup(g["sources"], g["targets"], int(g["r1"]), float(g["voxel_size"]), 16)
+    lw = O.drag_loss(T(g["edit"]), T(g["orig"]), setup, cof, loss_type)
+    assert abs(float(loss.cpu()) - float(lw)) <= 1e-5 * abs(float(lw)) + 1e-8
+    # mask bitmap equals the reference's complement sets
+    touched = dk.touched.cpu().reshape(3, 16, 16).bool()
+    for p in range(3):
+        assert torch.equal(~touched[p], setup.masks[p])

@@ -228,8 +228,8 @@ def g6_decoder():
 def g7_drag():
     g = torch.Generator().manual_seed(51)
     W, C, B, r1 = 16, 20, 2, 2
-    orig = torch.randn(3, C, W, W, generator=g)
-    edit0 = orig + 0.3 * torch.randn(3, C, W, W, generator=g)
+    orig = torch.randn(3, C, W, W, generator=g).half().float()          # fp16-representable: the device taps are fp16
+    edit0 = (orig + 0.3 * torch.randn(3, C, W, W, generator=g)).half().float()
     src = np.array([[0.1, -0.2, 0.3], [-0.4, 0.5, 0.0]], dtype=np.float32)
     tgt = np.array([[0.3, -0.1, 0.2], [-0.3, 0.3, 0.93]], dtype=np.float32)   # second one hits the border
     voxel = 2.0 / 32
