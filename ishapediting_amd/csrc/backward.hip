@@ -1,15 +1,251 @@
-// UNet input-gradient pass (filled in below).
+// UNet input-gradient pass: d(sum(tap * cot)) / dx, hand-derived, layer by layer in reverse.
+// Reference: loss.backward() at drag_utils.py:383 (autograd through guided_diffusion/unet.py:634-671 from
+// the tapped output block back to x) and :458 (full depth, from the model output).  Only what the path
+// needs is computed: gradients w.r.t. activations.  Weight gradients (which the reference computes and
+// throws away, its parameters keep requires_grad=True) and the attention checkpoint's second forward
+// (unet.py:297) have no counterpart here: activations needed for derivatives are recomputed inside the
+// elementwise kernels from the saved GN inputs and statistics.
+// Every convolution's input gradient is the same implicit-GEMM kernel run on the gradient map with the
+// tap-flipped, transposed weight operand packed at load time (ConvW::wT).
 #include "unet.h"
+
+#include "misc.h"
+#include "norm.h"
+
+static int gn_bwd_op(Exec& e, GnBwdArgs g) {
+  if (e.dry) return 0;
+  g.partial = e.u->gn_partial;
+  g.mstats = e.u->gn_mstats;
+  return gn_backward_launch(g, e.s);
+}
+
+// dY [N,H,W,cout] -> dX [N,H,W,rows of wT] through the transposed / flipped operand
+static int dgrad_op(Exec& e, const ConvW& c, const Tensor& dy, Tensor& dx_out, int n_out) {
+  dx_out = Tensor{nullptr, dy.N, dy.H, dy.W, n_out};
+  dx_out.p = aalloc<half_t>(e, dx_out.numel());
+  return conv_op(e, dy.p, dy.N, dy.H, dy.W, dy.C, c.wT, c.cout_pad, c.taps, n_out, nullptr, nullptr, 0, dx_out.p, n_out,
+                 IG_OUT_F16, 0, 0);
+}
+
+static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx) {
+  ishap_unet* u = e.u;
+  const ResSaved& sv = L.sv;
+  const Tensor& x = sv.x;
+  const Tensor& h1 = sv.h1;
+  ISHAP_REQUIRE(dy.C == L.cout && dy.H == h1.H && dy.N == x.N, "ResBlock gradient shape");
+  // out_layers: conv2 <- SiLU <- FiLM <- GN2
+  Tensor dc;
+  ISHAP_TRY(dgrad_op(e, L.c2, dy, dc, L.cout));
+  Tensor dh1 = h1;
+  dh1.p = aalloc<half_t>(e, h1.numel());
+  {
+    GnBwdArgs g;
+    g.g = dc.p; g.x = h1.p; g.dx = dh1.p; g.stats = sv.stats2; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
+    g.emb = u->d_film + L.emb_off; g.emb_ld = u->film_rows;
+    g.N = h1.N; g.H = h1.H; g.W = h1.W; g.C = L.cout; g.film = 1; g.act = 1; g.gmode = GB_SAME;
+    ISHAP_TRY(gn_bwd_op(e, g));
+  }
+  // in_layers: conv1 <- (up/down sample) <- SiLU <- GN1
+  Tensor da;
+  ISHAP_TRY(dgrad_op(e, L.c1, dh1, da, L.cin));
+  const half_t* add = dy.p;     // identity skip: gradient of `x_upd(x)` (unet.py:241,256)
+  if (L.has_skip) {
+    Tensor dxs;
+    ISHAP_TRY(dgrad_op(e, L.skip, dy, dxs, L.cin));
+    add = dxs.p;
+  }
+  dx = x;
+  dx.p = aalloc<half_t>(e, x.numel());
+  {
+    GnBwdArgs g;
+    g.g = da.p; g.x = x.p; g.add = add; g.dx = dx.p; g.stats = sv.stats1; g.gamma = L.n1.gamma; g.beta = L.n1.beta;
+    g.N = x.N; g.H = x.H; g.W = x.W; g.C = L.cin; g.film = 0; g.act = 1;
+    g.gmode = L.down ? GB_UNPOOL : (L.up ? GB_SUM4 : GB_SAME);
+    ISHAP_TRY(gn_bwd_op(e, g));
+  }
+  return 0;
+}
+
+static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx) {
+  ishap_unet* u = e.u;
+  const AttnSaved& sv = L.sv;
+  const Tensor& x = sv.x;
+  const int N = x.N, T = x.H * x.W, C = L.C, heads = L.heads, d = C / heads;
+  const int dpad = d < 64 ? 64 : d;
+  const float alpha = 1.f / sqrtf((float)d);
+  Tensor dA;
+  ISHAP_TRY(dgrad_op(e, L.proj, dy, dA, C));
+  Tensor dqkv{nullptr, N, x.H, x.W, 3 * C};
+  dqkv.p = aalloc<half_t>(e, dqkv.numel());
+  const size_t d_need = (size_t)N * heads * T;
+  if (e.dry) {
+    if (d_need > u->attn_D_floats) u->attn_D_floats = d_need;
+  } else {
+    const long long BH = (long long)N * heads;
+    const size_t slot = u->attn_T_halfs;
+    half_t* KT = u->attn_T;
+    half_t* dAT = u->attn_T + slot;
+    half_t* QT = u->attn_T + 2 * slot;
+    half_t* dS = u->attn_dS;
+    half_t* dST = u->attn_dS + u->attn_S_floats;
+    const half_t* qkv = sv.qkv.p;
+    auto gemm_heads = [&](const half_t* X, int ldx, long long bsx, const half_t* Wt, int ldw, long long bsw, void* out,
+                          int ldo, long long bso, int M, int Nn, int K, float al, int mode) -> int {
+      IgemmArgs g;
+      g.X = X; g.ldx = ldx; g.bsx = bsx; g.Wt = Wt; g.ldw = ldw; g.bsw = bsw; g.out = out; g.ldo = ldo; g.bso = bso;
+      g.M = M; g.N = Nn; g.K = K; g.nbatch = heads; g.alpha = al; g.out_mode = mode;
+      return igemm_launch(g, e.s);
+    };
+    // recompute P (forward: S = alpha q^T k, softmax)            [t][s]
+    for (int n = 0; n < N; ++n)
+      ISHAP_TRY(gemm_heads(qkv + (long long)n * T * 3 * C, 3 * C, 3 * d, qkv + (long long)n * T * 3 * C + d, 3 * C, 3 * d,
+                           u->attn_S + (long long)n * heads * T * T, T, (long long)T * T, T, T, d, alpha, IG_OUT_F32));
+    ISHAP_TRY(softmax_rows(u->attn_S, u->attn_P, sv.lse, BH * T, T, e.s));
+    // dP = dA V^T                                                 [t][s] fp32
+    for (int n = 0; n < N; ++n)
+      ISHAP_TRY(gemm_heads(dA.p + (long long)n * T * C, C, d, qkv + (long long)n * T * 3 * C + 2 * d, 3 * C, 3 * d,
+                           u->attn_S + (long long)n * heads * T * T, T, (long long)T * T, T, T, d, 1.f, IG_OUT_F32));
+    ISHAP_TRY(softmax_bwd_rows(u->attn_P, u->attn_S, dS, u->attn_D, BH * T, T, alpha, e.s));
+    // dQ = dS K
+    ISHAP_TRY(head_transpose(qkv, KT, N, T, 3 * C, heads, d, dpad, 3 * d, d, e.s));
+    for (int n = 0; n < N; ++n)
+      ISHAP_TRY(gemm_heads(dS + (long long)n * heads * T * T, T, (long long)T * T, KT + (long long)n * heads * dpad * T, T,
+                           (long long)dpad * T, dqkv.p + (long long)n * T * 3 * C, 3 * C, 3 * d, T, d, T, 1.f, IG_OUT_F16));
+    // P^T = exp(alpha k^T q - lse_t)                              [s][t]
+    for (int n = 0; n < N; ++n)
+      ISHAP_TRY(gemm_heads(qkv + (long long)n * T * 3 * C + d, 3 * C, 3 * d, qkv + (long long)n * T * 3 * C, 3 * C, 3 * d,
+                           u->attn_S + (long long)n * heads * T * T, T, (long long)T * T, T, T, d, alpha, IG_OUT_F32));
+    ISHAP_TRY(exp_sub_lse_cols(u->attn_S, sv.lse, u->attn_P, BH, T, e.s));
+    // dV = P^T dA
+    ISHAP_TRY(head_transpose(dA.p, dAT, N, T, C, heads, d, dpad, d, 0, e.s));
+    for (int n = 0; n < N; ++n)
+      ISHAP_TRY(gemm_heads(u->attn_P + (long long)n * heads * T * T, T, (long long)T * T,
+                           dAT + (long long)n * heads * dpad * T, T, (long long)dpad * T,
+                           dqkv.p + (long long)n * T * 3 * C + 2 * d, 3 * C, 3 * d, T, d, T, 1.f, IG_OUT_F16));
+    // dP^T = V dA^T                                               [s][t] fp32
+    for (int n = 0; n < N; ++n)
+      ISHAP_TRY(gemm_heads(qkv + (long long)n * T * 3 * C + 2 * d, 3 * C, 3 * d, dA.p + (long long)n * T * C, C, d,
+                           u->attn_S + (long long)n * heads * T * T, T, (long long)T * T, T, T, d, 1.f, IG_OUT_F32));
+    ISHAP_TRY(softmax_bwd_cols(u->attn_P, u->attn_S, u->attn_D, dST, BH, T, alpha, e.s));
+    // dK = dS^T Q
+    ISHAP_TRY(head_transpose(qkv, QT, N, T, 3 * C, heads, d, dpad, 3 * d, 0, e.s));
+    for (int n = 0; n < N; ++n)
+      ISHAP_TRY(gemm_heads(dST + (long long)n * heads * T * T, T, (long long)T * T, QT + (long long)n * heads * dpad * T, T,
+                           (long long)dpad * T, dqkv.p + (long long)n * T * 3 * C + d, 3 * C, 3 * d, T, d, T, 1.f,
+                           IG_OUT_F16));
+  }
+  Tensor dn;
+  ISHAP_TRY(dgrad_op(e, L.qkv, dqkv, dn, C));
+  dx = x;
+  dx.p = aalloc<half_t>(e, x.numel());
+  {
+    GnBwdArgs g;
+    g.g = dn.p; g.x = x.p; g.add = dy.p; g.dx = dx.p; g.stats = sv.stats; g.gamma = L.n.gamma; g.beta = L.n.beta;
+    g.N = N; g.H = x.H; g.W = x.W; g.C = C; g.film = 0; g.act = 0; g.gmode = GB_SAME;
+    ISHAP_TRY(gn_bwd_op(e, g));
+  }
+  return 0;
+}
+
+static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out) {
+  ishap_unet* u = e.u;
+  for (int i = (int)b.layers.size() - 1; i >= 0; --i) {
+    const LayerRef& l = b.layers[i];
+    Tensor dx;
+    if (l.kind == 0) {
+      ISHAP_TRY(dgrad_op(e, u->stem, g, dx, u->in_pad));
+    } else if (l.kind == 1) {
+      ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx));
+    } else {
+      ISHAP_TRY(attn_backward(e, u->attn[l.idx], g, dx));
+    }
+    g = dx;
+  }
+  out = g;
+  return 0;
+}
+
 int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const float* cot_out, const float* scale2, float* dx,
                        hipStream_t s, bool dry) {
-  if (dry) return 0;
-  ISHAP_REQUIRE(false, "backward not built yet");
+  Exec e{u, s, dry};
+  if (!dry) {
+    ISHAP_REQUIRE(u->have_saved, "backward needs a preceding forward with keep_for_backward=1");
+    u->arena.off = u->fwd_mark;
+  }
+  const ishap_unet_config& cfg = u->cfg;
+  const int N = dry ? cfg.max_batch : u->last_N;
+  const int n_in = (int)u->in_blocks.size(), n_out = (int)u->out_blocks.size();
+  int F;
+  Tensor g;
+  if (cot_out) {
+    // head backward: out = conv3x3(silu(gn(h)))  (unet.py:612-616,667-669)
+    F = n_out - 1;
+    const int S = cfg.image_size, opad = u->head.cout_pad;
+    Tensor dout{nullptr, N, S, S, opad};
+    dout.p = aalloc<half_t>(e, dout.numel());
+    if (!dry) ISHAP_TRY(nchw_to_nhwc_f16_scaled(cot_out, 1, dout.p, N, cfg.out_channels, S * S, opad, 1.f, s));
+    Tensor dact;
+    ISHAP_TRY(dgrad_op(e, u->head, dout, dact, u->final_ch));
+    g = u->h_final;
+    if (dry) g = Tensor{nullptr, N, S, S, u->final_ch};
+    Tensor gh = g;
+    gh.p = aalloc<half_t>(e, g.numel());
+    GnBwdArgs a;
+    a.g = dact.p; a.x = u->h_final.p; a.dx = gh.p; a.stats = u->head_stats; a.gamma = u->head_norm.gamma;
+    a.beta = u->head_norm.beta; a.N = N; a.H = S; a.W = S; a.C = u->final_ch; a.act = 1;
+    ISHAP_TRY(gn_bwd_op(e, a));
+    g = gh;
+  } else {
+    F = dry ? n_out - 1 : u->last_feat;
+    ISHAP_REQUIRE(F >= 0, "the last forward had no tap (feat_layer < 0)");
+    g = u->out_blocks[F].out;
+    g.p = const_cast<half_t*>(cot_tap);
+  }
+  std::vector<Tensor> skipgrad(n_in);
+  for (int i = F; i >= 0; --i) {
+    BlockL& b = u->out_blocks[i];
+    Tensor gcat;
+    ISHAP_TRY(block_backward(e, b, g, gcat));
+    const int Cs = b.skip_ch, Ch = b.cin - Cs;
+    Tensor gh{nullptr, gcat.N, gcat.H, gcat.W, Ch}, gs{nullptr, gcat.N, gcat.H, gcat.W, Cs};
+    gh.p = aalloc<half_t>(e, gh.numel());
+    gs.p = aalloc<half_t>(e, gs.numel());
+    if (!dry) {
+      ISHAP_TRY(slice_channels(gcat.p, gh.p, gcat.rows(), b.cin, 0, Ch, 0, s));
+      ISHAP_TRY(slice_channels(gcat.p, gs.p, gcat.rows(), b.cin, Ch, Cs, 0, s));
+    }
+    skipgrad[n_in - 1 - i] = gs;     // hs.pop() order (unet.py:663)
+    g = gh;
+  }
+  {
+    Tensor o;
+    ISHAP_TRY(block_backward(e, u->mid, g, o));
+    g = o;
+  }
+  for (int i = n_in - 1; i >= 0; --i) {
+    if (skipgrad[i].p) {
+      Tensor sum = g;
+      sum.p = aalloc<half_t>(e, g.numel());
+      if (!dry) ISHAP_TRY(add_f16(g.p, skipgrad[i].p, sum.p, g.numel(), s));
+      g = sum;
+    }
+    Tensor o;
+    ISHAP_TRY(block_backward(e, u->in_blocks[i], g, o));
+    g = o;
+  }
+  if (!dry)
+    ISHAP_TRY(nhwc_f16_to_nchw_f32_scaled(g.p, dx, N, cfg.in_channels, cfg.image_size * cfg.image_size, u->in_pad,
+                                          scale2 ? scale2 + 1 : nullptr, s));
+  return 0;
 }
+
 extern "C" int ishap_unet_backward_input(ishap_unet* u, const void* cot, const float* scale2, float* dx, void* stream) {
   ISHAP_REQUIRE(u && cot && dx, "null argument");
+  ISHAP_CHECK_HIP(hipSetDevice(u->device));
   return unet_backward_impl(u, (const half_t*)cot, nullptr, scale2, dx, (hipStream_t)stream, false);
 }
 extern "C" int ishap_unet_backward_from_output(ishap_unet* u, const float* cot_out, float* dx, void* stream) {
   ISHAP_REQUIRE(u && cot_out && dx, "null argument");
+  ISHAP_CHECK_HIP(hipSetDevice(u->device));
   return unet_backward_impl(u, nullptr, cot_out, nullptr, dx, (hipStream_t)stream, false);
 }

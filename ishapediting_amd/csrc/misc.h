@@ -17,3 +17,8 @@ int gemv_f32(const float* W, const float* b, const float* in, float* out, int ro
 int pack_conv_weight(const float* w, half_t* dst, int O, int I, int taps, int rows_pad, int cpad, int transpose_flip, hipStream_t s);
 int pack_conv_weight_split(const float* w, half_t* dst, int O, int I, int taps, int rows_pad, hipStream_t s);
 int round_through_f16(const float* src, float* dst, long long n, hipStream_t s);
+// attention backward pieces + gradient export (attn_bwd.hip)
+int exp_sub_lse_cols(const float* ST, const float* lse, half_t* PT, long long batches, int T, hipStream_t s);
+int softmax_bwd_rows(const half_t* P, const float* dP, half_t* dS, float* D, long long rows, int T, float alpha, hipStream_t s);
+int softmax_bwd_cols(const half_t* PT, const float* dPT, const float* D, half_t* dST, long long batches, int T, float alpha, hipStream_t s);
+int nhwc_f16_to_nchw_f32_scaled(const half_t* src, float* dst, int N, int C, int HW, int ld, const float* mul_dev, hipStream_t s);

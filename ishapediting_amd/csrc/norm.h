@@ -26,3 +26,24 @@ struct GnApplyArgs {
   int film = 0, act = 1, pool = 0, split = 0;
 };
 int gn_apply_launch(const GnApplyArgs& a, hipStream_t s);
+
+// ---- backward of  y = act(film(gn(x)))  w.r.t. x (no parameter gradients: the path never needs them) ----
+// g is the gradient arriving at y (possibly at another resolution, see gmode); result
+//   dx = rstd * (dyh - mean_g(dyh) - xh * mean_g(dyh * xh)) + add,   dyh = g * act'(.) * (1+scale) * gamma
+enum { GB_SAME = 0, GB_UNPOOL = 1, GB_SUM4 = 2 };
+struct GnBwdArgs {
+  const half_t* g = nullptr;      // upstream gradient: [N][H*W][C] (SAME), [N][H/2*W/2][C] (UNPOOL: each /4), [N][2H*2W][C] (SUM4)
+  const half_t* x = nullptr;      // GN input [N][H*W][C]
+  const half_t* add = nullptr;    // optional extra gradient added to dx, same indexing mode as g
+  half_t* dx = nullptr;           // [N][H*W][C]
+  const float* stats = nullptr;   // forward (mean, rstd) [N][32][2]
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  const float* emb = nullptr;     // film
+  int emb_ld = 0;
+  float* partial = nullptr;       // scratch, gn_partial_floats()
+  float* mstats = nullptr;        // scratch [N][32][2]
+  int N = 1, H = 0, W = 0, C = 0;
+  int film = 0, act = 1, gmode = GB_SAME;
+};
+int gn_backward_launch(const GnBwdArgs& a, hipStream_t s);

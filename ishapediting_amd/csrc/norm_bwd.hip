@@ -1,0 +1,180 @@
+// Input-gradient of  y = act(film(GroupNorm32(x)))  on NHWC fp16 maps.
+// Reference: what autograd derives for nn.py:16-18 + unet.py:248-252 when loss.backward() runs at
+// drag_utils.py:383.  No parameter gradients are formed (the reference computes and discards them).
+// Same two-stage deterministic reduction as the forward statistics; the forward's activations are
+// recomputed from the saved GN input and (mean, rstd) instead of being stored.
+#include "norm.h"
+
+__device__ __forceinline__ float rh_(float v) { return (float)(half_t)v; }
+__device__ __forceinline__ float silu_grad(float v) {
+  float sg = 1.f / (1.f + __expf(-v));
+  return sg * (1.f + v * (1.f - sg));
+}
+
+// gradient arriving at pixel (n, y, x) of the GN-input resolution, 8 channels
+__device__ __forceinline__ void load_upstream(const half_t* g, int gmode, int n, int y, int x, int H, int W, int C, int c0,
+                                              float* o) {
+  if (gmode == GB_SAME) {
+    half8 v = *reinterpret_cast<const half8*>(g + ((long long)n * H * W + y * W + x) * C + c0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  } else if (gmode == GB_UNPOOL) {      // forward was AvgPool2d(2,2): each input pixel gets 1/4 of its cell's gradient
+    const int Wh = W >> 1;
+    half8 v = *reinterpret_cast<const half8*>(g + ((long long)n * (H >> 1) * Wh + (y >> 1) * Wh + (x >> 1)) * C + c0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0.25f * (float)v[i];
+  } else {                              // forward was nearest x2: the gradients of the 4 copies add up
+    const int W2 = W << 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      half8 v = *reinterpret_cast<const half8*>(
+          g + ((long long)n * (H << 1) * W2 + (2 * y + (q >> 1)) * W2 + 2 * x + (q & 1)) * C + c0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] += (float)v[i];
+    }
+  }
+}
+
+// dyh[8] = upstream * act'(pre) * (1+scale) * gamma,  xh[8] = normalised input, for 8 channels of one pixel
+template <bool FILM, bool ACT>
+__device__ __forceinline__ void bwd_terms(const GnBwdArgs& a, int n, int y, int x, int c0, float* dyh, float* xh) {
+  const int cpg = a.C / 32;
+  float up[8];
+  load_upstream(a.g, a.gmode, n, y, x, a.H, a.W, a.C, c0, up);
+  half8 xv = *reinterpret_cast<const half8*>(a.x + ((long long)n * a.H * a.W + y * a.W + x) * a.C + c0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = c0 + i;
+    const int g = c / cpg;
+    const float mu = a.stats[(n * 32 + g) * 2], rs = a.stats[(n * 32 + g) * 2 + 1];
+    const float gam = a.gamma[c];
+    const float xhat = ((float)xv[i] - mu) * rs;
+    float u = up[i];
+    float mult = gam;
+    if (FILM || ACT) {
+      float pre = rh_(xhat * gam + a.beta[c]);
+      if (FILM) {
+        const float sc = rh_(1.f + rh_(a.emb[(long long)n * a.emb_ld + c]));
+        const float sh = rh_(a.emb[(long long)n * a.emb_ld + a.C + c]);
+        pre = rh_(rh_(pre * sc) + sh);
+        mult *= sc;
+      }
+      if (ACT) u *= silu_grad(pre);
+    }
+    dyh[i] = u * mult;
+    xh[i] = xhat;
+  }
+}
+
+template <bool FILM, bool ACT>
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnBwdArgs a, int rows_per_block) {
+  extern __shared__ float red[];
+  const int C = a.C, CV = C >> 3;
+  const int rpi = 256 / CV > 0 ? 256 / CV : 1;
+  const int tid = threadIdx.x, n = blockIdx.y, blk = blockIdx.x;
+  const int row0 = blk * rows_per_block;
+  const bool active = tid < rpi * CV;
+  const int cv = tid % CV, r0 = tid / CV;
+  float s[8], q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
+  if (active) {
+    for (int r = r0; r < rows_per_block; r += rpi) {
+      const int p = row0 + r;
+      float dyh[8], xh[8];
+      bwd_terms<FILM, ACT>(a, n, p / a.W, p % a.W, cv * 8, dyh, xh);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s[i] += dyh[i]; q[i] += dyh[i] * xh[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      red[((r0 * C) + cv * 8 + i) * 2 + 0] = s[i];
+      red[((r0 * C) + cv * 8 + i) * 2 + 1] = q[i];
+    }
+  }
+  __syncthreads();
+  float* out = a.partial + ((long long)n * gridDim.x + blk) * C * 2;
+  for (int c = tid; c < C * 2; c += 256) {
+    float acc = 0.f;
+    for (int r = 0; r < rpi; ++r) acc += red[r * C * 2 + c];
+    out[c] = acc;
+  }
+}
+
+// mstats[n][g] = (mean dyh, mean dyh*xh) over the group
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mstats,
+                                                              int nblk, int C, int HW) {
+  __shared__ double sh[2][256];
+  const int g = blockIdx.x, n = blockIdx.y, cpg = C / 32, tid = threadIdx.x;
+  double s = 0.0, q = 0.0;
+  const int total = nblk * cpg;
+  for (int i = tid; i < total; i += 256) {
+    int b = i / cpg, c = g * cpg + i % cpg;
+    const float* p = partial + (((long long)n * nblk + b) * C + c) * 2;
+    s += (double)p[0];
+    q += (double)p[1];
+  }
+  sh[0][tid] = s; sh[1][tid] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double cnt = (double)HW * cpg;
+    mstats[(n * 32 + g) * 2 + 0] = (float)(sh[0][0] / cnt);
+    mstats[(n * 32 + g) * 2 + 1] = (float)(sh[1][0] / cnt);
+  }
+}
+
+template <bool FILM, bool ACT>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
+  const int CV = a.C >> 3, HW = a.H * a.W, cpg = a.C / 32;
+  const long long total = (long long)a.N * HW * CV;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % CV);
+    const long long pix = idx / CV;
+    const int n = (int)(pix / HW), p = (int)(pix % HW);
+    const int y = p / a.W, x = p % a.W, c0 = cv * 8;
+    float dyh[8], xh[8], ad[8];
+    bwd_terms<FILM, ACT>(a, n, y, x, c0, dyh, xh);
+    if (a.add) load_upstream(a.add, a.gmode, n, y, x, a.H, a.W, a.C, c0, ad);
+    half8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int g = (c0 + i) / cpg;
+      const float rs = a.stats[(n * 32 + g) * 2 + 1];
+      const float m1 = a.mstats[(n * 32 + g) * 2], m2 = a.mstats[(n * 32 + g) * 2 + 1];
+      float v = rs * (dyh[i] - m1 - xh[i] * m2);
+      if (a.add) v += ad[i];
+      o[i] = (half_t)v;
+    }
+    *reinterpret_cast<half8*>(a.dx + pix * a.C + c0) = o;
+  }
+}
+
+int gn_backward_launch(const GnBwdArgs& a, hipStream_t s) {
+  ISHAP_REQUIRE(a.C % 32 == 0 && a.C / 8 <= 256, "GroupNorm channels");
+  const int HW = a.H * a.W;
+  const int rpb = gn_rows_per_block(HW), nblk = HW / rpb, CV = a.C / 8;
+  const int rpi = 256 / CV > 0 ? 256 / CV : 1;
+  const size_t smem = (size_t)rpi * a.C * 2 * sizeof(float);
+  long long total = (long long)a.N * HW * CV;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+#define GB_LAUNCH(F, A)                                                                                             \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((gn_bwd_partial_kernel<F, A>), dim3(nblk, a.N), dim3(256), smem, s, a, rpb);                 \
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(32, a.N), dim3(256), 0, s, a.partial, a.mstats, nblk, a.C, HW); \
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<F, A>), dim3(blocks), dim3(256), 0, s, a);                              \
+  } while (0)
+  if (a.film) GB_LAUNCH(true, true);
+  else if (a.act) GB_LAUNCH(false, true);
+  else GB_LAUNCH(false, false);
+#undef GB_LAUNCH
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}

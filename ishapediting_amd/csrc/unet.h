@@ -133,7 +133,23 @@ struct ishap_unet {
   Tensor tap;
   Tensor x0, h_final;
   float* head_stats = nullptr;
+  size_t fwd_mark = 0;          // arena offset after the forward (backward scratch goes above it)
+  float* gn_mstats = nullptr;   // backward GN scratch [max_batch][32][2]
+  float* attn_D = nullptr;      // backward attention row sums
+  size_t attn_D_floats = 0;
 };
+
+struct Exec {
+  ishap_unet* u;
+  hipStream_t s;
+  bool dry;
+};
+template <typename T>
+static inline T* aalloc(Exec& e, size_t count) { return (T*)e.u->arena.alloc(count * sizeof(T)); }
+// X [N,H,W,ldx] (*) Wt -> out; taps 9 (3x3, pad 1) or 1; picks split-K and uses the context workspace
+int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps, int cout,
+            const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups, int res_ups);
+int gn_stats_op(Exec& e, const Tensor& x, float* stats);
 
 int unet_build(ishap_unet* u);
 int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int feat_layer, float* out,

@@ -237,16 +237,7 @@ static int load_param(ishap_unet* u, ParamSlot& p, const float* data, hipStream_
 // ------------------------------------------------------------------------------------------------
 // op helpers
 // ------------------------------------------------------------------------------------------------
-struct Exec {
-  ishap_unet* u;
-  hipStream_t s;
-  bool dry;
-};
-
-template <typename T>
-static T* aalloc(Exec& e, size_t count) { return (T*)e.u->arena.alloc(count * sizeof(T)); }
-
-static int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps,
+int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps,
                    int cout, const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups,
                    int res_ups) {
   IgemmArgs a;
@@ -267,7 +258,7 @@ static int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const
   return igemm_launch(a, e.s);
 }
 
-static int gn_stats_op(Exec& e, const Tensor& x, float* stats) {
+int gn_stats_op(Exec& e, const Tensor& x, float* stats) {
   size_t need = gn_partial_floats(x.N, x.H * x.W, x.C);
   if (e.dry) {
     if (need > e.u->gn_partial_floats) e.u->gn_partial_floats = need;
@@ -471,6 +462,7 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
   u->last_N = N;
   u->last_feat = feat_layer;
   u->have_saved = keep != 0;
+  u->fwd_mark = u->arena.off;
   return 0;
 }
 
@@ -518,6 +510,8 @@ int ishap_unet_create(const ishap_unet_config* cfg, int device, ishap_unet** out
     ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_dS, 2 * u->attn_S_floats * sizeof(half_t)));
     ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_T, 4 * u->attn_T_halfs * sizeof(half_t) + 65536));
   }
+  ISHAP_CHECK_HIP(hipMalloc((void**)&u->gn_mstats, (size_t)cfg->max_batch * 64 * sizeof(float)));
+  if (u->attn_D_floats) ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_D, u->attn_D_floats * sizeof(float)));
   u->have_saved = false;
   *out = u;
   return 0;
@@ -536,7 +530,7 @@ void ishap_unet_destroy(ishap_unet* u) {
   for (auto& a : u->attn) { frc(a.qkv); frc(a.proj); fr(a.n.gamma); fr(a.n.beta); }
   fr(u->te_w0); fr(u->te_b0); fr(u->te_w2); fr(u->te_b2); fr(u->emb_w); fr(u->emb_b);
   fr(u->d_temb); fr(u->d_e1); fr(u->d_emb); fr(u->d_film);
-  fr(u->arena.base); fr(u->ws); fr(u->gn_partial); fr(u->attn_S); fr(u->attn_P); fr(u->attn_T); fr(u->attn_dS);
+  fr(u->arena.base); fr(u->ws); fr(u->gn_partial); fr(u->attn_S); fr(u->attn_P); fr(u->attn_T); fr(u->attn_dS); fr(u->gn_mstats); fr(u->attn_D);
   delete u;
 }
 

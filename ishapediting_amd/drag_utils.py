@@ -118,8 +118,10 @@ class DragKernels:
                               self.l1, self.touched.data_ptr(), self.nmask.data_ptr(), self.acc.data_ptr())
 
     def setup(self, sources, targets, cof: float):
-        self.sources = th.as_tensor(np.asarray(sources), dtype=th.float32).reshape(-1, 3).contiguous().to(self.device)
-        self.targets = th.as_tensor(np.asarray(targets), dtype=th.float32).reshape(-1, 3).contiguous().to(self.device)
+        def pts(v):
+            v = v.detach() if th.is_tensor(v) else th.as_tensor(np.asarray(v))
+            return v.to(device=self.device, dtype=th.float32).reshape(-1, 3).contiguous()
+        self.sources, self.targets = pts(sources), pts(targets)
         assert self.sources.shape[0] == self.targets.shape[0]
         self.cof = float(cof)
         a = self._args()
