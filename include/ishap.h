@@ -152,6 +152,13 @@ int ishap_triplane_decode_points(const float* planes, int S, const ishap_decoder
 int ishap_triplane_decode_grid(const float* planes, int S, const ishap_decoder_weights* w, const float* axis, int res,
                                float* volume, void* stream);
 
+/* ------------------------------------------------------------------ measurement aid (bench.py roofline leg)
+ * Brackets every implicit-GEMM launch with HIP events on its own stream between begin and end.
+ * out[v*3+{0,1,2}] = {launches, total ms, algorithmic FLOPs}; v: 0 conv3x3 128^2 tile, 1 conv3x3 64^2 tile,
+ * 2 GEMM 128^2 tile, 3 GEMM 64^2 tile. */
+int ishap_profile_begin(void);
+int ishap_profile_end(double* out, int nvar);
+
 #ifdef __cplusplus
 }
 #endif

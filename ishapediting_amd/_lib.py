@@ -68,6 +68,8 @@ SYMBOLS = {
     "ishap_planes_prepare": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p]),
     "ishap_triplane_decode_points": (C.c_int, [c_void_p, C.c_int, C.POINTER(DecoderWeightsC), c_void_p, C.c_longlong,
                                                c_void_p, c_void_p]),
+    "ishap_profile_begin": (C.c_int, []),
+    "ishap_profile_end": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "ishap_triplane_decode_grid": (C.c_int, [c_void_p, C.c_int, C.POINTER(DecoderWeightsC), c_void_p, C.c_int,
                                              c_void_p, c_void_p]),
 }
@@ -83,6 +85,13 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension is required (no CPU fallback exists). "
                 "Build it with `python -m ishapediting_amd.build`.")
+        # One HIP runtime per process: torch ships its own libamdhip64 and must be the one that is resident
+        # (torch owns the device memory and streams we are handed), so load it before our library resolves
+        # its libamdhip64.so.N dependency by SONAME.
+        import torch  # noqa: F401
+        tlib = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(tlib):
+            C.CDLL(tlib, mode=C.RTLD_GLOBAL)
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)     # AttributeError if the library does not export a declared symbol

@@ -68,6 +68,7 @@ struct IgemmArgs {
   int ksplit = 1;
   float alpha = 1.f;
   int out_mode = IG_OUT_F16;
+  float flops_scale = 1.f;       // algorithmic / executed FLOPs (1/3 for the hi-lo split head conv)
 };
 int igemm_launch(const IgemmArgs& a, hipStream_t s);
 // picks a split so the grid fills the chip; returns workspace floats needed

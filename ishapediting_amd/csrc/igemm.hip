@@ -235,6 +235,38 @@ __global__ void igemm_splitk_reduce(IgemmArgs a) {
   }
 }
 
+// ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream around the main kernel ----
+#include <vector>
+struct ProfRec { hipEvent_t a, b; double flops; int variant; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_prof_pool;
+static hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+extern "C" int ishap_profile_begin(void) {
+  for (auto& r : g_prof) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
+  g_prof.clear();
+  g_prof_on = true;
+  return 0;
+}
+// out[v*3 + {0,1,2}] = {launches, total milliseconds, algorithmic FLOPs} for variant v:
+//   0 conv3x3 128x128 tile, 1 conv3x3 64x64 tile, 2 GEMM 128x128 tile, 3 GEMM 64x64 tile
+extern "C" int ishap_profile_end(double* out, int nvar) {
+  g_prof_on = false;
+  for (int i = 0; i < nvar * 3; ++i) out[i] = 0.0;
+  for (auto& r : g_prof) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return -1;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return -1;
+    if (r.variant < nvar) { out[r.variant * 3] += 1.0; out[r.variant * 3 + 1] += ms; out[r.variant * 3 + 2] += r.flops; }
+  }
+  return 0;
+}
+
 template <int BM, int BN, int BK, int WM, int WN, bool CONV3>
 static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(half_t);
@@ -245,7 +277,18 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+  if (g_prof_on) {
+    ProfRec r;
+    r.a = prof_event(); r.b = prof_event();
+    r.flops = 2.0 * a.M * a.N * a.K * a.nbatch * a.flops_scale;
+    r.variant = (CONV3 ? 0 : 2) + (BM == 128 ? 0 : 1);
+    (void)hipEventRecord(r.a, s);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+    (void)hipEventRecord(r.b, s);
+    g_prof.push_back(r);
+  } else {
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+  }
   ISHAP_CHECK_HIP(hipGetLastError());
   if (a.ksplit > 1) {
     long long total = (long long)a.nbatch * a.M * (a.N >> 2);

@@ -247,6 +247,7 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
   a.ldx = ldx; a.ldw = taps * kpad; a.ldo = ldo; a.ldr = ldr;
   a.H = H; a.W = W; a.ups = ups; a.res_ups = res_ups;
   a.out_mode = out_mode;
+  a.flops_scale = (Wt == e.u->head.w) ? 1.f / 3.f : 1.f;
   a.ksplit = igemm_pick_ksplit(a.M, a.N, a.K, 1);
   size_t need = a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N : 0;
   if (e.dry) {
