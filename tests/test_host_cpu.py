@@ -1,0 +1,101 @@
+"""CPU-only checks of the host logic and of the C-ABI library (load + symbols; no compute calls without a GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = torch.from_numpy
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from ishapediting_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "ishap.h")).read()
+    declared = set(re.findall(r"\b(ishap_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/ishap.h but not exported"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    assert L.ishap_version() >= 1
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "ishapediting_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b|oracle/|ref_cpu", src, re.M), \
+                    f"{f} reaches into the oracle"
+
+
+@pytest.mark.parametrize("steps", [10, 40, 200, 256, 1000])
+def test_host_schedule_tables_bit_exact(gold, steps):
+    from ishapediting_amd.gaussian_diffusion import create_gaussian_diffusion
+    g = gold("g1_schedules")
+    d = create_gaussian_diffusion(timestep_respacing=str(steps))
+    assert d.timestep_map == g[f"T{steps}_timestep_map"].tolist()
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+              "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+        np.testing.assert_array_equal(getattr(d, k), g[f"T{steps}_{k}"])
+
+
+def test_resize_feat_align_and_offsets_match_reference(gold):
+    from ishapediting_amd.drag_utils import feat_channel_map, make_offsets, resize_feat_align
+    g = gold("g3_primitives")
+    for c in (512, 64, 96):
+        out = resize_feat_align(T(g[f"rfa_in_{c}"]))
+        np.testing.assert_array_equal(out.numpy(), g[f"rfa_out_{c}"])
+    cm = feat_channel_map(512)
+    assert cm.shape == (3, 170) and cm[0, 0] == 0 and cm[1, 0] == 85 and cm[0, 85] == 256 and cm.max() == 510
+    np.testing.assert_array_equal(make_offsets(2, "cpu").numpy(), g["offsets_r2"])
+
+
+def test_unet_spec_matches_full_reference_tree(gold):
+    from ishapediting_amd.unet_spec import build_spec, full_config
+    spec = build_spec(full_config())
+    assert [b.cout for b in spec.output_blocks][8] == 512 and spec.output_blocks[8].res_out == 64   # the drag tap
+    assert len(spec.input_blocks) == 15 and len(spec.output_blocks) == 15
+
+
+def test_get_args_defaults_and_no_argv_capture():
+    from ishapediting_amd.drag_utils import get_args
+    a = get_args()
+    assert (a.num_steps, a.w_time, a.feat_layer, a.shape_resolution, a.image_size) == (200, 170, 8, 256, 128)
+    assert a.use_fp16 and a.learn_sigma and a.timestep_respacing == "200"
+
+
+def _worker(rank, world, port, n_edits, q):
+    import torch.distributed as dist
+    from ishapediting_amd.parallel import gather_volumes, shard_edits
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    mine = shard_edits(n_edits, world, rank)
+    vols = [torch.full((4, 4, 4), float(i)) for i in mine]
+    out = gather_volumes(vols, n_edits, dst=0)
+    if rank == 0:
+        q.put([float(v[0, 0, 0]) for v in out])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_edits", [2, 3, 4])
+def test_gather_volumes_world_size_2_gloo(n_edits):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_edits, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [float(i) for i in range(n_edits)]
