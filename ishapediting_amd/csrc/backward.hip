@@ -13,7 +13,12 @@
 #include "norm.h"
 
 static int gn_bwd_op(Exec& e, GnBwdArgs g) {
-  if (e.dry) return 0;
+  const size_t need = gn_partial_floats(g.N, g.H * g.W, g.C);     // per-row-chunk partial sums (scratch)
+  if (e.dry) {
+    if (need > e.u->gn_partial_floats) e.u->gn_partial_floats = need;
+    return 0;
+  }
+  ISHAP_REQUIRE(need <= e.u->gn_partial_floats, "GroupNorm backward scratch too small");
   g.partial = e.u->gn_partial;
   g.mstats = e.u->gn_mstats;
   return gn_backward_launch(g, e.s);

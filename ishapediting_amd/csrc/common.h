@@ -39,6 +39,8 @@ void ishap_set_error(const std::string& msg);
     if (_r != 0) return _r;    \
   } while (0)
 
+#define STAT_SCALE_SUM 16777216.f      /* 2^24 */
+#define STAT_SCALE_SQ 1048576.f        /* 2^20 */
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
@@ -68,6 +70,8 @@ struct IgemmArgs {
   int ksplit = 1;
   float alpha = 1.f;
   int out_mode = IG_OUT_F16;
+  long long* stat_out = nullptr; // optional [N_img][N][2]: += per-channel (sum, sum of squares) of the fp16 outputs, as 64-bit
+                                 // fixed point (STAT_SCALE_*): integer atomics commute, so the statistics are bitwise reproducible
   float flops_scale = 1.f;       // algorithmic / executed FLOPs (1/3 for the hi-lo split head conv)
 };
 int igemm_launch(const IgemmArgs& a, hipStream_t s);

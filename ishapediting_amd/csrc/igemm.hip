@@ -14,6 +14,7 @@
 // (row>>1) so both the ds_write_b128 and the ds_read_b128 fragment reads are
 // bank-conflict free (lane-group table of the gfx950 LDS).
 #include "common.h"
+#include "igemm_epilogue.h"
 
 template <int BM, int BN, int BK, int WM, int WN, bool CONV3>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
@@ -154,10 +155,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     }
   }
 
-  // ---- epilogue: lane holds channels n..n+3 of pixel m ----
-#pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    const int m = m0 + wm * TMW + j * 16 + (lane & 15);
+  igemm_epilogue<MT, NT, TMW, TNW, BN>(a, acc, m0, n0, wm, wn, lane, batch, ks_id, reinterpret_cast<float*>(smem_raw));
+}
+
+// out = alpha * sum_z ws[z] (+bias)(+res).  Block = 16 rows x 64 channels (thread = one row, 4 channels); when
+// `stat_out` is set the block also adds its per-channel (sum, sum of squares) of the stored fp16 values.
+__global__ __launch_bounds__(256) void igemm_splitk_reduce(IgemmArgs a) {
+  __shared__ float red[16][64][2];
+  const int nq = (a.N + 63) / 64;                 // channel groups of 64
+  const int rb = a.M / 16;                        // row blocks
+  const int bid = blockIdx.x;
+  const int cg = bid % nq;
+  const int rbi = (bid / nq) % rb;
+  const int batch = bid / (nq * rb);
+  const int r = threadIdx.x >> 4, qd = threadIdx.x & 15;
+  const int m = rbi * 16 + r;
+  const int n = cg * 64 + qd * 4;
+  const bool ok = n < a.N;
+  const int HW = a.H * a.W;
+  half4 o = {0, 0, 0, 0};
+  if (ok) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < a.ksplit; ++z)
+      v += *reinterpret_cast<const f32x4*>(a.ws + (((long long)z * a.nbatch + batch) * a.M + m) * a.N + n);
+    v *= a.alpha;
+    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
     int n_img = 0, py = 0, px = 0;
     if (a.res_ups || a.out_mode == IG_OUT_NCHW_F32) {
       n_img = m / HW;
@@ -165,73 +187,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
       py = p / a.W;
       px = p - py * a.W;
     }
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int n = n0 + wn * TNW + i * 16 + (lane >> 4) * 4;
-      if (n >= a.N) continue;
-      f32x4 v = acc[i][j];
-      if (a.ksplit > 1) {
-        float* dst = a.ws + (((long long)ks_id * a.nbatch + batch) * a.M + m) * a.N + n;
-        *reinterpret_cast<f32x4*>(dst) = v;
-        continue;
-      }
-      v *= a.alpha;
-      if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-      if (a.res) {
-        long long rrow = a.res_ups ? ((long long)n_img * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1)) : m;
-        half4 r = *reinterpret_cast<const half4*>(a.res + rrow * a.ldr + n);
-        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
-      }
-      if (a.out_mode == IG_OUT_F16) {
-        half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        *reinterpret_cast<half4*>((half_t*)a.out + (long long)batch * a.bso + (long long)m * a.ldo + n) = o;
-      } else if (a.out_mode == IG_OUT_F32) {
-        *reinterpret_cast<f32x4*>((float*)a.out + (long long)batch * a.bso + (long long)m * a.ldo + n) = v;
-      } else {
-        float* o = (float*)a.out + ((long long)n_img * a.N + n) * HW + (py * a.W + px);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[(long long)r * HW] = v[r];
-      }
+    if (a.res) {
+      long long rrow = a.res_ups ? ((long long)n_img * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1)) : m;
+      half4 rr = *reinterpret_cast<const half4*>(a.res + rrow * a.ldr + n);
+      v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3];
+    }
+    if (a.out_mode == IG_OUT_F16) {
+      o = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<half4*>((half_t*)a.out + (long long)batch * a.bso + (long long)m * a.ldo + n) = o;
+    } else if (a.out_mode == IG_OUT_F32) {
+      *reinterpret_cast<f32x4*>((float*)a.out + (long long)batch * a.bso + (long long)m * a.ldo + n) = v;
+    } else {
+      float* op = (float*)a.out + ((long long)n_img * a.N + n) * HW + (py * a.W + px);
+      for (int k = 0; k < 4; ++k) op[(long long)k * HW] = v[k];
     }
   }
-}
-
-// out = alpha * sum_z ws[z] (+bias)(+res); one thread per 4 channels
-__global__ void igemm_splitk_reduce(IgemmArgs a) {
-  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int nq = a.N >> 2;
-  const long long total = (long long)a.nbatch * a.M * nq;
-  if (q >= total) return;
-  const int n = (int)(q % nq) * 4;
-  const long long bm = q / nq;
-  const int m = (int)(bm % a.M);
-  const int batch = (int)(bm / a.M);
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  for (int z = 0; z < a.ksplit; ++z)
-    v += *reinterpret_cast<const f32x4*>(a.ws + (((long long)z * a.nbatch + batch) * a.M + m) * a.N + n);
-  v *= a.alpha;
-  if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-  const int HW = a.H * a.W;
-  int n_img = 0, py = 0, px = 0;
-  if (a.res_ups || a.out_mode == IG_OUT_NCHW_F32) {
-    n_img = m / HW;
-    int p = m - n_img * HW;
-    py = p / a.W;
-    px = p - py * a.W;
-  }
-  if (a.res) {
-    long long rrow = a.res_ups ? ((long long)n_img * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1)) : m;
-    half4 r = *reinterpret_cast<const half4*>(a.res + rrow * a.ldr + n);
-    v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
-  }
-  if (a.out_mode == IG_OUT_F16) {
-    half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-    *reinterpret_cast<half4*>((half_t*)a.out + (long long)batch * a.bso + (long long)m * a.ldo + n) = o;
-  } else if (a.out_mode == IG_OUT_F32) {
-    *reinterpret_cast<f32x4*>((float*)a.out + (long long)batch * a.bso + (long long)m * a.ldo + n) = v;
-  } else {
-    float* o = (float*)a.out + ((long long)n_img * a.N + n) * HW + (py * a.W + px);
-    for (int r = 0; r < 4; ++r) o[(long long)r * HW] = v[r];
+  if (a.stat_out) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float f = (float)o[c];
+      red[r][qd * 4 + c][0] = f;
+      red[r][qd * 4 + c][1] = f * f;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 128) {
+      const int ch = t >> 1, k = t & 1;
+      float acc = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) acc += red[rr][ch][k];
+      const int nn = cg * 64 + ch;
+      if (nn < a.N)
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stat_out + ((long long)((rbi * 16) / HW) * a.N + nn) * 2 + k),
+                  (unsigned long long)__float2ll_rn(acc * (k ? STAT_SCALE_SQ : STAT_SCALE_SUM)));
+    }
   }
 }
 
@@ -267,6 +256,8 @@ extern "C" int ishap_profile_end(double* out, int nvar) {
   return 0;
 }
 
+int igemm2_launch_main(const IgemmArgs& a, bool big, hipStream_t s);   // igemm2.hip (LDS-DMA ring, BK = 64)
+
 template <int BM, int BN, int BK, int WM, int WN, bool CONV3>
 static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(half_t);
@@ -277,35 +268,47 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
+  auto fire = [&]() -> int {
+    if (BK == 64) return igemm2_launch_main(a, BM == 128, s);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+    return 0;
+  };
   if (g_prof_on) {
     ProfRec r;
     r.a = prof_event(); r.b = prof_event();
     r.flops = 2.0 * a.M * a.N * a.K * a.nbatch * a.flops_scale;
     r.variant = (CONV3 ? 0 : 2) + (BM == 128 ? 0 : 1);
     (void)hipEventRecord(r.a, s);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+    ISHAP_TRY(fire());
     (void)hipEventRecord(r.b, s);
     g_prof.push_back(r);
   } else {
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+    ISHAP_TRY(fire());
   }
   ISHAP_CHECK_HIP(hipGetLastError());
   if (a.ksplit > 1) {
-    long long total = (long long)a.nbatch * a.M * (a.N >> 2);
-    hipLaunchKernelGGL(igemm_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    const unsigned rblocks = (unsigned)((long long)a.nbatch * (a.M / 16) * ((a.N + 63) / 64));
+    hipLaunchKernelGGL(igemm_splitk_reduce, dim3(rblocks), dim3(256), 0, s, a);
     ISHAP_CHECK_HIP(hipGetLastError());
   }
   return 0;
 }
 
+// Tile and split-K policy.  256 CUs: prefer the 128x128 tile when it alone yields >= ~200 workgroups, otherwise the
+// 64x64 tile; split K only when even that leaves most of the chip idle (the small-map, weight-streaming layers),
+// keeping >= 6 K-steps of 64 per slice so the fp32 partial traffic stays below the weight traffic.
+static bool igemm_use_big(int M, int N, int nbatch) {
+  if (M % 128 != 0 || N < 128) return false;
+  long long blocks = (long long)(M / 128) * ceil_div(N, 128) * nbatch;
+  return blocks >= 192;
+}
 int igemm_pick_ksplit(int M, int N, int K, int nbatch) {
-  // aim for >= ~512 workgroups (2 per CU) while keeping >= 4 K-steps of 64 per slice
-  int bm = (M % 128 == 0 && M >= 1024) ? 128 : 64;
-  int bn = (N >= 128 && bm == 128) ? 128 : 64;
+  const bool big = igemm_use_big(M, N, nbatch);
+  const int bm = big ? 128 : 64, bn = big ? 128 : 64;
   long long blocks = (long long)(M / bm) * ceil_div(N, bn) * nbatch;
   int ks = K / 64;
   int split = 1;
-  while (blocks * split < 512 && ks / (split * 2) >= 4 && split < 32) split *= 2;
+  while (blocks * split < 160 && ks / (split * 2) >= 6 && split < 32) split *= 2;
   return split;
 }
 
@@ -317,7 +320,7 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
   ISHAP_REQUIRE(a.ksplit == 1 || a.ws != nullptr, "split-K needs a workspace");
   ISHAP_REQUIRE(a.ldx % 8 == 0 && a.ldw % 8 == 0, "row strides must keep 16-byte alignment");
   const bool k64 = a.conv3 ? (a.Cin % 64 == 0) : (a.K % 64 == 0);
-  const bool big = (a.M % 128 == 0) && a.M >= 1024 && a.N >= 128;
+  const bool big = igemm_use_big(a.M, a.N, a.nbatch);
 #define IG_DISPATCH(BM, BN, WM_, WN_)                                                          \
   do {                                                                                         \
     if (a.conv3) {                                                                             \

@@ -1,0 +1,222 @@
+// Implicit GEMM, second generation: LDS-DMA ring.
+// Same contract and output mapping as igemm.hip (weights = MFMA A operand, pixels = B operand, a lane
+// owns 4 consecutive output channels of one pixel), but operand tiles go global -> LDS directly with
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write), into an NST-deep ring.  A wave's instruction writes
+// 1 KiB linearly (wave-uniform base + lane*16), so the bank swizzle is applied to the per-lane SOURCE chunk and
+// again on the fragment read.  Zero padding of the 3x3 gather points the lane at a zero line instead of
+// predicating.  One raw s_barrier per K-step; loads stay in flight across it behind a counted s_waitcnt vmcnt.
+#include "common.h"
+#include "igemm_epilogue.h"
+
+__device__ __attribute__((aligned(128))) half_t g_zero_line[64];   // zero-initialised: source of padded rows
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int BM, int BN, int NST, bool CONV3>
+__global__ __launch_bounds__(256) void igemm2_kernel(IgemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only builtins; the host pass only needs the launch stub
+  constexpr int BK = 64;
+  constexpr int CPR = 8;                 // 16-byte chunks per tile row
+  constexpr int RPI = 8;                 // rows covered by one wave-instruction (64 lanes / CPR)
+  constexpr int XI = BM / RPI / 4;       // wave-instructions per wave per stage, X tile
+  constexpr int WI = BN / RPI / 4;
+  constexpr int STAGE = (BM + BN) * BK;  // halfs per ring slot
+  constexpr int TMW = BM / 2, TNW = BN / 2;
+  constexpr int MT = TMW / 16, NT = TNW / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  half_t* lds = reinterpret_cast<half_t*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with a private 4 MiB L2); remap the
+  // linear id so that one XCD gets a contiguous run of tiles (n fastest, then m): neighbouring image rows, whose 3x3
+  // halos overlap, and both n-tiles of the same rows then share an L2.  Pure speed: any placement is correct.
+  int tile_m, tile_n, tile_z;
+  {
+    const int nx = gridDim.x, ny = gridDim.y;
+    const int nwg = nx * ny * gridDim.z;
+    const int lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, pos = lin >> 3;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    tile_n = swz % ny;
+    tile_m = (swz / ny) % nx;
+    tile_z = swz / (ny * nx);
+  }
+#ifdef ABL_SAMEX
+  const int m0 = (tile_m & 1) * BM;      // every block reads the same two pixel tiles (L2-hot probe; wrong results)
+#else
+  const int m0 = tile_m * BM;
+#endif
+  const int n0 = tile_n * BN;
+  const int batch = tile_z / a.ksplit;
+  const int ks_id = tile_z % a.ksplit;
+  const half_t* X = a.X + (long long)batch * a.bsx;
+  const half_t* Wt = a.Wt + (long long)batch * a.bsw;
+  const int KS = a.K / BK;
+  const int per = (KS + a.ksplit - 1) / a.ksplit;
+  const int ks0 = ks_id * per;
+  const int ks1 = min(KS, ks0 + per);
+  const int nk = ks1 - ks0;
+  const int HW = a.H * a.W;
+
+  // ---- loader state: instruction i of this wave covers tile rows (wave*XI + i)*8 .. +7.  K order is tap-outer,
+  //      channel-inner (k = tap*Cin + c, linear in the K-step).  Source pointers are incremental: they advance by BK
+  //      halfs per K-step and are recomputed only when the 3x3 tap changes (measured: the chunk-outer order that
+  //      re-reads an activation line on consecutive steps is not faster -- the DMA rate, not L2 locality, bounds it). ----
+  const int steps_per_tap = CONV3 ? a.Cin / BK : KS;
+  const int lrow = lane >> 3;            // row within the instruction
+  const int pch = lane & 7;              // physical chunk this lane fills
+  int xn[XI], xy[XI], xx[XI], xsc[XI];
+  const half_t* xp[XI];
+  int xstep[XI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int row = (wave * XI + i) * RPI + lrow;
+    xsc[i] = (pch ^ ((row >> 1) & 7)) * 8;     // source chunk (halfs) for this physical slot
+    const int m = m0 + row;
+    if (CONV3) {
+      xn[i] = m / HW;
+      const int p = m - xn[i] * HW;
+      xy[i] = p / a.W;
+      xx[i] = p - xy[i] * a.W;
+      xp[i] = g_zero_line;
+      xstep[i] = 0;
+    } else {
+      xn[i] = m; xy[i] = 0; xx[i] = 0;
+      xp[i] = X + (long long)m * a.ldx + (long long)ks0 * BK + xsc[i];
+      xstep[i] = BK;
+    }
+  }
+  const half_t* wp[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int row = (wave * WI + i) * RPI + lrow;
+    wp[i] = Wt + (long long)(n0 + row) * a.ldw + (long long)ks0 * BK + (pch ^ ((row >> 1) & 7)) * 8;
+  }
+  int tap_left = 0;                      // K-steps left before the tap changes (conv)
+  int next_ks = ks0;
+
+  auto retap = [&]() {
+    const int tap = next_ks / steps_per_tap;
+    const int c0 = (next_ks - tap * steps_per_tap) * BK;
+    tap_left = steps_per_tap - (next_ks - tap * steps_per_tap);
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int yy = xy[i] + dy, xc = xx[i] + dx;
+      const bool ok = yy >= 0 && yy < a.H && xc >= 0 && xc < a.W;
+      const int yc = ok ? yy : 0, xq = ok ? xc : 0;
+      const long long pix = a.ups ? ((long long)xn[i] * (HW >> 2) + (yc >> 1) * (a.W >> 1) + (xq >> 1))
+                                  : ((long long)xn[i] * HW + yc * a.W + xq);
+      const half_t* src = X + pix * a.ldx + c0 + xsc[i];
+      xp[i] = ok ? src : (const half_t*)g_zero_line;
+      xstep[i] = ok ? BK : 0;
+    }
+  };
+
+  auto issue = [&](int slot) {
+    if (CONV3) {
+      if (tap_left == 0) retap();
+      --tap_left;
+    }
+    ++next_ks;
+    half_t* sx = lds + slot * STAGE;
+    half_t* sw = sx + BM * BK;
+#ifndef ABL_NOLOAD
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      __builtin_amdgcn_global_load_lds(xp[i], (lds_void*)(sx + (wave * XI + i) * RPI * BK), 16, 0, 0);
+      xp[i] += xstep[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      __builtin_amdgcn_global_load_lds(wp[i], (lds_void*)(sw + (wave * WI + i) * RPI * BK), 16, 0, 0);
+      wp[i] += BK;
+    }
+#endif
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: NST-1 stages in flight ----
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) issue(s);
+
+  for (int k = 0; k < nk; ++k) {
+    // stage k must have landed: stages up to min(nk, k+NST-1)-1 are issued, (XI+WI) instructions each
+    if (k + NST - 1 <= nk) {
+      #if defined(ABL_NOX)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (WI)) : "memory");
+#elif defined(ABL_NOW)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (XI)) : "memory");
+#else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (XI + WI)) : "memory");
+#endif
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (k + NST - 1 < nk) issue((k + NST - 1) % NST);
+    const half_t* bx = lds + (k % NST) * STAGE;
+    const half_t* bw = bx + BM * BK;
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      half8 xf[MT], wf[NT];
+      const int ch = (lane >> 4) + 4 * kk;
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int row = wm * TMW + j * 16 + (lane & 15);
+        xf[j] = *reinterpret_cast<const half8*>(bx + row * BK + ((ch ^ ((row >> 1) & 7)) * 8));
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int row = wn * TNW + i * 16 + (lane & 15);
+        wf[i] = *reinterpret_cast<const half8*>(bw + row * BK + ((ch ^ ((row >> 1) & 7)) * 8));
+      }
+#ifndef ABL_NOMFMA
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i][0][0] += (float)wf[i][0];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[0][j][1] += (float)xf[j][0];
+#endif
+    }
+  }
+
+  igemm_epilogue<MT, NT, TMW, TNW, BN>(a, acc, m0, n0, wm, wn, lane, batch, ks_id, reinterpret_cast<float*>(smem_raw));
+#endif
+}
+
+template <int BM, int BN, int NST, bool CONV3>
+static int launch2(const IgemmArgs& a, hipStream_t s) {
+  constexpr size_t smem = (size_t)NST * (BM + BN) * 64 * sizeof(half_t);
+  auto kern = igemm2_kernel<BM, BN, NST, CONV3>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ISHAP_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// main kernel only (the caller adds the split-K reduce); big = 128x128 tile, else 64x64
+int igemm2_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
+  if (big) return a.conv3 ? launch2<128, 128, 4, true>(a, s) : launch2<128, 128, 4, false>(a, s);
+  return a.conv3 ? launch2<64, 64, 4, true>(a, s) : launch2<64, 64, 4, false>(a, s);
+}

@@ -5,7 +5,8 @@
 int nchw_f32_to_nhwc_f16(const float* src, half_t* dst, int N, int C, int HW, int Cpad, hipStream_t s);
 int nhwc_f16_to_nchw(const half_t* src, void* dst, int out_f32, int N, int C, int HW, int ld, hipStream_t s);
 int nchw_to_nhwc_f16_scaled(const void* src, int src_f32, half_t* dst, int N, int C, int HW, int ld, float mul, hipStream_t s);
-int concat2(const half_t* a, const half_t* b, half_t* o, long long M, int Ca, int Cb, hipStream_t s);
+int concat2(const half_t* a, const half_t* b, half_t* o, long long M, int Ca, int Cb, hipStream_t s,
+            const long long* sa = nullptr, const long long* sb = nullptr, long long* so = nullptr, int N = 1);
 int slice_channels(const half_t* src, half_t* o, long long M, int Cs, int off, int Co, int accumulate, hipStream_t s);
 int add_f16(const half_t* a, const half_t* b, half_t* o, long long n, hipStream_t s);
 int head_transpose(const half_t* src, half_t* dst, int N, int T, int ld, int heads, int d, int dpad, int head_stride,

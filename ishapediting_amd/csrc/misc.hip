@@ -84,7 +84,15 @@ int nchw_to_nhwc_f16_scaled(const void* src, int src_f32, half_t* dst, int N, in
 
 // --------------------------- channel concat / split (16-byte vectors) ---------------------------
 __global__ void concat2_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, half_t* __restrict__ o,
-                               long long M, int Ca, int Cb) {
+                               long long M, int Ca, int Cb, const long long* __restrict__ sa,
+                               const long long* __restrict__ sb, long long* __restrict__ so, int N) {
+  if (so && blockIdx.x == 0) {           // per-channel GroupNorm sums of the concatenation = concatenation of the sums
+    const int Cc = Ca + Cb;
+    for (int i = threadIdx.x; i < N * Cc * 2; i += blockDim.x) {
+      const int k = i & 1, c = (i >> 1) % Cc, n = (i >> 1) / Cc;
+      so[i] = c < Ca ? sa[(n * Ca + c) * 2 + k] : sb[(n * Cb + (c - Ca)) * 2 + k];
+    }
+  }
   const int CV = (Ca + Cb) >> 3, CVa = Ca >> 3;
   const long long total = M * CV;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -95,10 +103,11 @@ __global__ void concat2_kernel(const half_t* __restrict__ a, const half_t* __res
     *reinterpret_cast<half8*>(o + m * (Ca + Cb) + cv * 8) = v;
   }
 }
-int concat2(const half_t* a, const half_t* b, half_t* o, long long M, int Ca, int Cb, hipStream_t s) {
+int concat2(const half_t* a, const half_t* b, half_t* o, long long M, int Ca, int Cb, hipStream_t s, const long long* sa,
+            const long long* sb, long long* so, int N) {
   long long total = M * ((Ca + Cb) / 8);
   int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(concat2_kernel, dim3(blocks), dim3(256), 0, s, a, b, o, M, Ca, Cb);
+  hipLaunchKernelGGL(concat2_kernel, dim3(blocks), dim3(256), 0, s, a, b, o, M, Ca, Cb, sa, sb, so, N);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

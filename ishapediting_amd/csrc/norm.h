@@ -17,7 +17,9 @@ struct GnApplyArgs {
   const half_t* x = nullptr;     // [N][H*W][C]
   half_t* out = nullptr;         // [N][HWo][C]  (or [N][HW][3C] when split)
   half_t* xpool = nullptr;       // pool: pooled raw x (may be null)
-  const float* stats = nullptr;  // [N][32][2]
+  const float* stats = nullptr;  // [N][32][2] (mean, rstd) -- used when `sums` is null
+  const long long* sums = nullptr;  // [N][C][2] per-channel (sum, sum of squares), 64-bit fixed point, from the producer's epilogue
+  float* stats_out = nullptr;    // with `sums`: block 0 stores the finalised (mean, rstd) here for the backward pass
   const float* gamma = nullptr;
   const float* beta = nullptr;
   const float* emb = nullptr;    // film: per image (scale[C] | shift[C]) fp32, images emb_ld floats apart

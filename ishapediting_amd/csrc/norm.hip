@@ -116,6 +116,37 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
   const int HWo = POOL ? (a.H >> 1) * (a.W >> 1) : a.H * a.W;
   const long long total = (long long)a.N * HWo * CV;
   const int cpg = a.C / 32;
+  // statistics: either finalised already (a.stats) or finalised here from the producer's per-channel sums:
+  // 8 lanes per (image, group) add up the group's channels, then mean / rstd (gd/nn.py:16-18, eps 1e-5)
+  __shared__ float sh_stats[16 * 32 * 2];
+  const float* stats = a.stats;
+  if (a.sums) {
+    const float cnt = (float)(a.H * a.W) * (float)cpg;
+    for (int idx = threadIdx.x; idx < a.N * 32 * 8; idx += 256) {
+      const int part = idx & 7, g = (idx >> 3) & 31, n = idx >> 8;
+      float s = 0.f, q = 0.f;
+      for (int c = g * cpg + part; c < (g + 1) * cpg; c += 8) {
+        s += (float)a.sums[((long long)n * a.C + c) * 2] * (1.f / STAT_SCALE_SUM);
+        q += (float)a.sums[((long long)n * a.C + c) * 2 + 1] * (1.f / STAT_SCALE_SQ);
+      }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+      if (part == 0) {
+        const float mean = s / cnt;
+        float var = q / cnt - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        const float rstd = rsqrtf(var + 1e-5f);
+        sh_stats[(n * 32 + g) * 2] = mean;
+        sh_stats[(n * 32 + g) * 2 + 1] = rstd;
+        if (a.stats_out && blockIdx.x == 0) {
+          a.stats_out[(n * 32 + g) * 2] = mean;
+          a.stats_out[(n * 32 + g) * 2 + 1] = rstd;
+        }
+      }
+    }
+    __syncthreads();
+    stats = sh_stats;
+  }
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int cv = (int)(idx % CV);
@@ -130,8 +161,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
       int g = c / cpg;
       gam[i] = a.gamma[c];
       bet[i] = a.beta[c];
-      mu[i] = a.stats[(n * 32 + g) * 2];
-      rs[i] = a.stats[(n * 32 + g) * 2 + 1];
+      mu[i] = stats[(n * 32 + g) * 2];
+      rs[i] = stats[(n * 32 + g) * 2 + 1];
       if (FILM) {
         sc[i] = rh(1.f + rh(a.emb[(long long)n * a.emb_ld + c]));
         sh[i] = rh(a.emb[(long long)n * a.emb_ld + a.C + c]);
@@ -193,7 +224,7 @@ int gn_apply_launch(const GnApplyArgs& a, hipStream_t s) {
   const int HWo = a.pool ? (a.H / 2) * (a.W / 2) : a.H * a.W;
   long long total = (long long)a.N * HWo * (a.C / 8);
   int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > (a.sums ? 1024 : 4096)) blocks = a.sums ? 1024 : 4096;   // fewer, fatter blocks amortise the finalise prologue
   dim3 g(blocks), b(256);
   if (a.split) hipLaunchKernelGGL((gn_apply_kernel<false, true, false, true>), g, b, 0, s, a);
   else if (a.pool) hipLaunchKernelGGL((gn_apply_kernel<false, true, true, false>), g, b, 0, s, a);

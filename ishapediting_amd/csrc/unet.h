@@ -10,6 +10,7 @@
 struct Tensor {
   half_t* p = nullptr;
   int N = 0, H = 0, W = 0, C = 0;
+  long long* sums = nullptr;   // [N][C][2] per-channel (sum, sum of squares), fixed point, gathered by the producer; or null
   long long rows() const { return (long long)N * H * W; }
   long long numel() const { return rows() * C; }
 };
@@ -133,6 +134,8 @@ struct ishap_unet {
   Tensor tap;
   Tensor x0, h_final;
   float* head_stats = nullptr;
+  long long* stat_base = nullptr;   // arena of per-channel GroupNorm sums, zeroed once per forward
+  size_t stat_cap = 0, stat_off = 0, stat_high = 0;
   size_t fwd_mark = 0;          // arena offset after the forward (backward scratch goes above it)
   float* gn_mstats = nullptr;   // backward GN scratch [max_batch][32][2]
   float* attn_D = nullptr;      // backward attention row sums
@@ -148,7 +151,9 @@ template <typename T>
 static inline T* aalloc(Exec& e, size_t count) { return (T*)e.u->arena.alloc(count * sizeof(T)); }
 // X [N,H,W,ldx] (*) Wt -> out; taps 9 (3x3, pad 1) or 1; picks split-K and uses the context workspace
 int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps, int cout,
-            const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups, int res_ups);
+            const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups, int res_ups,
+            long long* stat_out = nullptr);
+long long* salloc(Exec& e, size_t count);   // from the stats arena
 int gn_stats_op(Exec& e, const Tensor& x, float* stats);
 
 int unet_build(ishap_unet* u);

@@ -237,10 +237,20 @@ static int load_param(ishap_unet* u, ParamSlot& p, const float* data, hipStream_
 // ------------------------------------------------------------------------------------------------
 // op helpers
 // ------------------------------------------------------------------------------------------------
+long long* salloc(Exec& e, size_t count) {
+  ishap_unet* u = e.u;
+  size_t o = (u->stat_off + 63) / 64 * 64;
+  u->stat_off = o + count;
+  if (u->stat_off > u->stat_high) u->stat_high = u->stat_off;
+  if (e.dry) return (long long*)(uintptr_t)(0x1000 + o * 8);
+  return u->stat_off <= u->stat_cap ? u->stat_base + o : nullptr;
+}
+
 int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps,
                    int cout, const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups,
-                   int res_ups) {
+                   int res_ups, long long* stat_out) {
   IgemmArgs a;
+  a.stat_out = stat_out;
   a.X = X; a.Wt = Wt; a.out = out; a.bias = bias; a.res = res;
   a.M = N * H * W; a.N = cout; a.K = taps * kpad;
   a.conv3 = taps == 9; a.Cin = kpad;
@@ -265,6 +275,7 @@ int gn_stats_op(Exec& e, const Tensor& x, float* stats) {
     if (need > e.u->gn_partial_floats) e.u->gn_partial_floats = need;
     return 0;
   }
+  ISHAP_REQUIRE(need <= e.u->gn_partial_floats, "GroupNorm statistics scratch too small");
   return gn_stats_launch(x.p, e.u->gn_partial, stats, x.N, x.H * x.W, x.C, e.s);
 }
 
@@ -275,7 +286,7 @@ static int res_forward(Exec& e, ResL& L, const Tensor& x, Tensor& y) {
   ISHAP_REQUIRE(x.C == L.cin, "ResBlock input channels");
   float* st1 = aalloc<float>(e, (size_t)N * 64);
   float* st2 = aalloc<float>(e, (size_t)N * 64);
-  ISHAP_TRY(gn_stats_op(e, x, st1));
+  if (!x.sums) ISHAP_TRY(gn_stats_op(e, x, st1));
   Tensor a{nullptr, N, L.down ? Ho : H, L.down ? Wo : W, L.cin};
   a.p = aalloc<half_t>(e, a.numel());
   Tensor xs = x;
@@ -283,34 +294,35 @@ static int res_forward(Exec& e, ResL& L, const Tensor& x, Tensor& y) {
   if (!e.dry) {
     GnApplyArgs g;
     g.x = x.p; g.out = a.p; g.xpool = L.down ? xs.p : nullptr;
-    g.stats = st1; g.gamma = L.n1.gamma; g.beta = L.n1.beta;
+    g.stats = st1; g.sums = x.sums; g.stats_out = x.sums ? st1 : nullptr; g.gamma = L.n1.gamma; g.beta = L.n1.beta;
     g.N = N; g.H = H; g.W = W; g.C = L.cin; g.act = 1; g.pool = L.down;
     ISHAP_TRY(gn_apply_launch(g, e.s));
   }
   Tensor h1{nullptr, N, Ho, Wo, L.cout};
   h1.p = aalloc<half_t>(e, h1.numel());
+  h1.sums = salloc(e, (size_t)N * L.cout * 2);
   ISHAP_TRY(conv_op(e, a.p, N, Ho, Wo, L.cin, L.c1.w, L.c1.kpad, 9, L.cout, L.c1.bias, nullptr, 0, h1.p, L.cout, IG_OUT_F16,
-                    L.up, 0));
-  ISHAP_TRY(gn_stats_op(e, h1, st2));
+                    L.up, 0, h1.sums));
   Tensor c = h1;
   c.p = aalloc<half_t>(e, h1.numel());
   if (!e.dry) {
     GnApplyArgs g;
-    g.x = h1.p; g.out = c.p; g.stats = st2; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
+    g.x = h1.p; g.out = c.p; g.stats = st2; g.sums = h1.sums; g.stats_out = st2; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
     g.emb = u->d_film + L.emb_off; g.emb_ld = u->film_rows;
     g.N = N; g.H = Ho; g.W = Wo; g.C = L.cout; g.film = 1; g.act = 1;
     ISHAP_TRY(gn_apply_launch(g, e.s));
   }
   y = h1;
   y.p = aalloc<half_t>(e, h1.numel());
+  y.sums = salloc(e, (size_t)N * L.cout * 2);
   if (L.has_skip) {
     ISHAP_TRY(conv_op(e, xs.p, N, Ho, Wo, L.cin, L.skip.w, L.skip.kpad, 1, L.cout, L.skip.bias, nullptr, 0, y.p, L.cout,
                       IG_OUT_F16, 0, 0));
     ISHAP_TRY(conv_op(e, c.p, N, Ho, Wo, L.cout, L.c2.w, L.c2.kpad, 9, L.cout, L.c2.bias, y.p, L.cout, y.p, L.cout,
-                      IG_OUT_F16, 0, 0));
+                      IG_OUT_F16, 0, 0, y.sums));
   } else {
     ISHAP_TRY(conv_op(e, c.p, N, Ho, Wo, L.cout, L.c2.w, L.c2.kpad, 9, L.cout, L.c2.bias, xs.p, L.cin, y.p, L.cout,
-                      IG_OUT_F16, 0, L.up));
+                      IG_OUT_F16, 0, L.up, y.sums));
   }
   L.sv.x = x; L.sv.h1 = h1; L.sv.xs = xs; L.sv.stats1 = st1; L.sv.stats2 = st2;
   return 0;
@@ -324,12 +336,12 @@ static int attn_forward(Exec& e, AttnL& L, const Tensor& x, Tensor& y) {
   ISHAP_REQUIRE(d % 32 == 0, "head width must be a multiple of 32");
   float* st = aalloc<float>(e, (size_t)N * 64);
   float* lse = aalloc<float>(e, (size_t)N * heads * T);
-  ISHAP_TRY(gn_stats_op(e, x, st));
+  if (!x.sums) ISHAP_TRY(gn_stats_op(e, x, st));
   Tensor nrm = x;
   nrm.p = aalloc<half_t>(e, x.numel());
   if (!e.dry) {
     GnApplyArgs g;
-    g.x = x.p; g.out = nrm.p; g.stats = st; g.gamma = L.n.gamma; g.beta = L.n.beta;
+    g.x = x.p; g.out = nrm.p; g.stats = st; g.sums = x.sums; g.stats_out = x.sums ? st : nullptr; g.gamma = L.n.gamma; g.beta = L.n.beta;
     g.N = N; g.H = x.H; g.W = x.W; g.C = C; g.act = 0;
     ISHAP_TRY(gn_apply_launch(g, e.s));
   }
@@ -368,7 +380,9 @@ static int attn_forward(Exec& e, AttnL& L, const Tensor& x, Tensor& y) {
   }
   y = x;
   y.p = aalloc<half_t>(e, x.numel());
-  ISHAP_TRY(conv_op(e, a.p, N, x.H, x.W, C, L.proj.w, L.proj.kpad, 1, C, L.proj.bias, x.p, C, y.p, C, IG_OUT_F16, 0, 0));
+  y.sums = salloc(e, (size_t)N * C * 2);
+  ISHAP_TRY(conv_op(e, a.p, N, x.H, x.W, C, L.proj.w, L.proj.kpad, 1, C, L.proj.bias, x.p, C, y.p, C, IG_OUT_F16, 0, 0,
+                    y.sums));
   L.sv.x = x; L.sv.qkv = qkv; L.sv.a = a; L.sv.stats = st; L.sv.lse = lse;
   return 0;
 }
@@ -380,8 +394,9 @@ static int block_forward(Exec& e, BlockL& b, Tensor h, Tensor& out) {
     if (l.kind == 0) {
       y = Tensor{nullptr, h.N, h.H, h.W, u->stem.cout};
       y.p = aalloc<half_t>(e, y.numel());
+      y.sums = salloc(e, (size_t)h.N * u->stem.cout * 2);
       ISHAP_TRY(conv_op(e, h.p, h.N, h.H, h.W, h.C, u->stem.w, u->stem.kpad, 9, u->stem.cout, u->stem.bias, nullptr, 0, y.p,
-                        u->stem.cout, IG_OUT_F16, 0, 0));
+                        u->stem.cout, IG_OUT_F16, 0, 0, y.sums));
     } else if (l.kind == 1) {
       ISHAP_TRY(res_forward(e, u->res[l.idx], h, y));
     } else {
@@ -401,6 +416,8 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
   ISHAP_REQUIRE(feat_layer < (int)u->out_blocks.size(), "feat_layer out of range");
   Exec e{u, s, dry};
   u->arena.reset();
+  u->stat_off = 0;
+  if (!dry && u->stat_cap) ISHAP_CHECK_HIP(hipMemsetAsync(u->stat_base, 0, u->stat_cap * sizeof(long long), s));
   u->have_saved = false;
   const int S = cfg.image_size, HW = S * S;
   // ---- timestep embedding -> emb -> every ResBlock's (scale | shift)   (unet.py:651, :245-250) ----
@@ -437,7 +454,8 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     Tensor cat{nullptr, h.N, h.H, h.W, h.C + skip.C};
     ISHAP_REQUIRE(skip.H == h.H && cat.C == b.cin, "skip connection shape");
     cat.p = aalloc<half_t>(e, cat.numel());
-    if (!dry) ISHAP_TRY(concat2(h.p, skip.p, cat.p, cat.rows(), h.C, skip.C, s));
+    cat.sums = (h.sums && skip.sums) ? salloc(e, (size_t)cat.N * cat.C * 2) : nullptr;
+    if (!dry) ISHAP_TRY(concat2(h.p, skip.p, cat.p, cat.rows(), h.C, skip.C, s, h.sums, skip.sums, cat.sums, cat.N));
     b.cat = cat;
     Tensor y;
     ISHAP_TRY(block_forward(e, b, cat, y));
@@ -448,11 +466,12 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
   // ---- head in fp32 (unet.py:667-669): GroupNorm, SiLU, 3x3 conv with fp32 weights.  The fp32 products are
   //      formed on the fp16 MFMA from hi/lo splits of both operands (3 partial products, fp32 accumulate). ----
   u->head_stats = aalloc<float>(e, (size_t)N * 64);
-  ISHAP_TRY(gn_stats_op(e, h, u->head_stats));
+  if (!h.sums) ISHAP_TRY(gn_stats_op(e, h, u->head_stats));
   half_t* hsplit = aalloc<half_t>(e, (size_t)h.numel() * 3);
   if (!dry) {
     GnApplyArgs g;
-    g.x = h.p; g.out = hsplit; g.stats = u->head_stats; g.gamma = u->head_norm.gamma; g.beta = u->head_norm.beta;
+    g.x = h.p; g.out = hsplit; g.stats = u->head_stats; g.sums = h.sums; g.stats_out = h.sums ? u->head_stats : nullptr;
+    g.gamma = u->head_norm.gamma; g.beta = u->head_norm.beta;
     g.N = N; g.H = S; g.W = S; g.C = h.C; g.act = 1; g.split = 1;
     ISHAP_TRY(gn_apply_launch(g, s));
   }
@@ -511,6 +530,8 @@ int ishap_unet_create(const ishap_unet_config* cfg, int device, ishap_unet** out
     ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_dS, 2 * u->attn_S_floats * sizeof(half_t)));
     ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_T, 4 * u->attn_T_halfs * sizeof(half_t) + 65536));
   }
+  u->stat_cap = (u->stat_high + 1023) / 1024 * 1024;
+  ISHAP_CHECK_HIP(hipMalloc((void**)&u->stat_base, std::max<size_t>(u->stat_cap, 1024) * sizeof(long long)));
   ISHAP_CHECK_HIP(hipMalloc((void**)&u->gn_mstats, (size_t)cfg->max_batch * 64 * sizeof(float)));
   if (u->attn_D_floats) ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_D, u->attn_D_floats * sizeof(float)));
   u->have_saved = false;
@@ -531,7 +552,7 @@ void ishap_unet_destroy(ishap_unet* u) {
   for (auto& a : u->attn) { frc(a.qkv); frc(a.proj); fr(a.n.gamma); fr(a.n.beta); }
   fr(u->te_w0); fr(u->te_b0); fr(u->te_w2); fr(u->te_b2); fr(u->emb_w); fr(u->emb_b);
   fr(u->d_temb); fr(u->d_e1); fr(u->d_emb); fr(u->d_film);
-  fr(u->arena.base); fr(u->ws); fr(u->gn_partial); fr(u->attn_S); fr(u->attn_P); fr(u->attn_T); fr(u->attn_dS); fr(u->gn_mstats); fr(u->attn_D);
+  fr(u->arena.base); fr(u->ws); fr(u->gn_partial); fr(u->attn_S); fr(u->attn_P); fr(u->attn_T); fr(u->attn_dS); fr(u->gn_mstats); fr(u->attn_D); fr(u->stat_base);
   delete u;
 }
 
