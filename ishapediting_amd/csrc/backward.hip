@@ -13,14 +13,9 @@
 #include "norm.h"
 
 static int gn_bwd_op(Exec& e, GnBwdArgs g) {
-  const size_t need = gn_partial_floats(g.N, g.H * g.W, g.C);     // per-row-chunk partial sums (scratch)
-  if (e.dry) {
-    if (need > e.u->gn_partial_floats) e.u->gn_partial_floats = need;
-    return 0;
-  }
-  ISHAP_REQUIRE(need <= e.u->gn_partial_floats, "GroupNorm backward scratch too small");
-  g.partial = e.u->gn_partial;
-  g.mstats = e.u->gn_mstats;
+  g.csums = salloc(e, (size_t)g.N * g.C * 2);     // zeroed with the rest of the stats arena at the start of the forward
+  if (e.dry) return 0;
+  ISHAP_REQUIRE(g.csums != nullptr, "stats arena exhausted");
   return gn_backward_launch(g, e.s);
 }
 
@@ -101,16 +96,20 @@ static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx) {
       g.M = M; g.N = Nn; g.K = K; g.nbatch = heads; g.alpha = al; g.out_mode = mode;
       return igemm_launch(g, e.s);
     };
-    // recompute P (forward: S = alpha q^T k, softmax)            [t][s]
-    for (int n = 0; n < N; ++n)
-      ISHAP_TRY(gemm_heads(qkv + (long long)n * T * 3 * C, 3 * C, 3 * d, qkv + (long long)n * T * 3 * C + d, 3 * C, 3 * d,
-                           u->attn_S + (long long)n * heads * T * T, T, (long long)T * T, T, T, d, alpha, IG_OUT_F32));
-    ISHAP_TRY(softmax_rows(u->attn_S, u->attn_P, sv.lse, BH * T, T, e.s));
+    // P: kept by the forward, or recomputed (S = alpha q^T k, softmax)            [t][s]
+    const half_t* P = sv.P;
+    if (!P) {
+      for (int n = 0; n < N; ++n)
+        ISHAP_TRY(gemm_heads(qkv + (long long)n * T * 3 * C, 3 * C, 3 * d, qkv + (long long)n * T * 3 * C + d, 3 * C, 3 * d,
+                             u->attn_S + (long long)n * heads * T * T, T, (long long)T * T, T, T, d, alpha, IG_OUT_F32));
+      ISHAP_TRY(softmax_rows(u->attn_S, u->attn_P, sv.lse, BH * T, T, e.s));
+      P = u->attn_P;
+    }
     // dP = dA V^T                                                 [t][s] fp32
     for (int n = 0; n < N; ++n)
       ISHAP_TRY(gemm_heads(dA.p + (long long)n * T * C, C, d, qkv + (long long)n * T * 3 * C + 2 * d, 3 * C, 3 * d,
                            u->attn_S + (long long)n * heads * T * T, T, (long long)T * T, T, T, d, 1.f, IG_OUT_F32));
-    ISHAP_TRY(softmax_bwd_rows(u->attn_P, u->attn_S, dS, u->attn_D, BH * T, T, alpha, e.s));
+    ISHAP_TRY(softmax_bwd_rows(P, u->attn_S, dS, u->attn_D, BH * T, T, alpha, e.s));
     // dQ = dS K
     ISHAP_TRY(head_transpose(qkv, KT, N, T, 3 * C, heads, d, dpad, 3 * d, d, e.s));
     for (int n = 0; n < N; ++n)
@@ -176,6 +175,9 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const float* cot_ou
   if (!dry) {
     ISHAP_REQUIRE(u->have_saved, "backward needs a preceding forward with keep_for_backward=1");
     u->arena.off = u->fwd_mark;
+    u->stat_off = u->stat_fwd_mark;
+    if (u->bwd_since_fwd++ > 0 && u->stat_cap > u->stat_fwd_mark)   // a second backward on the same forward: fresh zeros
+      ISHAP_CHECK_HIP(hipMemsetAsync(u->stat_base + u->stat_fwd_mark, 0, (u->stat_cap - u->stat_fwd_mark) * sizeof(long long), s));
   }
   const ishap_unet_config& cfg = u->cfg;
   const int N = dry ? cfg.max_batch : u->last_N;

@@ -43,8 +43,7 @@ struct GnBwdArgs {
   const float* beta = nullptr;
   const float* emb = nullptr;     // film
   int emb_ld = 0;
-  float* partial = nullptr;       // scratch, gn_partial_floats()
-  float* mstats = nullptr;        // scratch [N][32][2]
+  long long* csums = nullptr;     // zeroed scratch [N][C][2]: per-channel (sum dyh, sum dyh*xh) in 64-bit fixed point
   int N = 1, H = 0, W = 0, C = 0;
   int film = 0, act = 1, gmode = GB_SAME;
 };

@@ -95,37 +95,12 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnBwdArgs a, int ro
     }
   }
   __syncthreads();
-  float* out = a.partial + ((long long)n * gridDim.x + blk) * C * 2;
+  // one fixed-point atomic per (channel, term) per block: integer adds commute -> bitwise reproducible sums
   for (int c = tid; c < C * 2; c += 256) {
     float acc = 0.f;
     for (int r = 0; r < rpi; ++r) acc += red[r * C * 2 + c];
-    out[c] = acc;
-  }
-}
-
-// mstats[n][g] = (mean dyh, mean dyh*xh) over the group
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mstats,
-                                                              int nblk, int C, int HW) {
-  __shared__ double sh[2][256];
-  const int g = blockIdx.x, n = blockIdx.y, cpg = C / 32, tid = threadIdx.x;
-  double s = 0.0, q = 0.0;
-  const int total = nblk * cpg;
-  for (int i = tid; i < total; i += 256) {
-    int b = i / cpg, c = g * cpg + i % cpg;
-    const float* p = partial + (((long long)n * nblk + b) * C + c) * 2;
-    s += (double)p[0];
-    q += (double)p[1];
-  }
-  sh[0][tid] = s; sh[1][tid] = q;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    double cnt = (double)HW * cpg;
-    mstats[(n * 32 + g) * 2 + 0] = (float)(sh[0][0] / cnt);
-    mstats[(n * 32 + g) * 2 + 1] = (float)(sh[1][0] / cnt);
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.csums + (long long)n * C * 2 + c),
+              (unsigned long long)__float2ll_rn(acc * STAT_SCALE_SUM));
   }
 }
 
@@ -133,6 +108,23 @@ template <bool FILM, bool ACT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
   const int CV = a.C >> 3, HW = a.H * a.W, cpg = a.C / 32;
   const long long total = (long long)a.N * HW * CV;
+  // group means of dyh and dyh*xh from the per-channel sums (8 lanes per (image, group))
+  __shared__ float sh_m[16 * 32 * 2];
+  {
+    const float cnt = (float)HW * (float)cpg;
+    for (int idx = threadIdx.x; idx < a.N * 32 * 8; idx += 256) {
+      const int part = idx & 7, g = (idx >> 3) & 31, n = idx >> 8;
+      float s1 = 0.f, s2 = 0.f;
+      for (int c = g * cpg + part; c < (g + 1) * cpg; c += 8) {
+        s1 += (float)a.csums[((long long)n * a.C + c) * 2] * (1.f / STAT_SCALE_SUM);
+        s2 += (float)a.csums[((long long)n * a.C + c) * 2 + 1] * (1.f / STAT_SCALE_SUM);
+      }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      if (part == 0) { sh_m[(n * 32 + g) * 2] = s1 / cnt; sh_m[(n * 32 + g) * 2 + 1] = s2 / cnt; }
+    }
+    __syncthreads();
+  }
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int cv = (int)(idx % CV);
@@ -147,7 +139,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
     for (int i = 0; i < 8; ++i) {
       const int g = (c0 + i) / cpg;
       const float rs = a.stats[(n * 32 + g) * 2 + 1];
-      const float m1 = a.mstats[(n * 32 + g) * 2], m2 = a.mstats[(n * 32 + g) * 2 + 1];
+      const float m1 = sh_m[(n * 32 + g) * 2], m2 = sh_m[(n * 32 + g) * 2 + 1];
       float v = rs * (dyh[i] - m1 - xh[i] * m2);
       if (a.add) v += ad[i];
       o[i] = (half_t)v;
@@ -164,11 +156,10 @@ int gn_backward_launch(const GnBwdArgs& a, hipStream_t s) {
   const size_t smem = (size_t)rpi * a.C * 2 * sizeof(float);
   long long total = (long long)a.N * HW * CV;
   int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 1024) blocks = 1024;
 #define GB_LAUNCH(F, A)                                                                                             \
   do {                                                                                                              \
     hipLaunchKernelGGL((gn_bwd_partial_kernel<F, A>), dim3(nblk, a.N), dim3(256), smem, s, a, rpb);                 \
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(32, a.N), dim3(256), 0, s, a.partial, a.mstats, nblk, a.C, HW); \
     hipLaunchKernelGGL((gn_bwd_apply_kernel<F, A>), dim3(blocks), dim3(256), 0, s, a);                              \
   } while (0)
   if (a.film) GB_LAUNCH(true, true);

@@ -55,6 +55,7 @@ struct AttnSaved {
   Tensor x, qkv, a;
   float* stats = nullptr;
   float* lse = nullptr;
+  half_t* P = nullptr;    // softmax probabilities [N*heads][T][T] kept for the backward (null: recompute)
 };
 
 struct ResL {
@@ -135,7 +136,8 @@ struct ishap_unet {
   Tensor x0, h_final;
   float* head_stats = nullptr;
   long long* stat_base = nullptr;   // arena of per-channel GroupNorm sums, zeroed once per forward
-  size_t stat_cap = 0, stat_off = 0, stat_high = 0;
+  size_t stat_cap = 0, stat_off = 0, stat_high = 0, stat_fwd_mark = 0;
+  int bwd_since_fwd = 0;
   size_t fwd_mark = 0;          // arena offset after the forward (backward scratch goes above it)
   float* gn_mstats = nullptr;   // backward GN scratch [max_batch][32][2]
   float* attn_D = nullptr;      // backward attention row sums
@@ -146,6 +148,7 @@ struct Exec {
   ishap_unet* u;
   hipStream_t s;
   bool dry;
+  bool keep = false;   // the forward keeps what a following backward re-reads
 };
 template <typename T>
 static inline T* aalloc(Exec& e, size_t count) { return (T*)e.u->arena.alloc(count * sizeof(T)); }

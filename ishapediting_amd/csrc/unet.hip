@@ -352,6 +352,7 @@ static int attn_forward(Exec& e, AttnL& L, const Tensor& x, Tensor& y) {
   Tensor a = x;
   a.p = aalloc<half_t>(e, x.numel());
   const size_t s_need = (size_t)N * heads * T * T;
+  half_t* Pbuf = e.keep ? aalloc<half_t>(e, s_need) : nullptr;     // kept for the backward, else shared scratch
   const size_t t_need = (size_t)N * heads * dpad * T;
   if (e.dry) {
     if (s_need > u->attn_S_floats) u->attn_S_floats = s_need;
@@ -366,11 +367,12 @@ static int attn_forward(Exec& e, AttnL& L, const Tensor& x, Tensor& y) {
       g.out_mode = IG_OUT_F32;
       ISHAP_TRY(igemm_launch(g, e.s));
     }
-    ISHAP_TRY(softmax_rows(u->attn_S, u->attn_P, lse, (long long)N * heads * T, T, e.s));
+    half_t* P = Pbuf ? Pbuf : u->attn_P;
+    ISHAP_TRY(softmax_rows(u->attn_S, P, lse, (long long)N * heads * T, T, e.s));
     ISHAP_TRY(head_transpose(qkv.p, u->attn_T, N, T, 3 * C, heads, d, dpad, 3 * d, 2 * d, e.s));
     for (int n = 0; n < N; ++n) {      // a = P v   (unet.py:353)
       IgemmArgs g;
-      g.X = u->attn_P + (long long)n * heads * T * T;      g.ldx = T; g.bsx = (long long)T * T;
+      g.X = P + (long long)n * heads * T * T;      g.ldx = T; g.bsx = (long long)T * T;
       g.Wt = u->attn_T + (long long)n * heads * dpad * T;  g.ldw = T; g.bsw = (long long)dpad * T;
       g.out = a.p + (long long)n * T * C; g.ldo = C; g.bso = d;
       g.M = T; g.N = d; g.K = T; g.nbatch = heads;
@@ -383,7 +385,7 @@ static int attn_forward(Exec& e, AttnL& L, const Tensor& x, Tensor& y) {
   y.sums = salloc(e, (size_t)N * C * 2);
   ISHAP_TRY(conv_op(e, a.p, N, x.H, x.W, C, L.proj.w, L.proj.kpad, 1, C, L.proj.bias, x.p, C, y.p, C, IG_OUT_F16, 0, 0,
                     y.sums));
-  L.sv.x = x; L.sv.qkv = qkv; L.sv.a = a; L.sv.stats = st; L.sv.lse = lse;
+  L.sv.x = x; L.sv.qkv = qkv; L.sv.a = a; L.sv.stats = st; L.sv.lse = lse; L.sv.P = Pbuf;
   return 0;
 }
 
@@ -415,6 +417,7 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
   ISHAP_REQUIRE(N >= 1 && N <= cfg.max_batch && N <= 16, "batch size outside [1, max_batch]");
   ISHAP_REQUIRE(feat_layer < (int)u->out_blocks.size(), "feat_layer out of range");
   Exec e{u, s, dry};
+  e.keep = keep != 0;
   u->arena.reset();
   u->stat_off = 0;
   if (!dry && u->stat_cap) ISHAP_CHECK_HIP(hipMemsetAsync(u->stat_base, 0, u->stat_cap * sizeof(long long), s));
@@ -483,6 +486,8 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
   u->last_feat = feat_layer;
   u->have_saved = keep != 0;
   u->fwd_mark = u->arena.off;
+  u->stat_fwd_mark = u->stat_off;
+  u->bwd_since_fwd = 0;
   return 0;
 }
 
