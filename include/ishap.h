@@ -78,7 +78,9 @@ int ishap_unet_copy_tap(const ishap_unet* u, void* dst, void* stream);
 int ishap_unet_backward_input(ishap_unet* u, const void* cot_nhwc, const float* scale2, float* dx, void* stream);
 /* same, from a cotangent of the model output [N][out_channels][S][S] fp32 (full-depth backward,
  * drag_utils.py:458 in train_triplane) */
-int ishap_unet_backward_from_output(ishap_unet* u, const float* cot_out, float* dx, void* stream);
+int ishap_unet_backward_from_output(ishap_unet* u, const void* cot_out, int cot_is_f16, const float* scale2, float* dx,
+                                    void* stream);
+/*   cot_out: fp32, or fp16 already multiplied by scale2[0] (ishap_grad_to_scaled_f16); scale2 as above */
 
 /* ------------------------------------------- diffusion step (gd/gaussian_diffusion.py:232-331, 400-510) */
 typedef struct {
@@ -151,6 +153,19 @@ int ishap_triplane_decode_points(const float* planes, int S, const ishap_decoder
  * volume[res][res][res] with x slowest, no host round trips */
 int ishap_triplane_decode_grid(const float* planes, int S, const ishap_decoder_weights* w, const float* axis, int res,
                                float* volume, void* stream);
+
+/* real-shape guidance (drag_utils.py:447-463): prediction = decoder(0, coord); loss = -BCEWithLogitsLoss()(prediction, gt);
+ * loss.backward() -- forward and backward of the decoder on sampled points.  W1T / W2T: transposed copies of
+ * net.1.weight / net.3.weight.  Outputs: loss[1], dplanes [3][S][S][32] = d loss / d planes, optional logits[npts]. */
+int ishap_triplane_points_loss_grad(const float* planes, int S, const ishap_decoder_weights* w, const float* W1T,
+                                    const float* W2T, const float* coords, const float* gt, long long npts,
+                                    float* dplanes, float* loss, float* logits, void* stream);
+/* chain rule from planes = clamp(sqrt_recip*x - sqrt_recipm1*eps, -1, 1)*range + middle back to the step's inputs
+ * (drag_utils.py:448-450, gd/gaussian_diffusion.py:333-338,299-301): g_direct [96][S][S] = explicit d/dx term,
+ * cot_out [192][S][S] = cotangent of the model output (eps half; variance half zero) for the UNet backward */
+int ishap_x0_grad_to_cotangent(const float* dplanes, const float* range, const float* x, const float* model_out,
+                               float sqrt_recip, float sqrt_recipm1, int clip_denoised, int S, float* g_direct,
+                               float* cot_out, void* stream);
 
 /* ------------------------------------------------------------------ measurement aid (bench.py roofline leg)
  * Brackets every implicit-GEMM launch with HIP events on its own stream between begin and end.

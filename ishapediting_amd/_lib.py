@@ -56,7 +56,11 @@ SYMBOLS = {
     "ishap_unet_tap_ptr": (c_void_p, [c_void_p]),
     "ishap_unet_copy_tap": (C.c_int, [c_void_p, c_void_p, c_void_p]),
     "ishap_unet_backward_input": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ishap_unet_backward_from_output": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ishap_unet_backward_from_output": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p]),
+    "ishap_triplane_points_loss_grad": (C.c_int, [c_void_p, C.c_int, C.POINTER(DecoderWeightsC), c_void_p, c_void_p, c_void_p,
+                                                  c_void_p, C.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ishap_x0_grad_to_cotangent": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_float, C.c_float, C.c_int, C.c_int,
+                                             c_void_p, c_void_p, c_void_p]),
     "ishap_ddpm_step": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(StepCoefs), C.c_int, C.c_int,
                                   C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ishap_guided_update": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_float, c_void_p, C.c_longlong, c_void_p,

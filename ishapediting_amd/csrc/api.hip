@@ -89,6 +89,26 @@ int ishap_triplane_decode_points(const float* planes, int S, const ishap_decoder
   return triplane_decode_launch(d, (hipStream_t)stream);
 }
 
+int ishap_triplane_points_loss_grad(const float* planes, int S, const ishap_decoder_weights* w, const float* W1T,
+                                    const float* W2T, const float* coords, const float* gt, long long npts,
+                                    float* dplanes, float* loss, float* logits, void* stream) {
+  DecodeArgs d;
+  ISHAP_TRY(fill_dec(w, d));
+  ISHAP_REQUIRE(planes && W1T && W2T && coords && gt && dplanes && loss, "null argument");
+  DecBwdArgs b;
+  b.planes = planes; b.S = S; b.B = d.B; b.W1 = d.W1; b.b1 = d.b1; b.W2 = d.W2; b.b2 = d.b2; b.w3 = d.w3; b.b3 = d.b3;
+  b.W1T = W1T; b.W2T = W2T; b.coords = coords; b.gt = gt; b.npts = npts; b.dplanes = dplanes; b.loss = loss; b.logits = logits;
+  return decode_points_bwd_launch(b, (hipStream_t)stream);
+}
+
+int ishap_x0_grad_to_cotangent(const float* dplanes, const float* range, const float* x, const float* model_out,
+                               float sqrt_recip, float sqrt_recipm1, int clip_denoised, int S, float* g_direct,
+                               float* cot_out, void* stream) {
+  ISHAP_REQUIRE(dplanes && x && model_out && g_direct && cot_out && (S * S) % 32 == 0, "null argument");
+  return x0_grad_launch(dplanes, range, x, model_out, sqrt_recip, sqrt_recipm1, clip_denoised, S, g_direct, cot_out,
+                        (hipStream_t)stream);
+}
+
 int ishap_triplane_decode_grid(const float* planes, int S, const ishap_decoder_weights* w, const float* axis, int res,
                                float* volume, void* stream) {
   DecodeArgs d;

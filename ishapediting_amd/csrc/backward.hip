@@ -169,8 +169,8 @@ static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out) {
   return 0;
 }
 
-int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const float* cot_out, const float* scale2, float* dx,
-                       hipStream_t s, bool dry) {
+int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out, int cot_out_f16, const float* scale2,
+                       float* dx, hipStream_t s, bool dry) {
   Exec e{u, s, dry};
   if (!dry) {
     ISHAP_REQUIRE(u->have_saved, "backward needs a preceding forward with keep_for_backward=1");
@@ -190,7 +190,7 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const float* cot_ou
     const int S = cfg.image_size, opad = u->head.cout_pad;
     Tensor dout{nullptr, N, S, S, opad};
     dout.p = aalloc<half_t>(e, dout.numel());
-    if (!dry) ISHAP_TRY(nchw_to_nhwc_f16_scaled(cot_out, 1, dout.p, N, cfg.out_channels, S * S, opad, 1.f, s));
+    if (!dry) ISHAP_TRY(nchw_to_nhwc_f16_scaled(cot_out, cot_out_f16 ? 0 : 1, dout.p, N, cfg.out_channels, S * S, opad, 1.f, s));
     Tensor dact;
     ISHAP_TRY(dgrad_op(e, u->head, dout, dact, u->final_ch));
     g = u->h_final;
@@ -249,10 +249,11 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const float* cot_ou
 extern "C" int ishap_unet_backward_input(ishap_unet* u, const void* cot, const float* scale2, float* dx, void* stream) {
   ISHAP_REQUIRE(u && cot && dx, "null argument");
   ISHAP_CHECK_HIP(hipSetDevice(u->device));
-  return unet_backward_impl(u, (const half_t*)cot, nullptr, scale2, dx, (hipStream_t)stream, false);
+  return unet_backward_impl(u, (const half_t*)cot, nullptr, 0, scale2, dx, (hipStream_t)stream, false);
 }
-extern "C" int ishap_unet_backward_from_output(ishap_unet* u, const float* cot_out, float* dx, void* stream) {
+extern "C" int ishap_unet_backward_from_output(ishap_unet* u, const void* cot_out, int cot_is_f16, const float* scale2,
+                                               float* dx, void* stream) {
   ISHAP_REQUIRE(u && cot_out && dx, "null argument");
   ISHAP_CHECK_HIP(hipSetDevice(u->device));
-  return unet_backward_impl(u, nullptr, cot_out, nullptr, dx, (hipStream_t)stream, false);
+  return unet_backward_impl(u, nullptr, cot_out, cot_is_f16, scale2, dx, (hipStream_t)stream, false);
 }

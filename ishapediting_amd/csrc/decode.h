@@ -19,4 +19,20 @@ struct DecodeArgs {
   float* out = nullptr;            // [npts] logits
 };
 int triplane_decode_launch(const DecodeArgs& a, hipStream_t s);
+
+struct DecBwdArgs {
+  const float* planes = nullptr;   // [3][S][S][32]
+  int S = 0;
+  const float *B = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
+  const float *W1T = nullptr, *W2T = nullptr;   // transposed copies (coalesced forward mat-vecs)
+  const float* coords = nullptr;   // [npts][3]
+  const float* gt = nullptr;       // [npts] occupancy targets
+  long long npts = 0;
+  float* dplanes = nullptr;        // [3][S][S][32] d(-BCE)/d planes (zeroed by the launch)
+  float* loss = nullptr;           // [1] = -BCEWithLogits mean
+  float* logits = nullptr;         // optional [npts]
+};
+int decode_points_bwd_launch(const DecBwdArgs& a, hipStream_t s);
+int x0_grad_launch(const float* dplanes, const float* rng, const float* x, const float* model_out, float sr, float srm1,
+                   int clip, int S, float* g_direct, float* cot_out, hipStream_t s);
 int planes_prepare_launch(const float* latent, const float* rng, const float* mid, float* planes, int S, hipStream_t s);

@@ -162,5 +162,5 @@ int gn_stats_op(Exec& e, const Tensor& x, float* stats);
 int unet_build(ishap_unet* u);
 int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int feat_layer, float* out,
                       void* inter_feat, int keep, hipStream_t s, bool dry);
-int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const float* cot_out, const float* scale2, float* dx,
-                       hipStream_t s, bool dry);
+int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out, int cot_out_f16, const float* scale2,
+                       float* dx, hipStream_t s, bool dry);

@@ -521,7 +521,7 @@ int ishap_unet_create(const ishap_unet_config* cfg, int device, ishap_unet** out
   size_t fwd_high = u->arena.high;
   if (!r) {
     u->arena.off = fwd_high;     // backward allocates on top of the kept forward state
-    r = unet_backward_impl(u, nullptr, (const float*)0x1000, nullptr, nullptr, 0, true);
+    r = unet_backward_impl(u, nullptr, (const void*)0x1000, 0, nullptr, nullptr, 0, true);
   }
   if (r) { delete u; return r; }
   u->arena.dry = false;

@@ -353,8 +353,62 @@ class DragStuff:
                                                                 self.args.points_uniform_ratio)
             if points is None:
                 return
-        raise NotImplementedError("guided reconstruction (full-depth backward + decoder backward) is scheduled after "
-                                  "the drag path; see DESIGN.md scope table row a16")
+        points = th.as_tensor(np.asarray(points), dtype=th.float32).to(self.device)
+        occupancies = th.as_tensor(np.asarray(occupancies), dtype=th.float32).reshape(-1).to(self.device)
+        img = self.reconstruct(points, occupancies)
+        np.save(os.path.join(path, "tri_feat.npy"), img.cpu().numpy())
+        self.clear_params()
+        self.mesh = self.get_mesh(tri_feat=img)
+        self.mesh0 = copy.deepcopy(self.mesh)
+        mesh_backend.write_mesh(os.path.join(path, "mesh_recon.obj"), self.mesh0)
+        self.latent_inversion(tri_feat=img)
+
+    def reconstruct(self, points, occupancies, scale=600, batch_size=40000, img=None, batch_fn=None, steps=None):
+        """The guided-sampling loop of train_triplane (drag_utils.py:442-463): every step decodes `pred_xstart` on a
+        random batch of occupancy samples and pushes the latent along d(-BCE)/d img (full-depth UNet backward).
+        `batch_fn(i) -> (coord, gt)`, `img` and `steps` (step indices to run) replace the random batch / initial noise /
+        full schedule for parity runs."""
+        L = _lib.lib()
+        d = self.diffusion
+        if img is None:
+            img = th.randn((1, 96, self.args.image_size, self.args.image_size), dtype=th.float32, device=self.device)
+        img = img.to(self.device).float().contiguous()
+        rng_t = self.range if th.is_tensor(self.range) else None
+        S = self.args.image_size
+        bits = th.zeros(1, dtype=th.int32, device=self.device)
+        scale2 = th.ones(2, dtype=th.float32, device=self.device)
+        self.last_losses = []
+        for i in (steps if steps is not None else range(self.args.num_steps - 1, -1, -1)):
+            outs = d.p_sample_guidance(self.model, img, i, keep_for_backward=True, noise=self._noise(i, img))
+            if batch_fn is not None:
+                coord, gt = batch_fn(i)
+            else:     # DataLoader(shuffle=True, batch_size=40000); next(iter(...)) -> a fresh random batch each step (:453)
+                idx = th.randperm(points.shape[0], device=self.device)[:batch_size]
+                coord, gt = points[idx], occupancies[idx]
+            from .triplane_decoder import prepare_planes
+            planes = prepare_planes(outs["pred_xstart"], self.range, self.middle)
+            loss, dplanes, _ = self.decoder.points_loss_grad(planes, coord, gt)
+            g_direct = th.empty_like(img)
+            cot = th.empty((1, 192, S, S), dtype=th.float32, device=self.device)
+            sr = float(np.float32(d.sqrt_recip_alphas_cumprod[i]))
+            srm1 = float(np.float32(d.sqrt_recipm1_alphas_cumprod[i]))
+            new = th.empty_like(img)
+            cot16 = th.empty((1, 192, S, S), dtype=th.float16, device=self.device)
+            with th.cuda.device(self.device):
+                s = _lib.stream_ptr(self.device)
+                _lib.check(L.ishap_x0_grad_to_cotangent(dplanes.data_ptr(), _lib.ptr(rng_t.reshape(-1).contiguous()) if rng_t is not None else None,
+                                                        img.data_ptr(), outs["model_output"].data_ptr(), sr, srm1,
+                                                        int(self.args.clip_denoised), S, g_direct.data_ptr(), cot.data_ptr(), s))
+                _lib.check(L.ishap_grad_to_scaled_f16(cot.data_ptr(), cot16.data_ptr(), bits.data_ptr(), scale2.data_ptr(),
+                                                      cot.numel(), s))
+            dx = self.model.backward_from_output(cot16, scale2)
+            grads1 = dx + g_direct                                   # = img.grad of the reference (:459)
+            with th.cuda.device(self.device):
+                _lib.check(L.ishap_guided_update(outs["sample"].data_ptr(), outs["variance"].data_ptr(), grads1.data_ptr(),
+                                                 float(scale), None, img.numel(), new.data_ptr(), _lib.stream_ptr(self.device)))
+            img = new
+            self.last_losses.append(loss)
+        return img
 
     def latent_inversion(self, tri_feat, fwd_noise=None):
         outs = self.diffusion.ddpm_inversion(self.model, tri_feat, self.args.w_time, fwd_noise=fwd_noise,

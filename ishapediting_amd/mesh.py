@@ -53,6 +53,15 @@ def volume_to_mesh(volume: torch.Tensor, res: int, smooth_iterations: int = 10):
     return mesh.filter_smooth_simple(number_of_iterations=smooth_iterations)
 
 
+def write_mesh(path, mesh):
+    """o3d.io.write_triangle_mesh (drag_utils.py:470) when Open3D produced the mesh; the raw volume otherwise."""
+    if isinstance(mesh, OccupancyMesh):
+        np.save(path + ".volume.npy", mesh.volume.detach().cpu().numpy())
+        return
+    import open3d as o3d
+    o3d.io.write_triangle_mesh(path, mesh)
+
+
 def sample_occupancy(mesh, mesh_path, center_mesh, points_size, uniform_ratio):
     """drag_utils.py:411-440 via Open3D (RaycastingScene); returns (None, None) when no mesh is given."""
     if mesh is None and mesh_path is None:

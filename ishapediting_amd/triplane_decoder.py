@@ -100,6 +100,25 @@ class MultiTriplane:
 
     __call__ = forward
 
+    def points_loss_grad(self, planes: torch.Tensor, coords: torch.Tensor, gt: torch.Tensor):
+        """drag_utils.py:455-458 on explicit planes: loss = -BCEWithLogitsLoss()(decoder(coords), gt) and
+        d loss / d planes ([3,S,S,32]); also returns the logits."""
+        coords = coords.detach().to(device=self.device, dtype=torch.float32).reshape(-1, 3).contiguous()
+        gt = gt.detach().to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+        assert coords.shape[0] == gt.shape[0]
+        sd = self.net.sd
+        w1t, w2t = sd["1.weight"].t().contiguous(), sd["3.weight"].t().contiguous()
+        dplanes = torch.empty_like(planes)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        logits = torch.empty(coords.shape[0], dtype=torch.float32, device=self.device)
+        w = self.net.weights_c()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ishap_triplane_points_loss_grad(
+                planes.data_ptr(), planes.shape[1], C.byref(w), w1t.data_ptr(), w2t.data_ptr(), coords.data_ptr(),
+                gt.data_ptr(), coords.shape[0], dplanes.data_ptr(), loss.data_ptr(), logits.data_ptr(),
+                _lib.stream_ptr(self.device)))
+        return loss, dplanes, logits
+
 
 def prepare_planes(latent: torch.Tensor, rng: Optional[torch.Tensor], mid: Optional[torch.Tensor]) -> torch.Tensor:
     """(tri_feat * range + middle).reshape(3,32,S,S) (drag_utils.py:295) as channels-last planes, one kernel."""

@@ -164,10 +164,14 @@ class UNetModel:
                                                          dx.data_ptr(), _lib.stream_ptr(self.device)))
         return dx
 
-    def backward_from_output(self, cot_out: torch.Tensor) -> torch.Tensor:
+    def backward_from_output(self, cot_out: torch.Tensor, scale2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Full-depth input gradient of sum(out * cot).  `cot_out` fp32, or fp16 pre-multiplied by scale2[0]."""
         dx = torch.empty(self._last_shape, dtype=torch.float32, device=self.device)
-        cot_out = cot_out.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        is_f16 = cot_out.dtype == torch.float16
+        cot_out = cot_out.detach().to(device=self.device).contiguous()
+        if not is_f16:
+            cot_out = cot_out.float()
         with torch.cuda.device(self.device):
-            _lib.check(self._L.ishap_unet_backward_from_output(self._h, cot_out.data_ptr(), dx.data_ptr(),
-                                                               _lib.stream_ptr(self.device)))
+            _lib.check(self._L.ishap_unet_backward_from_output(self._h, cot_out.data_ptr(), int(is_f16), _lib.ptr(scale2),
+                                                               dx.data_ptr(), _lib.stream_ptr(self.device)))
         return dx

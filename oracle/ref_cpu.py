@@ -426,3 +426,21 @@ def drag_loop(diff: DiffusionOracle, unet: UNetOracle, w, cache, setup: DragSetu
         losses.append(float(loss.detach()))
         img = (o["sample"] + o["variance"] * (scale * g)).detach()
     return img, losses
+
+
+def reconstruct_loop(diff: DiffusionOracle, unet: UNetOracle, net, img, rng, mid, coords, gts, noises, scale=600.0):
+    """drag_utils.py:445-463 (train_triplane's guided loop) for given point batches: per step decode pred_xstart on the
+    batch, loss = -BCEWithLogits, img <- sample + variance * scale * d loss / d img."""
+    T = diff.tb.num_timesteps
+    imgs, losses, grads = [], [], []
+    for k, i in enumerate(range(T - 1, -1, -1)):
+        img = img.detach().requires_grad_(True)
+        o = diff.p_sample_guidance(unet, img, i, noise=noises[k])
+        S = img.shape[-1]
+        planes = (o["pred_xstart"] * rng + mid).reshape(3, 32, S, S)
+        pred = decoder_forward(net, planes, coords[k])
+        loss = -F.binary_cross_entropy_with_logits(pred, gts[k].reshape(-1))
+        g, = torch.autograd.grad(loss, img)
+        img = (o["sample"] + o["variance"] * (scale * g)).detach()
+        imgs.append(img); losses.append(loss.detach()); grads.append(g)
+    return imgs, losses, grads

@@ -168,3 +168,29 @@ def test_drag_loss_gradient_vs_golden(gold, loss_type, cof):
     touched = dk.touched.cpu().reshape(3, 16, 16).bool()
     for p in range(3):
         assert torch.equal(~touched[p], setup.masks[p])
+
+
+def test_decoder_points_loss_grad_vs_oracle_autograd():
+    """decode_bwd.hip (loss = -BCEWithLogits(decoder(coords), gt), d loss / d planes) vs torch autograd on the oracle
+    decoder.  Tolerance 1e-3 relative L2 (fp32 both sides; atomics reorder the scatter)."""
+    from oracle import ref_cpu as O
+    from ishapediting_amd.triplane_decoder import MultiTriplane
+    net = synthetic.decoder_state_dict()
+    gen = torch.Generator().manual_seed(9)
+    planes = (torch.randn(3, 32, 16, 16, generator=gen) * 0.5).requires_grad_(True)
+    coords = torch.rand(1024, 3, generator=gen) * 2.2 - 1.1
+    gt = (torch.rand(1024, generator=gen) > 0.5).float()
+    pred = O.decoder_forward(net, planes, coords)
+    loss = -torch.nn.functional.binary_cross_entropy_with_logits(pred, gt)
+    gp, = torch.autograd.grad(loss, planes)
+    dec = MultiTriplane(1, device=dev())
+    dec.net.load_state_dict(net)
+    hwc = planes.detach().permute(0, 2, 3, 1).contiguous().to(dev())
+    l, dplanes, logits = dec.points_loss_grad(hwc, coords.to(dev()), gt.to(dev()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(logits.cpu().numpy(), pred.detach().numpy(), rtol=1e-4, atol=1e-4)
+    assert abs(float(l) - float(loss)) < 1e-5
+    got = dplanes.cpu().permute(0, 3, 1, 2)
+    r = float((got - gp).norm() / gp.norm())
+    print(f"decoder backward rel err {r:.3e}")
+    assert r < 1e-3

@@ -357,6 +357,52 @@ def g8_g9_tiny_loops():
     save("g8_g9_tiny_loops", **out)
 
 
+def small96_config():
+    return UNetConfig(image_size=16, in_channels=96, model_channels=32, out_channels=192, num_res_blocks=1,
+                      attention_resolutions="8", channel_mult=(1, 2), num_head_channels=32)
+
+
+def g11_reconstruct():
+    """Two steps of train_triplane's guided loop (drag_utils.py:445-463), restated line by line over the
+    reference's own model / diffusion / MultiTriplane objects (the method itself needs Open3D for its sampling)."""
+    import torch as th
+    cfg = small96_config()
+    T = 4
+    model, diff = load_ref_unet(cfg, 202, str(T))
+    dec = MultiTriplane(1, input_dim=3, output_dim=1, device="cpu")
+    dec.net.load_state_dict(synthetic.decoder_state_dict())
+    dec.eval()
+    for p in dec.net.parameters():
+        p.requires_grad = False
+    g = th.Generator().manual_seed(71)
+    # small normalisation range: keeps the random decoder's Fourier phases O(1) rad, so the fixture measures the
+    # arithmetic and not the amplification of fp16 noise through sin/cos of 30-rad phases
+    rng = (th.rand(1, 96, 1, 1, generator=g) + 0.5) * 0.04
+    mid = th.randn(1, 96, 1, 1, generator=g) * 0.01
+    img = th.randn(1, 96, 16, 16, generator=g)
+    coords = th.rand(T, 2048, 3, generator=g) * 2 - 1
+    gts = (th.rand(T, 2048, 1, generator=g) > 0.5).float()
+    noises = th.randn(T, 1, 96, 16, 16, generator=g)
+    out = {"img0": img, "range": rng, "middle": mid, "coords": coords, "gt": gts, "noise": noises, "T": T}
+    scale = 600
+    imgs, losses, grads = [], [], []
+    for k, i in enumerate(range(T - 1, -1, -1)):
+        img = img.detach().requires_grad_(True)
+        outs = diff.p_sample_guidance(model, img, th.tensor([i]), noise=noises[k])
+        predict_x0 = (outs["pred_xstart"] * rng + mid).reshape(3, 32, 16, 16)
+        for j in range(3):
+            dec.embeddings[j] = predict_x0[[j]]
+        prediction = dec(0, coords[k].unsqueeze(0)).squeeze(0)
+        loss = -th.nn.BCEWithLogitsLoss()(prediction, gts[k])
+        loss.backward()
+        grads1 = img.grad.clone().detach()
+        with th.no_grad():
+            img = (outs["sample"] + outs["variance"] * (scale * grads1)).clone().detach()
+        imgs.append(img); losses.append(loss.detach()); grads.append(grads1)
+    out["imgs"] = th.stack(imgs); out["losses"] = th.stack(losses); out["grads"] = th.stack(grads)
+    save("g11_reconstruct", **out)
+
+
 def g10_full_keys():
     """Key table + parameter count of the full-size model (structure only, no tensors stored)."""
     cfg = full_config()
@@ -374,7 +420,9 @@ def g10_full_keys():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] if len(sys.argv) > 1 else None
-    todo = [g1_schedules, g2_steps, g3_primitives, g4_tiny_unet, g6_decoder, g7_drag, g8_g9_tiny_loops, g10_full_keys]
+    todo = [g1_schedules, g2_steps, g3_primitives, g4_tiny_unet, g6_decoder, g7_drag, g8_g9_tiny_loops, g10_full_keys, g11_reconstruct]
+    if which:
+        todo = [f for f in todo if f.__name__ in which]
     with torch.no_grad():
         pass
     for fn in todo:
