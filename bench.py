@@ -175,12 +175,8 @@ def main():
         cpu = cpu_baseline(1234)
 
     if rank == 0:
-        mesh_cells = None
-        try:
-            from ishapediting_amd.mesh import OccupancyMesh
-            mesh_cells = OccupancyMesh(vol, RES).surface_cells()
-        except Exception:
-            pass
+        from ishapediting_amd.mesh import mc_vertices
+        mesh_cells = int(mc_vertices(vol).shape[0])     # marching-cubes vertex count of the last decoded volume
         line = {
             "metric": "end-to-end drag-edit wall-clock (s) per shape", "value": round(sec_per_shape, 4), "unit": "s/shape",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
@@ -193,7 +189,7 @@ def main():
             "algorithmic_tflops_per_gpu": round((GUIDED_STEPS * GUIDED_GFLOP + 1185.0) / 1e3 / (dt / a.steps), 1),
             "unet_steps_per_s": round(NUM_STEPS / t_setup, 2),
             "setup_s": round(t_setup, 3),
-            "surface_cells": mesh_cells,
+            "mc_vertices": mesh_cells,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if cpu:

@@ -194,3 +194,34 @@ def test_decoder_points_loss_grad_vs_oracle_autograd():
     r = float((got - gp).norm() / gp.norm())
     print(f"decoder backward rel err {r:.3e}")
     assert r < 1e-3
+
+
+def test_noise2shape_batch_equals_single_samples():
+    """generate.py's driver (image_sample.py:138-201) at batch 3 vs the same three samples one by one: the batched
+    kernels (M = N*HW rows, per-image GroupNorm / attention) must not mix images."""
+    from argparse import Namespace
+    from ishapediting_amd import image_sample
+    from ishapediting_amd.unet_spec import UNetConfig
+    cfg = UNetConfig(image_size=16, in_channels=96, model_channels=32, out_channels=192, num_res_blocks=1,
+                     attention_resolutions="8", channel_mult=(1, 2), num_head_channels=32)
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 202))
+    Tn, B = 4, 3
+
+    def args(bs):
+        return Namespace(clip_denoised=True, num_samples=bs, batch_size=bs, use_ddim=False, model_path=None, stats_dir=None,
+                         explicit_normalization=True, image_size=16, num_channels=32, num_res_blocks=1, num_heads=4,
+                         num_heads_upsample=-1, num_head_channels=32, attention_resolutions="8", channel_mult="1,2",
+                         dropout=0.1, class_cond=False, use_checkpoint=False, use_scale_shift_norm=True,
+                         resblock_updown=True, use_fp16=True, use_new_attention_order=False, in_out_channels=96,
+                         learn_sigma=True, diffusion_steps=1000, noise_schedule="linear", timestep_respacing=str(Tn),
+                         use_kl=False, predict_xstart=False, rescale_timesteps=False, rescale_learned_sigmas=False)
+    gen = torch.Generator().manual_seed(5)
+    x0 = torch.randn(B, 96, 16, 16, generator=gen).to(dev())
+    step = torch.randn(Tn, B, 96, 16, 16, generator=gen).to(dev())
+    lo, hi = -np.linspace(0.5, 1.5, 96).astype(np.float32), np.linspace(1.0, 2.0, 96).astype(np.float32)
+    full = image_sample.noise2shape(args(B), state_dict=sd, bounds=(lo, hi), noise=x0, step_noise=lambda i: step[i])
+    assert full.shape == (B, 16, 16, 96)
+    for b in range(B):
+        one = image_sample.noise2shape(args(1), state_dict=sd, bounds=(lo, hi), noise=x0[b:b + 1],
+                                       step_noise=lambda i: step[i, b:b + 1])
+        np.testing.assert_allclose(full[b], one[0], rtol=1e-3, atol=1e-3)

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Full-size parity report: a shortened drag edit (T DDPM steps, the last W of them recorded as guidance, then W
+guided iterations, then the occupancy decode) on the device vs the fp32 CPU oracle with identical seeds, weights,
+handles and injected noise.  Writes latent / logit errors, sign flips, marching-cubes vertex counts and the Chamfer
+distance of meshProcess.py:18-35 to a JSON file (profiles/).  Test infrastructure (imports the oracle)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--T", type=int, default=12)
+    ap.add_argument("--W", type=int, default=4)
+    ap.add_argument("--res", type=int, default=96)
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "round1_parity.json"))
+    a = ap.parse_args()
+    from ishapediting_amd import synthetic
+    from ishapediting_amd.drag_utils import DragStuff, get_args
+    from ishapediting_amd.mesh import chamfer_distance, mc_vertices
+    from ishapediting_amd.unet_spec import build_spec, full_config
+    from oracle import ref_cpu as O
+    dev = torch.device("cuda", 0)
+    args = get_args(["--w_time", str(a.W), "--num_steps", str(a.T), "--shape_resolution", str(a.res)])
+    cfg = full_config()
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 1234))
+    dec_sd = synthetic.decoder_state_dict(4321)
+    lo, hi = -0.05 * np.ones(96, np.float32), 0.05 * np.ones(96, np.float32)    # realistic small feature range
+    src, tgt = synthetic.handles(3)
+    gen = torch.Generator().manual_seed(99)
+    lat = torch.from_numpy(synthetic.latent(0))
+    n1 = [torch.randn(1, 96, 128, 128, generator=gen) for _ in range(a.T)]
+    n2 = [torch.randn(1, 96, 128, 128, generator=gen) for _ in range(a.W)]
+    scale, cof = 1200.0, 0.4
+    # ---------------- device ----------------
+    ds = DragStuff(dev, args=args)
+    ds.load_weights(sd, dec_sd, lo, hi)
+    ds.step_noise = lambda i: n1[a.T - 1 - i]
+    t0 = time.time()
+    ds.update_latent_params(img=lat)
+    ds.step_noise = lambda i: n2[a.W - 1 - i]
+    for _ in ds.training(src, tgt, scale=scale, cof=cof):
+        pass
+    torch.cuda.synchronize()
+    t_gpu = time.time() - t0
+    vol_gpu = ds.volume.cpu()
+    lat_gpu = ds.tri_feat.cpu()
+    # ---------------- oracle (fp32, CPU) ----------------
+    torch.set_num_threads(min(16, os.cpu_count()))
+    net = O.UNetOracle(build_spec(cfg), sd, fp16=False)
+    diff = O.DiffusionOracle(O.Tables(str(a.T)))
+    t0 = time.time()
+    img, w, cache = O.sample_with_guidance_cache(diff, net, lat, a.T, a.W, 8, {a.T - 1 - k: n1[k] for k in range(a.T)})
+    setup = O.DragSetup(src, tgt, 12, 2.0 / a.res, cache[0].shape[-1])
+    final, losses = O.drag_loop(diff, net, w, cache, setup, a.W, 8, scale, cof, {a.W - 1 - k: n2[k] for k in range(a.W)})
+    rng = torch.from_numpy((hi - lo) / 2).reshape(1, 96, 1, 1)
+    mid = torch.from_numpy((hi + lo) / 2).reshape(1, 96, 1, 1)
+    vol_cpu = O.decode_volume(dec_sd, final, rng, mid, a.res)
+    t_cpu = time.time() - t0
+    # ---------------- report ----------------
+    rel = lambda x, y: float((x - y).norm() / y.norm())
+    va, vb = mc_vertices(vol_gpu) / a.res * 2 - 1, mc_vertices(vol_cpu) / a.res * 2 - 1     # visualize.py:101 convention
+    rep = {
+        "config": {"T": a.T, "guided_steps": a.W, "decode_res": a.res, "handles": 3, "scale": scale, "cof": cof,
+                   "weights": "synthetic seed 1234 (421M params)", "feature_range": "+-0.05"},
+        "latent_rel_l2": rel(lat_gpu, final),
+        "w_rel_l2": rel(ds.w0.cpu(), w),
+        "logit_max_abs_err": float((vol_gpu - vol_cpu).abs().max()),
+        "logit_rms_err": float((vol_gpu - vol_cpu).pow(2).mean().sqrt()),
+        "logit_rms": float(vol_cpu.pow(2).mean().sqrt()),
+        "sign_flips": int(((vol_gpu > 0) != (vol_cpu > 0)).sum()), "voxels": int(vol_cpu.numel()),
+        "mc_vertices_device": int(va.shape[0]), "mc_vertices_oracle": int(vb.shape[0]),
+        "chamfer_all_vertices": chamfer_distance(va.to(dev), vb.to(dev), None) if min(va.shape[0], vb.shape[0]) > 0 else None,
+        "chamfer_20k_samples": chamfer_distance(va, vb, 20000) if min(va.shape[0], vb.shape[0]) > 0 else None,
+        "chamfer_20k_sampling_floor": chamfer_distance(vb, vb.clone(), 20000, seed=1),
+        "oracle_drag_losses": losses, "device_drag_losses": [float(l) for l in ds.last_losses],
+        "seconds_device": round(t_gpu, 2), "seconds_oracle_cpu": round(t_cpu, 1),
+    }
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    with open(a.out, "w") as f:
+        json.dump(rep, f, indent=1)
+    print(json.dumps(rep))
+
+
+if __name__ == "__main__":
+    main()
