@@ -1,0 +1,302 @@
+// Fused attention for the UNet's AttentionBlocks (reference: guided_diffusion/unet.py:337-354, QKVAttentionLegacy:
+// per head  w = softmax_fp32((q*s)^T (k*s)), s = d^-1/4;  a = w v;  tokens T <= 1024, head width d = 64).
+// Forward and backward are flash-style: the T x T score matrix never leaves the CU.
+//   forward : one workgroup = 64 queries of one (image, head); online softmax over 64-key tiles; writes a and
+//             lse = m + log(sum) per query.
+//   backward: dQ kernel (same tiling) and dK/dV kernel (one workgroup = 64 keys, loops over query tiles); P is
+//             recomputed from q, k and the saved lse; D_q = sum_d dA*A is produced by the dQ kernel for the dK/dV one.
+// All products run on v_mfma_f32_16x16x32_f16.  Operand convention used throughout: for a row-major matrix R[idx][k]
+// (k contiguous) lane l loads R[i0 + (l&15)][k0 + 8*(l>>4) .. +7] -- this is the A fragment when idx is the output row
+// and the B fragment when idx is the output column.  The accumulator holds C[row=(l>>4)*4+r][col=l&15].
+// Probabilities / dS go through a per-wave LDS tile to turn that accumulator layout back into an operand; operands
+// that are contracted over their row index (V, K, Q^T, dA^T) are staged into LDS transposed.
+// qkv layout (legacy order): token row of 3C halfs, head h at [h*3d, (h+1)*3d): q | k | v.
+#include "attention.h"
+
+#define TS 72   // row stride (halfs) of 64-wide LDS tiles: 144 B rows -> conflict-free 16-byte fragment reads
+
+template <int D>
+struct Tiles {
+  static constexpr int RS = D + 8;          // row stride of [64][D] row-major tiles
+};
+
+__device__ __forceinline__ half8 ld_frag(const half_t* tile, int stride, int i0, int k0, int lane) {
+  return *reinterpret_cast<const half8*>(tile + (i0 + (lane & 15)) * stride + k0 + 8 * (lane >> 4));
+}
+
+// copy 64 rows x D halfs (row-major, global row stride ld) into LDS, row-major and/or transposed
+template <int D, bool ROWS, bool TRANS>
+__device__ __forceinline__ void stage_tile(const half_t* __restrict__ src, int ld, half_t* rows, half_t* trans, int tid) {
+  constexpr int CPR = D / 8;
+#pragma unroll
+  for (int c = tid; c < 64 * CPR; c += 256) {
+    const int r = c / CPR, ch = c % CPR;
+    const half8 v = *reinterpret_cast<const half8*>(src + (long long)r * ld + ch * 8);
+    if (ROWS) *reinterpret_cast<half8*>(rows + r * (D + 8) + ch * 8) = v;
+    if (TRANS) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) trans[(ch * 8 + e) * TS + r] = v[e];
+    }
+  }
+}
+
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
+  __shared__ __attribute__((aligned(16))) half_t sK[64 * RS];
+  __shared__ __attribute__((aligned(16))) half_t sVt[D * TS];
+  __shared__ __attribute__((aligned(16))) half_t sP[4][16 * TS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+  const int ld = 3 * a.C;
+  const half_t* base = a.qkv + (long long)n * a.T * ld + h * 3 * D;
+  half8 qf[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk)
+    qf[kk] = *reinterpret_cast<const half8*>(base + (long long)(q0 + wave * 16 + (lane & 15)) * ld + kk * 32 + 8 * (lane >> 4));
+  float m[4], lsum[4];
+  f32x4 o[DS];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m[r] = -1e30f; lsum[r] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < DS; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < a.T; kt += 64) {
+    __syncthreads();
+    stage_tile<D, true, false>(base + (long long)kt * ld + D, ld, sK, nullptr, tid);
+    stage_tile<D, false, true>(base + (long long)kt * ld + 2 * D, ld, nullptr, sVt, tid);
+    __syncthreads();
+    f32x4 s[4];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      s[sub] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+        s[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[kk], ld_frag(sK, RS, sub * 16, kk * 32, lane), s[sub], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) { s[sub][r] *= a.alpha; mx = fmaxf(mx, s[sub][r]); }
+      mx = group16_max(mx);
+      const float mn = fmaxf(m[r], mx);
+      const float corr = __expf(m[r] - mn);
+      float rs = 0.f;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        const float p = __expf(s[sub][r] - mn);
+        rs += p;
+        sP[wave][((lane >> 4) * 4 + r) * TS + sub * 16 + (lane & 15)] = (half_t)p;
+      }
+      rs = group16_sum(rs);
+      lsum[r] = lsum[r] * corr + rs;
+      m[r] = mn;
+#pragma unroll
+      for (int i = 0; i < DS; ++i) o[i][r] *= corr;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DS; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        o[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sP[wave], TS, 0, kk * 32, lane),
+                                                      ld_frag(sVt, TS, i * 16, kk * 32, lane), o[i], 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = q0 + wave * 16 + (lane >> 4) * 4 + r;
+    const float inv = 1.f / lsum[r];
+#pragma unroll
+    for (int i = 0; i < DS; ++i)
+      a.out[((long long)n * a.T + q) * a.C + h * D + i * 16 + (lane & 15)] = (half_t)(o[i][r] * inv);
+    if ((lane & 15) == 0) a.lse[((long long)n * a.heads + h) * a.T + q] = m[r] + __logf(lsum[r]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dQ[q][:] = sum_key dS[q][key] K[key][:],  dS = alpha * P * (dP - D_q),  dP = dA V^T.   Also writes D_q.
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+  constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
+  __shared__ __attribute__((aligned(16))) half_t sK[64 * RS];
+  __shared__ __attribute__((aligned(16))) half_t sKt[D * TS];
+  __shared__ __attribute__((aligned(16))) half_t sV[64 * RS];
+  __shared__ __attribute__((aligned(16))) half_t sS[4][16 * TS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+  const int ld = 3 * a.C;
+  const half_t* base = a.qkv + (long long)n * a.T * ld + h * 3 * D;
+  const long long bh = (long long)n * a.heads + h;
+  half8 qf[KK], daf[KK];
+  float dpart = 0.f;
+  {
+    const long long row = (long long)n * a.T + q0 + wave * 16 + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      qf[kk] = *reinterpret_cast<const half8*>(base + (long long)(q0 + wave * 16 + (lane & 15)) * ld + kk * 32 + 8 * (lane >> 4));
+      daf[kk] = *reinterpret_cast<const half8*>(a.dout + row * a.C + h * D + kk * 32 + 8 * (lane >> 4));
+      const half8 av = *reinterpret_cast<const half8*>(a.out + row * a.C + h * D + kk * 32 + 8 * (lane >> 4));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dpart += (float)daf[kk][j] * (float)av[j];
+    }
+  }
+  dpart += __shfl_xor(dpart, 16);
+  dpart += __shfl_xor(dpart, 32);            // D of row (lane & 15), in every lane of that column group
+  float Dr[4], lser[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    Dr[r] = __shfl(dpart, (lane >> 4) * 4 + r);
+    lser[r] = a.lse[bh * a.T + q0 + wave * 16 + (lane >> 4) * 4 + r];
+  }
+  if (lane < 16) a.Dbuf[bh * a.T + q0 + wave * 16 + lane] = dpart;
+  f32x4 dq[DS];
+#pragma unroll
+  for (int i = 0; i < DS; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < a.T; kt += 64) {
+    __syncthreads();
+    stage_tile<D, true, true>(base + (long long)kt * ld + D, ld, sK, sKt, tid);
+    stage_tile<D, true, false>(base + (long long)kt * ld + 2 * D, ld, sV, nullptr, tid);
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[kk], ld_frag(sK, RS, sub * 16, kk * 32, lane), s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(daf[kk], ld_frag(sV, RS, sub * 16, kk * 32, lane), dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[r] * a.alpha - lser[r]);
+        sS[wave][((lane >> 4) * 4 + r) * TS + sub * 16 + (lane & 15)] = (half_t)(a.alpha * p * (dp[r] - Dr[r]));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DS; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        dq[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sS[wave], TS, 0, kk * 32, lane),
+                                                       ld_frag(sKt, TS, i * 16, kk * 32, lane), dq[i], 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = q0 + wave * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+    for (int i = 0; i < DS; ++i)
+      a.dqkv[((long long)n * a.T + q) * ld + h * 3 * D + i * 16 + (lane & 15)] = (half_t)dq[i][r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// One workgroup = 64 keys: dV[key][:] = sum_q P[q][key] dA[q][:],  dK[key][:] = sum_q dS[q][key] Q[q][:].
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+  constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
+  __shared__ __attribute__((aligned(16))) half_t sQ[64 * RS];
+  __shared__ __attribute__((aligned(16))) half_t sQt[D * TS];
+  __shared__ __attribute__((aligned(16))) half_t sA[64 * RS];
+  __shared__ __attribute__((aligned(16))) half_t sAt[D * TS];
+  __shared__ __attribute__((aligned(16))) half_t sPT[4][16 * TS];
+  __shared__ __attribute__((aligned(16))) half_t sST[4][16 * TS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+  const int ld = 3 * a.C;
+  const half_t* base = a.qkv + (long long)n * a.T * ld + h * 3 * D;
+  const long long bh = (long long)n * a.heads + h;
+  half8 kf[KK], vf[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const half_t* row = base + (long long)(k0 + wave * 16 + (lane & 15)) * ld + kk * 32 + 8 * (lane >> 4);
+    kf[kk] = *reinterpret_cast<const half8*>(row + D);
+    vf[kk] = *reinterpret_cast<const half8*>(row + 2 * D);
+  }
+  f32x4 dk[DS], dv[DS];
+#pragma unroll
+  for (int i = 0; i < DS; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int qt = 0; qt < a.T; qt += 64) {
+    __syncthreads();
+    stage_tile<D, true, true>(base + (long long)qt * ld, ld, sQ, sQt, tid);
+    stage_tile<D, true, true>(a.dout + ((long long)n * a.T + qt) * a.C + h * D, a.C, sA, sAt, tid);
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kk], ld_frag(sQ, RS, sub * 16, kk * 32, lane), st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[kk], ld_frag(sA, RS, sub * 16, kk * 32, lane), dp, 0, 0, 0);
+      }
+      const int q = qt + sub * 16 + (lane & 15);           // this lane's column
+      const float lse = a.lse[bh * a.T + q], Dq = a.Dbuf[bh * a.T + q];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(st[r] * a.alpha - lse);
+        const int o = ((lane >> 4) * 4 + r) * TS + sub * 16 + (lane & 15);
+        sPT[wave][o] = (half_t)p;
+        sST[wave][o] = (half_t)(a.alpha * p * (dp[r] - Dq));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DS; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sPT[wave], TS, 0, kk * 32, lane),
+                                                       ld_frag(sAt, TS, i * 16, kk * 32, lane), dv[i], 0, 0, 0);
+        dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sST[wave], TS, 0, kk * 32, lane),
+                                                       ld_frag(sQt, TS, i * 16, kk * 32, lane), dk[i], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int key = k0 + wave * 16 + (lane >> 4) * 4 + r;
+    half_t* row = a.dqkv + ((long long)n * a.T + key) * ld + h * 3 * D;
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+      row[D + i * 16 + (lane & 15)] = (half_t)dk[i][r];
+      row[2 * D + i * 16 + (lane & 15)] = (half_t)dv[i][r];
+    }
+  }
+}
+
+static int check_attn(const AttnArgs& a) {
+  ISHAP_REQUIRE(a.T % 64 == 0 && a.T >= 64, "attention: tokens must be a multiple of 64");
+  ISHAP_REQUIRE(a.C == a.heads * a.d && (a.d == 64 || a.d == 32), "attention: head width 64 or 32");
+  return 0;
+}
+
+int attn_forward_launch(const AttnArgs& a, hipStream_t s) {
+  ISHAP_TRY(check_attn(a));
+  dim3 g(a.T / 64, a.heads, a.N);
+  if (a.d == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, g, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<32>, g, dim3(256), 0, s, a);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int attn_backward_launch(const AttnArgs& a, hipStream_t s) {
+  ISHAP_TRY(check_attn(a));
+  dim3 g(a.T / 64, a.heads, a.N);
+  if (a.d == 64) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, g, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, g, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, g, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, g, dim3(256), 0, s, a);
+  }
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -9,6 +9,7 @@
 // tap-flipped, transposed weight operand packed at load time (ConvW::wT).
 #include "unet.h"
 
+#include "attention.h"
 #include "misc.h"
 #include "norm.h"
 
@@ -71,7 +72,6 @@ static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx) {
   const AttnSaved& sv = L.sv;
   const Tensor& x = sv.x;
   const int N = x.N, T = x.H * x.W, C = L.C, heads = L.heads, d = C / heads;
-  const int dpad = d < 64 ? 64 : d;
   const float alpha = 1.f / sqrtf((float)d);
   Tensor dA;
   ISHAP_TRY(dgrad_op(e, L.proj, dy, dA, C));
@@ -81,62 +81,10 @@ static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx) {
   if (e.dry) {
     if (d_need > u->attn_D_floats) u->attn_D_floats = d_need;
   } else {
-    const long long BH = (long long)N * heads;
-    const size_t slot = u->attn_T_halfs;
-    half_t* KT = u->attn_T;
-    half_t* dAT = u->attn_T + slot;
-    half_t* QT = u->attn_T + 2 * slot;
-    half_t* dS = u->attn_dS;
-    half_t* dST = u->attn_dS + u->attn_S_floats;
-    const half_t* qkv = sv.qkv.p;
-    auto gemm_heads = [&](const half_t* X, int ldx, long long bsx, const half_t* Wt, int ldw, long long bsw, void* out,
-                          int ldo, long long bso, int M, int Nn, int K, float al, int mode) -> int {
-      IgemmArgs g;
-      g.X = X; g.ldx = ldx; g.bsx = bsx; g.Wt = Wt; g.ldw = ldw; g.bsw = bsw; g.out = out; g.ldo = ldo; g.bso = bso;
-      g.M = M; g.N = Nn; g.K = K; g.nbatch = heads; g.alpha = al; g.out_mode = mode;
-      return igemm_launch(g, e.s);
-    };
-    // P: kept by the forward, or recomputed (S = alpha q^T k, softmax)            [t][s]
-    const half_t* P = sv.P;
-    if (!P) {
-      for (int n = 0; n < N; ++n)
-        ISHAP_TRY(gemm_heads(qkv + (long long)n * T * 3 * C, 3 * C, 3 * d, qkv + (long long)n * T * 3 * C + d, 3 * C, 3 * d,
-                             u->attn_S + (long long)n * heads * T * T, T, (long long)T * T, T, T, d, alpha, IG_OUT_F32));
-      ISHAP_TRY(softmax_rows(u->attn_S, u->attn_P, sv.lse, BH * T, T, e.s));
-      P = u->attn_P;
-    }
-    // dP = dA V^T                                                 [t][s] fp32
-    for (int n = 0; n < N; ++n)
-      ISHAP_TRY(gemm_heads(dA.p + (long long)n * T * C, C, d, qkv + (long long)n * T * 3 * C + 2 * d, 3 * C, 3 * d,
-                           u->attn_S + (long long)n * heads * T * T, T, (long long)T * T, T, T, d, 1.f, IG_OUT_F32));
-    ISHAP_TRY(softmax_bwd_rows(P, u->attn_S, dS, u->attn_D, BH * T, T, alpha, e.s));
-    // dQ = dS K
-    ISHAP_TRY(head_transpose(qkv, KT, N, T, 3 * C, heads, d, dpad, 3 * d, d, e.s));
-    for (int n = 0; n < N; ++n)
-      ISHAP_TRY(gemm_heads(dS + (long long)n * heads * T * T, T, (long long)T * T, KT + (long long)n * heads * dpad * T, T,
-                           (long long)dpad * T, dqkv.p + (long long)n * T * 3 * C, 3 * C, 3 * d, T, d, T, 1.f, IG_OUT_F16));
-    // P^T = exp(alpha k^T q - lse_t)                              [s][t]
-    for (int n = 0; n < N; ++n)
-      ISHAP_TRY(gemm_heads(qkv + (long long)n * T * 3 * C + d, 3 * C, 3 * d, qkv + (long long)n * T * 3 * C, 3 * C, 3 * d,
-                           u->attn_S + (long long)n * heads * T * T, T, (long long)T * T, T, T, d, alpha, IG_OUT_F32));
-    ISHAP_TRY(exp_sub_lse_cols(u->attn_S, sv.lse, u->attn_P, BH, T, e.s));
-    // dV = P^T dA
-    ISHAP_TRY(head_transpose(dA.p, dAT, N, T, C, heads, d, dpad, d, 0, e.s));
-    for (int n = 0; n < N; ++n)
-      ISHAP_TRY(gemm_heads(u->attn_P + (long long)n * heads * T * T, T, (long long)T * T,
-                           dAT + (long long)n * heads * dpad * T, T, (long long)dpad * T,
-                           dqkv.p + (long long)n * T * 3 * C + 2 * d, 3 * C, 3 * d, T, d, T, 1.f, IG_OUT_F16));
-    // dP^T = V dA^T                                               [s][t] fp32
-    for (int n = 0; n < N; ++n)
-      ISHAP_TRY(gemm_heads(qkv + (long long)n * T * 3 * C + 2 * d, 3 * C, 3 * d, dA.p + (long long)n * T * C, C, d,
-                           u->attn_S + (long long)n * heads * T * T, T, (long long)T * T, T, T, d, 1.f, IG_OUT_F32));
-    ISHAP_TRY(softmax_bwd_cols(u->attn_P, u->attn_S, u->attn_D, dST, BH, T, alpha, e.s));
-    // dK = dS^T Q
-    ISHAP_TRY(head_transpose(qkv, QT, N, T, 3 * C, heads, d, dpad, 3 * d, 0, e.s));
-    for (int n = 0; n < N; ++n)
-      ISHAP_TRY(gemm_heads(dST + (long long)n * heads * T * T, T, (long long)T * T, QT + (long long)n * heads * dpad * T, T,
-                           (long long)dpad * T, dqkv.p + (long long)n * T * 3 * C + d, 3 * C, 3 * d, T, d, T, 1.f,
-                           IG_OUT_F16));
+    AttnArgs g;
+    g.qkv = sv.qkv.p; g.out = sv.a.p; g.dout = dA.p; g.dqkv = dqkv.p; g.lse = sv.lse; g.Dbuf = u->attn_D;
+    g.N = N; g.T = T; g.C = C; g.heads = heads; g.d = d; g.alpha = alpha;
+    ISHAP_TRY(attn_backward_launch(g, e.s));
   }
   Tensor dn;
   ISHAP_TRY(dgrad_op(e, L.qkv, dqkv, dn, C));

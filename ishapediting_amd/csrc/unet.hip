@@ -6,6 +6,7 @@
 
 #include <cstring>
 
+#include "attention.h"
 #include "decode.h"
 #include "misc.h"
 #include "norm.h"
@@ -331,7 +332,6 @@ static int res_forward(Exec& e, ResL& L, const Tensor& x, Tensor& y) {
 static int attn_forward(Exec& e, AttnL& L, const Tensor& x, Tensor& y) {
   ishap_unet* u = e.u;
   const int N = x.N, T = x.H * x.W, C = L.C, heads = L.heads, d = C / heads;
-  const int dpad = d < 64 ? 64 : d;
   ISHAP_REQUIRE(x.C == C, "attention channels");
   ISHAP_REQUIRE(d % 32 == 0, "head width must be a multiple of 32");
   float* st = aalloc<float>(e, (size_t)N * 64);
@@ -351,41 +351,19 @@ static int attn_forward(Exec& e, AttnL& L, const Tensor& x, Tensor& y) {
                     IG_OUT_F16, 0, 0));
   Tensor a = x;
   a.p = aalloc<half_t>(e, x.numel());
-  const size_t s_need = (size_t)N * heads * T * T;
-  half_t* Pbuf = e.keep ? aalloc<half_t>(e, s_need) : nullptr;     // kept for the backward, else shared scratch
-  const size_t t_need = (size_t)N * heads * dpad * T;
-  if (e.dry) {
-    if (s_need > u->attn_S_floats) u->attn_S_floats = s_need;
-    if (t_need > u->attn_T_halfs) u->attn_T_halfs = t_need;
-  } else {
-    for (int n = 0; n < N; ++n) {      // S = (q*s)^T (k*s), s = d^-1/4   (unet.py:348-351)
-      IgemmArgs g;
-      g.X = qkv.p + (long long)n * T * 3 * C;       g.ldx = 3 * C; g.bsx = 3 * d;
-      g.Wt = qkv.p + (long long)n * T * 3 * C + d;  g.ldw = 3 * C; g.bsw = 3 * d;
-      g.out = u->attn_S + (long long)n * heads * T * T; g.ldo = T; g.bso = (long long)T * T;
-      g.M = T; g.N = T; g.K = d; g.nbatch = heads; g.alpha = 1.f / sqrtf((float)d);
-      g.out_mode = IG_OUT_F32;
-      ISHAP_TRY(igemm_launch(g, e.s));
-    }
-    half_t* P = Pbuf ? Pbuf : u->attn_P;
-    ISHAP_TRY(softmax_rows(u->attn_S, P, lse, (long long)N * heads * T, T, e.s));
-    ISHAP_TRY(head_transpose(qkv.p, u->attn_T, N, T, 3 * C, heads, d, dpad, 3 * d, 2 * d, e.s));
-    for (int n = 0; n < N; ++n) {      // a = P v   (unet.py:353)
-      IgemmArgs g;
-      g.X = P + (long long)n * heads * T * T;      g.ldx = T; g.bsx = (long long)T * T;
-      g.Wt = u->attn_T + (long long)n * heads * dpad * T;  g.ldw = T; g.bsw = (long long)dpad * T;
-      g.out = a.p + (long long)n * T * C; g.ldo = C; g.bso = d;
-      g.M = T; g.N = d; g.K = T; g.nbatch = heads;
-      g.out_mode = IG_OUT_F16;
-      ISHAP_TRY(igemm_launch(g, e.s));
-    }
+  if (!e.dry) {
+    // fused flash-style attention: w = softmax((q*s)^T (k*s)), a = w v   (unet.py:347-353)
+    AttnArgs g;
+    g.qkv = qkv.p; g.out = a.p; g.lse = lse; g.N = N; g.T = T; g.C = C; g.heads = heads; g.d = d;
+    g.alpha = 1.f / sqrtf((float)d);
+    ISHAP_TRY(attn_forward_launch(g, e.s));
   }
   y = x;
   y.p = aalloc<half_t>(e, x.numel());
   y.sums = salloc(e, (size_t)N * C * 2);
   ISHAP_TRY(conv_op(e, a.p, N, x.H, x.W, C, L.proj.w, L.proj.kpad, 1, C, L.proj.bias, x.p, C, y.p, C, IG_OUT_F16, 0, 0,
                     y.sums));
-  L.sv.x = x; L.sv.qkv = qkv; L.sv.a = a; L.sv.stats = st; L.sv.lse = lse; L.sv.P = Pbuf;
+  L.sv.x = x; L.sv.qkv = qkv; L.sv.a = a; L.sv.stats = st; L.sv.lse = lse; L.sv.P = nullptr;
   return 0;
 }
 
