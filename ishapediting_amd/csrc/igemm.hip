@@ -257,6 +257,8 @@ extern "C" int ishap_profile_end(double* out, int nvar) {
 }
 
 int igemm2_launch_main(const IgemmArgs& a, bool big, hipStream_t s);   // igemm2.hip (LDS-DMA ring, BK = 64)
+bool igemm3_applicable(const IgemmArgs& a, bool big);                  // igemm3.hip (3x3 with activation reuse across dx)
+int igemm3_launch_main(const IgemmArgs& a, bool big, hipStream_t s);
 
 template <int BM, int BN, int BK, int WM, int WN, bool CONV3>
 static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
@@ -269,6 +271,8 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   }
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
   auto fire = [&]() -> int {
+    static const int use3 = [] { const char* e = getenv("ISHAP_IGEMM3"); return e ? atoi(e) : 0; }();   // 1 = big tiles, 2 = all
+    if (BK == 64 && CONV3 && use3 && (use3 > 1 || BM == 128) && igemm3_applicable(a, BM == 128)) return igemm3_launch_main(a, BM == 128, s);
     if (BK == 64) return igemm2_launch_main(a, BM == 128, s);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
     return 0;

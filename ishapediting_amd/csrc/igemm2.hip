@@ -12,8 +12,12 @@ __device__ __attribute__((aligned(128))) half_t g_zero_line[64];   // zero-initi
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+#ifndef IG2_LOADERS
+#define IG2_LOADERS 4          // loader waves per workgroup (4 measured faster than 8)
+#endif
+
 template <int BM, int BN, int NST, bool CONV3>
-__global__ __launch_bounds__(256) void igemm2_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(256 + 64 * IG2_LOADERS) void igemm2_kernel(IgemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only builtins; the host pass only needs the launch stub
   constexpr int BK = 64;
   constexpr int CPR = 8;                 // 16-byte chunks per tile row
@@ -26,9 +30,15 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   half_t* lds = reinterpret_cast<half_t*>(smem_raw);
 
+  // 8 waves: 0-3 compute (2x2 MFMA sub-tiles), 4-7 only issue the global->LDS DMA.  A DMA instruction costs its wave
+  // ~150 cycles of issue time; on dedicated loader waves that time overlaps the consumers' MFMAs instead of preceding them.
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave8 >= 4;
+  constexpr int LSPLIT = IG2_LOADERS / 4;               // loader waves sharing one consumer-wave's worth of DMA instructions
+  const int wave = loader ? (wave8 - 4) / LSPLIT : wave8;
+  const int lpart = loader ? (wave8 - 4) % LSPLIT : 0;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with a private 4 MiB L2); remap the
   // linear id so that one XCD gets a contiguous run of tiles (n fastest, then m): neighbouring image rows, whose 3x3
@@ -127,12 +137,14 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmArgs a) {
 #ifndef ABL_NOLOAD
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      __builtin_amdgcn_global_load_lds(xp[i], (lds_void*)(sx + (wave * XI + i) * RPI * BK), 16, 0, 0);
+      if (i % LSPLIT == lpart)
+        __builtin_amdgcn_global_load_lds(xp[i], (lds_void*)(sx + (wave * XI + i) * RPI * BK), 16, 0, 0);
       xp[i] += xstep[i];
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      __builtin_amdgcn_global_load_lds(wp[i], (lds_void*)(sw + (wave * WI + i) * RPI * BK), 16, 0, 0);
+      if (i % LSPLIT == lpart)
+        __builtin_amdgcn_global_load_lds(wp[i], (lds_void*)(sw + (wave * WI + i) * RPI * BK), 16, 0, 0);
       wp[i] += BK;
     }
 #endif
@@ -145,26 +157,33 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmArgs a) {
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: NST-1 stages in flight ----
+  if (loader) {
 #pragma unroll
-  for (int s = 0; s < NST - 1; ++s)
-    if (s < nk) issue(s);
+    for (int s = 0; s < NST - 1; ++s)
+      if (s < nk) issue(s);
+  }
 
   for (int k = 0; k < nk; ++k) {
-    // stage k must have landed: stages up to min(nk, k+NST-1)-1 are issued, (XI+WI) instructions each
-    if (k + NST - 1 <= nk) {
+    if (loader) {
+      // stage k must have landed: stages up to min(nk, k+NST-1)-1 are issued, (XI+WI) instructions each
+      if (k + NST - 1 <= nk) {
       #if defined(ABL_NOX)
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (WI)) : "memory");
 #elif defined(ABL_NOW)
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (XI)) : "memory");
 #else
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (XI + WI)) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (XI + WI) / LSPLIT) : "memory");
 #endif
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (k + NST - 1 < nk) issue((k + NST - 1) % NST);
+    if (loader) {
+      if (k + NST - 1 < nk) issue((k + NST - 1) % NST);
+      continue;
+    }
     const half_t* bx = lds + (k % NST) * STAGE;
     const half_t* bw = bx + BM * BK;
 #pragma unroll
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmArgs a) {
     }
   }
 
-  igemm_epilogue<MT, NT, TMW, TNW, BN>(a, acc, m0, n0, wm, wn, lane, batch, ks_id, reinterpret_cast<float*>(smem_raw));
+  igemm_epilogue<MT, NT, TMW, TNW, BN>(a, acc, m0, n0, wm, wn, lane, batch, ks_id, reinterpret_cast<float*>(smem_raw), !loader);
 #endif
 }
 
@@ -210,7 +229,7 @@ static int launch2(const IgemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+  hipLaunchKernelGGL(kern, grid, dim3(256 + 64 * IG2_LOADERS), smem, s, a);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -8,7 +8,9 @@
 
 template <int MT, int NT, int TMW, int TNW, int BN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[NT][MT], int m0, int n0, int wm, int wn,
-                                               int lane, int batch, int ks_id, float* lds_f) {
+                                               int lane, int batch, int ks_id, float* lds_f, bool active = true) {
+  // `active` = false: a loader wave of a producer/consumer kernel -- it owns no outputs but must take part in the
+  // workgroup barriers of the statistics reduction below
   const int HW = a.H * a.W;
   float ssum[NT][4], ssq[NT][4];
 #pragma unroll
@@ -17,6 +19,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     for (int c = 0; c < 4; ++c) { ssum[i][c] = 0.f; ssq[i][c] = 0.f; }
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
+    if (!active) break;
     const int m = m0 + wm * TMW + j * 16 + (lane & 15);
     int n_img = 0, py = 0, px = 0;
     if (a.res_ups || a.out_mode == IG_OUT_NCHW_F32) {
@@ -70,7 +73,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         ssum[i][c] = s; ssq[i][c] = q;
       }
     __syncthreads();                       // the K-loop's LDS tiles are dead from here on
-    if ((lane & 15) == 0) {
+    if (active && (lane & 15) == 0) {
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll

@@ -4,11 +4,12 @@
 #include <cstdlib>
 #include <vector>
 #include "../ishapediting_amd/csrc/igemm2.hip"
+#include "../ishapediting_amd/csrc/igemm3.hip"
 void ishap_set_error(const std::string& m) { fprintf(stderr, "ERR %s\n", m.c_str()); }
 
 int main(int argc, char** argv) {
   int H = argc > 1 ? atoi(argv[1]) : 128, Cin = argc > 2 ? atoi(argv[2]) : 256, Cout = argc > 3 ? atoi(argv[3]) : 256;
-  int big = argc > 4 ? atoi(argv[4]) : 1, ksplit = argc > 5 ? atoi(argv[5]) : 1;
+  int big = argc > 4 ? atoi(argv[4]) : 1, ksplit = argc > 5 ? atoi(argv[5]) : 1, gen = argc > 6 ? atoi(argv[6]) : 2;
   int M = H * H, K = 9 * Cin;
   half_t *X, *W, *O; float* ws;
   hipMalloc(&X, (size_t)M * Cin * 2); hipMalloc(&W, (size_t)((Cout + 127) / 128 * 128) * K * 2); hipMalloc(&O, (size_t)M * Cout * 2);
@@ -22,15 +23,16 @@ int main(int argc, char** argv) {
   a.X = X; a.Wt = W; a.out = O; a.M = M; a.N = Cout; a.K = K; a.conv3 = 1; a.Cin = Cin; a.ldx = Cin; a.ldw = K; a.ldo = Cout;
   a.H = H; a.W = H; a.ksplit = ksplit; a.ws = ws;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 5; ++i) igemm2_launch_main(a, big, 0);
+  auto run = [&]() { if (gen == 3 && igemm3_applicable(a, big)) igemm3_launch_main(a, big, 0); else igemm2_launch_main(a, big, 0); };
+  for (int i = 0; i < 5; ++i) run();
   hipDeviceSynchronize();
   const int it = 50;
   hipEventRecord(e0, 0);
-  for (int i = 0; i < it; ++i) igemm2_launch_main(a, big, 0);
+  for (int i = 0; i < it; ++i) run();
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   double us = ms * 1e3 / it, tf = 2.0 * M * Cout * K / (us * 1e-6) / 1e12;
-  printf("H=%d Cin=%d Cout=%d big=%d ksplit=%d : %.2f us  %.1f TFLOP/s\n", H, Cin, Cout, big, ksplit, us, tf);
+  printf("gen%d H=%d Cin=%d Cout=%d big=%d ksplit=%d : %.2f us  %.1f TFLOP/s\n", gen, H, Cin, Cout, big, ksplit, us, tf);
   return 0;
 }
