@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shape-profile", default=None, help="write the per-shape conv/GEMM timing CSV of one edit here")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -157,6 +158,11 @@ def main():
         torch.cuda.synchronize()
         out = (C.c_double * 12)()
         L.ishap_profile_end(out, 4)
+        if a.shape_profile:
+            buf = C.create_string_buffer(1 << 16)
+            L.ishap_profile_shapes(buf, len(buf))
+            with open(a.shape_profile, "w") as f:
+                f.write("M,N,K,conv3,tile,ksplit,launches,main_ms,reduce_ms,gflop\n" + buf.value.decode())
         names = ["igemm_kernel<128,128,*,conv3x3>", "igemm_kernel<64,64,*,conv3x3>", "igemm_kernel<128,128,*,gemm>",
                  "igemm_kernel<64,64,*,gemm>"]
         v = max(range(4), key=lambda i: out[i * 3 + 1])

@@ -173,6 +173,9 @@ int ishap_x0_grad_to_cotangent(const float* dplanes, const float* range, const f
  * 2 GEMM 128^2 tile, 3 GEMM 64^2 tile. */
 int ishap_profile_begin(void);
 int ishap_profile_end(double* out, int nvar);
+/* Per-shape CSV ("M,N,K,conv3,tile,ksplit,launches,main_ms,reduce_ms,gflop" lines) of the same records; call
+ * before the next ishap_profile_begin.  Returns the number of lines, -2 when `cap` is too small. */
+int ishap_profile_shapes(char* buf, int cap);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,7 @@ SYMBOLS = {
                                                c_void_p, c_void_p]),
     "ishap_profile_begin": (C.c_int, []),
     "ishap_profile_end": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
+    "ishap_profile_shapes": (C.c_int, [C.c_char_p, C.c_int]),
     "ishap_triplane_decode_grid": (C.c_int, [c_void_p, C.c_int, C.POINTER(DecoderWeightsC), c_void_p, C.c_int,
                                              c_void_p, c_void_p]),
 }

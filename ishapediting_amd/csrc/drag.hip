@@ -30,12 +30,23 @@ __device__ __forceinline__ Bilin bilin_setup(float u, float v, int W) {
   return b;
 }
 
+// workgroup sum of the per-lane loss terms, then ONE atomic on the accumulator (thousands of same-address atomics
+// -- one per wave -- were the whole run time of these kernels)
+__device__ __forceinline__ void block_loss_add(float lsum, float* dst) {
+  __shared__ float red[4];
+  for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dst, red[0] + red[1] + red[2] + red[3]);
+}
+
 __global__ __launch_bounds__(256) void drag_motion_kernel(DragArgs a) {
   const int side = 2 * a.r + 1;
   const int npos = 3 * a.B * side * side;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (wave >= npos) return;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  float lsum = 0.f;
+  for (int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < npos; wave += nwaves) {
   int j = wave % side;            // lattice index along the row axis
   int i = (wave / side) % side;   // along the column axis
   int b = (wave / (side * side)) % a.B;
@@ -47,7 +58,6 @@ __global__ __launch_bounds__(256) void drag_motion_kernel(DragArgs a) {
   Bilin bt = bilin_setup(a.targets[b * 3 + ac] + oi, a.targets[b * 3 + ar] + oj, a.W);
   const float mult = (float)side;
   const float ntot = 3.f * (float)a.Cc * (float)a.B * (float)side * (float)side * (float)side;
-  float lsum = 0.f;
   for (int c = lane; c < a.Cc; c += 64) {
     const int ch = a.chmap[p * a.Cc + c];
     float patch = 0.f, shift = 0.f;
@@ -69,8 +79,8 @@ __global__ __launch_bounds__(256) void drag_motion_kernel(DragArgs a) {
         atomicAdd(a.grad + ((long long)yt * a.W + xt) * a.ld + ch, bt.w[q] * g);
     }
   }
-  for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
-  if (lane == 0) atomicAdd(a.acc + 0, lsum);
+  }
+  block_loss_add(lsum, a.acc + 0);
 }
 
 // touched[p][row][col] = 1 where a rounded lattice texel of any source/target point lands (drag_utils.py:322-334)
@@ -107,14 +117,14 @@ __global__ void drag_count_kernel(DragArgs a) {
 
 // mask term on untouched texels; one wave per (plane, texel)
 __global__ __launch_bounds__(256) void drag_mask_kernel(DragArgs a) {
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int WW = a.W * a.W;
-  if (wave >= 3 * WW) return;
-  const int p = wave / WW, tex = wave % WW;
-  if (a.touched[wave]) return;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const float denom = (float)a.Cc * (float)a.nmask[0];
   float lsum = 0.f;
+  for (int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < 3 * WW; wave += nwaves) {
+  const int p = wave / WW, tex = wave % WW;
+  if (a.touched[wave]) continue;
   for (int c = lane; c < a.Cc; c += 64) {
     const int ch = a.chmap[p * a.Cc + c];
     const long long o = (long long)tex * a.ld + ch;
@@ -124,8 +134,8 @@ __global__ __launch_bounds__(256) void drag_mask_kernel(DragArgs a) {
     else { lsum += d * d; g = -a.cof * 2.f * d / denom; }
     atomicAdd(a.grad + o, g);   // (plane, c) -> unique ch, but chmap may repeat a channel (nearest resize)
   }
-  for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
-  if (lane == 0) atomicAdd(a.acc + 1, lsum);
+  }
+  block_loss_add(lsum, a.acc + 1);
 }
 
 __global__ void drag_finish_kernel(DragArgs a) {
@@ -151,8 +161,8 @@ int drag_loss_grad_launch(const DragArgs& a, hipStream_t s) {
   ISHAP_CHECK_HIP(hipMemsetAsync(a.grad, 0, (size_t)a.W * a.W * a.ld * sizeof(float), s));
   ISHAP_CHECK_HIP(hipMemsetAsync(a.acc, 0, 2 * sizeof(float), s));
   int npos = 3 * a.B * side * side;
-  hipLaunchKernelGGL(drag_motion_kernel, dim3(ceil_div(npos * 64, 256)), dim3(256), 0, s, a);
-  if (a.cof > 0.f) hipLaunchKernelGGL(drag_mask_kernel, dim3(ceil_div(3 * a.W * a.W * 64, 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(drag_motion_kernel, dim3(min(ceil_div(npos * 64, 256), 1024)), dim3(256), 0, s, a);
+  if (a.cof > 0.f) hipLaunchKernelGGL(drag_mask_kernel, dim3(min(ceil_div(3 * a.W * a.W * 64, 256), 1024)), dim3(256), 0, s, a);
   hipLaunchKernelGGL(drag_finish_kernel, dim3(1), dim3(1), 0, s, a);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
@@ -164,7 +174,10 @@ __global__ void absmax_kernel(const float* __restrict__ g, long long n, unsigned
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     m = fmaxf(m, fabsf(g[i]));
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out_bits, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));   // one per workgroup
 }
 __global__ void pick_scale_kernel(const unsigned* __restrict__ bits, float* __restrict__ scale2) {
   float m = __uint_as_float(bits[0]);
@@ -183,7 +196,7 @@ __global__ void scale_to_f16_kernel(const float* __restrict__ g, half_t* __restr
 int grad_to_scaled_f16_launch(const float* g, half_t* o, unsigned* bits, float* scale2, long long n, hipStream_t s) {
   ISHAP_CHECK_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned), s));
   int blocks = (int)std::min<long long>((n + 255) / 256, 1024);
-  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, g, n, bits);
+  hipLaunchKernelGGL(absmax_kernel, dim3(std::min(blocks, 512)), dim3(256), 0, s, g, n, bits);
   hipLaunchKernelGGL(pick_scale_kernel, dim3(1), dim3(1), 0, s, bits, scale2);
   hipLaunchKernelGGL(scale_to_f16_kernel, dim3(blocks), dim3(256), 0, s, g, o, scale2, n);
   ISHAP_CHECK_HIP(hipGetLastError());

@@ -176,8 +176,15 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(IgemmArgs a) {
   half4 o = {0, 0, 0, 0};
   if (ok) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < a.ksplit; ++z)
-      v += *reinterpret_cast<const f32x4*>(a.ws + (((long long)z * a.nbatch + batch) * a.M + m) * a.N + n);
+    const float* wp = a.ws + ((long long)batch * a.M + m) * a.N + n;
+    const long long zs = (long long)a.nbatch * a.M * a.N;
+    int z = 0;
+    for (; z + 4 <= a.ksplit; z += 4) {             // four slices in flight; summed in slice order
+      const f32x4 p0 = *reinterpret_cast<const f32x4*>(wp + (z + 0) * zs), p1 = *reinterpret_cast<const f32x4*>(wp + (z + 1) * zs);
+      const f32x4 p2 = *reinterpret_cast<const f32x4*>(wp + (z + 2) * zs), p3 = *reinterpret_cast<const f32x4*>(wp + (z + 3) * zs);
+      v += p0; v += p1; v += p2; v += p3;
+    }
+    for (; z < a.ksplit; ++z) v += *reinterpret_cast<const f32x4*>(wp + z * zs);
     v *= a.alpha;
     if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
     int n_img = 0, py = 0, px = 0;
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(IgemmArgs a) {
 
 // ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream around the main kernel ----
 #include <vector>
-struct ProfRec { hipEvent_t a, b; double flops; int variant; };
+struct ProfRec { hipEvent_t a, b, c; double flops; int variant; int M, N, K, conv3, big, ksplit; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -237,7 +244,7 @@ static hipEvent_t prof_event() {
   return e;
 }
 extern "C" int ishap_profile_begin(void) {
-  for (auto& r : g_prof) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
+  for (auto& r : g_prof) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); if (r.c) g_prof_pool.push_back(r.c); }
   g_prof.clear();
   g_prof_on = true;
   return 0;
@@ -256,6 +263,34 @@ extern "C" int ishap_profile_end(double* out, int nvar) {
   return 0;
 }
 
+// Per-shape breakdown of the launches recorded since ishap_profile_begin (call before ishap_profile_end resets
+// nothing; both may be called): CSV lines "M,N,K,conv3,tile,ksplit,launches,main_ms,reduce_ms,gflop" into buf.
+#include <map>
+#include <cstring>
+#include <array>
+#include <string>
+extern "C" int ishap_profile_shapes(char* buf, int cap) {
+  std::map<std::array<int, 6>, std::array<double, 4>> agg;
+  for (auto& r : g_prof) {
+    if (hipEventSynchronize(r.c ? r.c : r.b) != hipSuccess) return -1;
+    float ms = 0.f, ms2 = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return -1;
+    if (r.c && hipEventElapsedTime(&ms2, r.b, r.c) != hipSuccess) return -1;
+    auto& v = agg[{r.M, r.N, r.K, r.conv3, r.big ? 128 : 64, r.ksplit}];
+    v[0] += 1.0; v[1] += ms; v[2] += ms2; v[3] += r.flops * 1e-9;
+  }
+  std::string out;
+  char line[160];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof line, "%d,%d,%d,%d,%d,%d,%.0f,%.4f,%.4f,%.3f\n", kv.first[0], kv.first[1], kv.first[2], kv.first[3],
+             kv.first[4], kv.first[5], kv.second[0], kv.second[1], kv.second[2], kv.second[3]);
+    out += line;
+  }
+  if ((int)out.size() + 1 > cap) return -2;
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return (int)agg.size();
+}
+
 int igemm2_launch_main(const IgemmArgs& a, bool big, hipStream_t s);   // igemm2.hip (LDS-DMA ring, BK = 64)
 bool igemm3_applicable(const IgemmArgs& a, bool big);                  // igemm3.hip (3x3 with activation reuse across dx)
 int igemm3_launch_main(const IgemmArgs& a, bool big, hipStream_t s);
@@ -270,6 +305,7 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
+  int prof_slot = -1;
   auto fire = [&]() -> int {
     static const int use3 = [] { const char* e = getenv("ISHAP_IGEMM3"); return e ? atoi(e) : 0; }();   // 1 = big tiles, 2 = all
     if (BK == 64 && CONV3 && use3 && (use3 > 1 || BM == 128) && igemm3_applicable(a, BM == 128)) return igemm3_launch_main(a, BM == 128, s);
@@ -279,12 +315,14 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   };
   if (g_prof_on) {
     ProfRec r;
-    r.a = prof_event(); r.b = prof_event();
+    r.a = prof_event(); r.b = prof_event(); r.c = nullptr;
     r.flops = 2.0 * a.M * a.N * a.K * a.nbatch * a.flops_scale;
     r.variant = (CONV3 ? 0 : 2) + (BM == 128 ? 0 : 1);
+    r.M = a.M * a.nbatch; r.N = a.N; r.K = a.K; r.conv3 = CONV3; r.big = BM == 128; r.ksplit = a.ksplit;
     (void)hipEventRecord(r.a, s);
     ISHAP_TRY(fire());
     (void)hipEventRecord(r.b, s);
+    prof_slot = (int)g_prof.size();
     g_prof.push_back(r);
   } else {
     ISHAP_TRY(fire());
@@ -294,6 +332,10 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
     const unsigned rblocks = (unsigned)((long long)a.nbatch * (a.M / 16) * ((a.N + 63) / 64));
     hipLaunchKernelGGL(igemm_splitk_reduce, dim3(rblocks), dim3(256), 0, s, a);
     ISHAP_CHECK_HIP(hipGetLastError());
+    if (prof_slot >= 0) {
+      g_prof[prof_slot].c = prof_event();
+      (void)hipEventRecord(g_prof[prof_slot].c, s);
+    }
   }
   return 0;
 }

@@ -2,6 +2,7 @@
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DABL_NOLOAD|-DABL_NOMFMA] tools/bench_igemm.hip -o /tmp/bench_igemm
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <vector>
 #include "../ishapediting_amd/csrc/igemm2.hip"
 #include "../ishapediting_amd/csrc/igemm3.hip"
@@ -10,7 +11,8 @@ void ishap_set_error(const std::string& m) { fprintf(stderr, "ERR %s\n", m.c_str
 int main(int argc, char** argv) {
   int H = argc > 1 ? atoi(argv[1]) : 128, Cin = argc > 2 ? atoi(argv[2]) : 256, Cout = argc > 3 ? atoi(argv[3]) : 256;
   int big = argc > 4 ? atoi(argv[4]) : 1, ksplit = argc > 5 ? atoi(argv[5]) : 1, gen = argc > 6 ? atoi(argv[6]) : 2;
-  int M = H * H, K = 9 * Cin;
+  int ksize = argc > 7 ? atoi(argv[7]) : 3;
+  int M = H * H, K = ksize * ksize * Cin;
   half_t *X, *W, *O; float* ws;
   hipMalloc(&X, (size_t)M * Cin * 2); hipMalloc(&W, (size_t)((Cout + 127) / 128 * 128) * K * 2); hipMalloc(&O, (size_t)M * Cout * 2);
   hipMalloc(&ws, (size_t)ksplit * M * Cout * 4);
@@ -20,7 +22,7 @@ int main(int argc, char** argv) {
   hipMemcpy(X, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
   IgemmArgs a;
-  a.X = X; a.Wt = W; a.out = O; a.M = M; a.N = Cout; a.K = K; a.conv3 = 1; a.Cin = Cin; a.ldx = Cin; a.ldw = K; a.ldo = Cout;
+  a.X = X; a.Wt = W; a.out = O; a.M = M; a.N = Cout; a.K = K; a.conv3 = ksize == 3; a.Cin = Cin; a.ldx = Cin; a.ldw = K; a.ldo = Cout;
   a.H = H; a.W = H; a.ksplit = ksplit; a.ws = ws;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto run = [&]() { if (gen == 3 && igemm3_applicable(a, big)) igemm3_launch_main(a, big, 0); else igemm2_launch_main(a, big, 0); };
