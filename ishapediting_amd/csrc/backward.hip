@@ -14,18 +14,26 @@
 #include "norm.h"
 
 static int gn_bwd_op(Exec& e, GnBwdArgs g) {
-  g.csums = salloc(e, (size_t)g.N * g.C * 2);     // zeroed with the rest of the stats arena at the start of the forward
+  if (!g.sums_ready) g.csums = salloc(e, (size_t)g.N * g.C * 2);     // zeroed with the rest of the stats arena at the start of the forward
   if (e.dry) return 0;
   ISHAP_REQUIRE(g.csums != nullptr, "stats arena exhausted");
   return gn_backward_launch(g, e.s);
 }
 
 // dY [N,H,W,cout] -> dX [N,H,W,rows of wT] through the transposed / flipped operand
-static int dgrad_op(Exec& e, const ConvW& c, const Tensor& dy, Tensor& dx_out, int n_out) {
+// `gb`: the GroupNorm whose activation this gradient arrives at, at the same resolution (GB_SAME) -- its per-channel
+// backward sums are then accumulated in this launch's epilogue (gb->csums allocated here, gb->sums_ready set).
+static int dgrad_op(Exec& e, const ConvW& c, const Tensor& dy, Tensor& dx_out, int n_out, GnBwdArgs* gb = nullptr) {
   dx_out = Tensor{nullptr, dy.N, dy.H, dy.W, n_out};
   dx_out.p = aalloc<half_t>(e, dx_out.numel());
+  if (gb) {
+    gb->csums = salloc(e, (size_t)gb->N * gb->C * 2);
+    gb->sums_ready = 1;
+    ISHAP_REQUIRE(e.dry || gb->csums != nullptr, "stats arena exhausted");
+    ISHAP_REQUIRE(gb->C == n_out && gb->gmode == GB_SAME, "fused GroupNorm-backward sums need the gradient at the GN resolution");
+  }
   return conv_op(e, dy.p, dy.N, dy.H, dy.W, dy.C, c.wT, c.cout_pad, c.taps, n_out, nullptr, nullptr, 0, dx_out.p, n_out,
-                 IG_OUT_F16, 0, 0);
+                 IG_OUT_F16, 0, 0, nullptr, gb);
 }
 
 static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx) {
@@ -36,19 +44,24 @@ static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx) {
   ISHAP_REQUIRE(dy.C == L.cout && dy.H == h1.H && dy.N == x.N, "ResBlock gradient shape");
   // out_layers: conv2 <- SiLU <- FiLM <- GN2
   Tensor dc;
-  ISHAP_TRY(dgrad_op(e, L.c2, dy, dc, L.cout));
   Tensor dh1 = h1;
-  dh1.p = aalloc<half_t>(e, h1.numel());
   {
     GnBwdArgs g;
-    g.g = dc.p; g.x = h1.p; g.dx = dh1.p; g.stats = sv.stats2; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
+    g.x = h1.p; g.stats = sv.stats2; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
     g.emb = u->d_film + L.emb_off; g.emb_ld = u->film_rows;
     g.N = h1.N; g.H = h1.H; g.W = h1.W; g.C = L.cout; g.film = 1; g.act = 1; g.gmode = GB_SAME;
+    ISHAP_TRY(dgrad_op(e, L.c2, dy, dc, L.cout, &g));
+    dh1.p = aalloc<half_t>(e, h1.numel());
+    g.g = dc.p; g.dx = dh1.p;
     ISHAP_TRY(gn_bwd_op(e, g));
   }
   // in_layers: conv1 <- (up/down sample) <- SiLU <- GN1
+  GnBwdArgs g1;
+  g1.x = x.p; g1.stats = sv.stats1; g1.gamma = L.n1.gamma; g1.beta = L.n1.beta;
+  g1.N = x.N; g1.H = x.H; g1.W = x.W; g1.C = L.cin; g1.film = 0; g1.act = 1;
+  g1.gmode = L.down ? GB_UNPOOL : (L.up ? GB_SUM4 : GB_SAME);
   Tensor da;
-  ISHAP_TRY(dgrad_op(e, L.c1, dh1, da, L.cin));
+  ISHAP_TRY(dgrad_op(e, L.c1, dh1, da, L.cin, g1.gmode == GB_SAME ? &g1 : nullptr));
   const half_t* add = dy.p;     // identity skip: gradient of `x_upd(x)` (unet.py:241,256)
   if (L.has_skip) {
     Tensor dxs;
@@ -57,13 +70,8 @@ static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx) {
   }
   dx = x;
   dx.p = aalloc<half_t>(e, x.numel());
-  {
-    GnBwdArgs g;
-    g.g = da.p; g.x = x.p; g.add = add; g.dx = dx.p; g.stats = sv.stats1; g.gamma = L.n1.gamma; g.beta = L.n1.beta;
-    g.N = x.N; g.H = x.H; g.W = x.W; g.C = L.cin; g.film = 0; g.act = 1;
-    g.gmode = L.down ? GB_UNPOOL : (L.up ? GB_SUM4 : GB_SAME);
-    ISHAP_TRY(gn_bwd_op(e, g));
-  }
+  g1.g = da.p; g1.add = add; g1.dx = dx.p;
+  ISHAP_TRY(gn_bwd_op(e, g1));
   return 0;
 }
 
@@ -87,13 +95,14 @@ static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx) {
     ISHAP_TRY(attn_backward_launch(g, e.s));
   }
   Tensor dn;
-  ISHAP_TRY(dgrad_op(e, L.qkv, dqkv, dn, C));
   dx = x;
-  dx.p = aalloc<half_t>(e, x.numel());
   {
     GnBwdArgs g;
-    g.g = dn.p; g.x = x.p; g.add = dy.p; g.dx = dx.p; g.stats = sv.stats; g.gamma = L.n.gamma; g.beta = L.n.beta;
+    g.x = x.p; g.stats = sv.stats; g.gamma = L.n.gamma; g.beta = L.n.beta;
     g.N = N; g.H = x.H; g.W = x.W; g.C = C; g.film = 0; g.act = 0; g.gmode = GB_SAME;
+    ISHAP_TRY(dgrad_op(e, L.qkv, dqkv, dn, C, &g));
+    dx.p = aalloc<half_t>(e, x.numel());
+    g.g = dn.p; g.add = dy.p; g.dx = dx.p;
     ISHAP_TRY(gn_bwd_op(e, g));
   }
   return 0;
@@ -140,14 +149,15 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
     dout.p = aalloc<half_t>(e, dout.numel());
     if (!dry) ISHAP_TRY(nchw_to_nhwc_f16_scaled(cot_out, cot_out_f16 ? 0 : 1, dout.p, N, cfg.out_channels, S * S, opad, 1.f, s));
     Tensor dact;
-    ISHAP_TRY(dgrad_op(e, u->head, dout, dact, u->final_ch));
+    GnBwdArgs a;
+    a.x = u->h_final.p; a.stats = u->head_stats; a.gamma = u->head_norm.gamma;
+    a.beta = u->head_norm.beta; a.N = N; a.H = S; a.W = S; a.C = u->final_ch; a.act = 1;
+    ISHAP_TRY(dgrad_op(e, u->head, dout, dact, u->final_ch, &a));
     g = u->h_final;
     if (dry) g = Tensor{nullptr, N, S, S, u->final_ch};
     Tensor gh = g;
     gh.p = aalloc<half_t>(e, g.numel());
-    GnBwdArgs a;
-    a.g = dact.p; a.x = u->h_final.p; a.dx = gh.p; a.stats = u->head_stats; a.gamma = u->head_norm.gamma;
-    a.beta = u->head_norm.beta; a.N = N; a.H = S; a.W = S; a.C = u->final_ch; a.act = 1;
+    a.g = dact.p; a.dx = gh.p;
     ISHAP_TRY(gn_bwd_op(e, a));
     g = gh;
   } else {

@@ -73,6 +73,17 @@ struct IgemmArgs {
   long long* stat_out = nullptr; // optional [N_img][N][2]: += per-channel (sum, sum of squares) of the fp16 outputs, as 64-bit
                                  // fixed point (STAT_SCALE_*): integer atomics commute, so the statistics are bitwise reproducible
   float flops_scale = 1.f;       // algorithmic / executed FLOPs (1/3 for the hi-lo split head conv)
+  // Fused GroupNorm-backward sums (input-gradient launches whose output is the gradient arriving at act(film(GN(x)))):
+  // the epilogue adds per-channel sum(dyh), sum(dyh*xhat) of its fp16 outputs to gb_csums [N_img][N][2] (fixed point,
+  // STAT_SCALE_SUM both), so norm_bwd.hip's partial pass is not needed.  Exclusive with stat_out.
+  const half_t* gb_x = nullptr;      // GN input [M][N] (row stride N)
+  const float* gb_stats = nullptr;   // forward (mean, rstd) [N_img][32][2]
+  const float* gb_gamma = nullptr;
+  const float* gb_beta = nullptr;
+  const float* gb_emb = nullptr;     // FiLM rows (scale at c, shift at N + c), per image stride gb_emb_ld
+  int gb_emb_ld = 0;
+  int gb_film = 0, gb_act = 0;
+  long long* gb_csums = nullptr;
 };
 int igemm_launch(const IgemmArgs& a, hipStream_t s);
 // picks a split so the grid fills the chip; returns workspace floats needed

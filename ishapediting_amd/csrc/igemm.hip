@@ -15,6 +15,7 @@
 // bank-conflict free (lane-group table of the gfx950 LDS).
 #include "common.h"
 #include "igemm_epilogue.h"
+#include "gn_bwd_terms.h"
 
 template <int BM, int BN, int BK, int WM, int WN, bool CONV3>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
@@ -209,12 +210,32 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(IgemmArgs a) {
       for (int k = 0; k < 4; ++k) op[(long long)k * HW] = v[k];
     }
   }
-  if (a.stat_out) {
+  if (a.stat_out || a.gb_x) {
+    long long* const sdst = a.gb_x ? a.gb_csums : a.stat_out;
+    const float scale_q = a.gb_x ? STAT_SCALE_SUM : STAT_SCALE_SQ;
+    if (a.gb_x) {                              // GroupNorm-backward sums of the stored gradient (see common.h)
+      const int n_img = m / HW, cpg = a.N / 32;
+      half4 xv = {0, 0, 0, 0};
+      if (ok) xv = *reinterpret_cast<const half4*>(a.gb_x + (long long)m * a.N + n);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float f = (float)o[c];
-      red[r][qd * 4 + c][0] = f;
-      red[r][qd * 4 + c][1] = f * f;
+      for (int c = 0; c < 4; ++c) {
+        float dyh = 0.f, xhat = 0.f;
+        if (ok) {
+          const int g = (n + c) / cpg;
+          gn_bwd_term((float)o[c], (float)xv[c], a.gb_stats[(n_img * 32 + g) * 2], a.gb_stats[(n_img * 32 + g) * 2 + 1],
+                      a.gb_gamma[n + c], a.gb_beta[n + c], a.gb_film ? a.gb_emb[(long long)n_img * a.gb_emb_ld + n + c] : 0.f,
+                      a.gb_film ? a.gb_emb[(long long)n_img * a.gb_emb_ld + a.N + n + c] : 0.f, a.gb_film != 0, a.gb_act != 0, dyh, xhat);
+        }
+        red[r][qd * 4 + c][0] = dyh;
+        red[r][qd * 4 + c][1] = dyh * xhat;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float f = (float)o[c];
+        red[r][qd * 4 + c][0] = f;
+        red[r][qd * 4 + c][1] = f * f;
+      }
     }
     __syncthreads();
     const int t = threadIdx.x;
@@ -225,8 +246,8 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(IgemmArgs a) {
       for (int rr = 0; rr < 16; ++rr) acc += red[rr][ch][k];
       const int nn = cg * 64 + ch;
       if (nn < a.N)
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stat_out + ((long long)((rbi * 16) / HW) * a.N + nn) * 2 + k),
-                  (unsigned long long)__float2ll_rn(acc * (k ? STAT_SCALE_SQ : STAT_SCALE_SUM)));
+        atomicAdd(reinterpret_cast<unsigned long long*>(sdst + ((long long)((rbi * 16) / HW) * a.N + nn) * 2 + k),
+                  (unsigned long long)__float2ll_rn(acc * (k ? scale_q : STAT_SCALE_SUM)));
     }
   }
 }
@@ -353,6 +374,7 @@ int igemm_pick_ksplit(int M, int N, int K, int nbatch) {
   const int bm = big ? 128 : 64, bn = big ? 128 : 64;
   long long blocks = (long long)(M / bm) * ceil_div(N, bn) * nbatch;
   int ks = K / 64;
+  if (ks < 48) return 1;        // measured (tools/sweep_igemm.sh): below ~48 K-steps the extra reduce launch (~5.5 us) costs more than the split saves
   int split = 1;
   while (blocks * split < 160 && ks / (split * 2) >= 6 && split < 32) split *= 2;
   return split;
@@ -364,6 +386,9 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
   ISHAP_REQUIRE(a.K % 32 == 0, "K must be a multiple of 32");
   ISHAP_REQUIRE(!a.conv3 || (a.Cin % 32 == 0 && a.K == 9 * a.Cin), "conv3: K = 9*Cin, Cin % 32 == 0");
   ISHAP_REQUIRE(a.ksplit == 1 || a.ws != nullptr, "split-K needs a workspace");
+  ISHAP_REQUIRE(!a.gb_x || (!a.stat_out && a.out_mode == IG_OUT_F16 && a.ldo == a.N && a.N % 32 == 0 && a.nbatch == 1 && a.gb_csums &&
+                            a.gb_stats && a.gb_gamma && a.gb_beta && (!a.gb_film || a.gb_emb)),
+                "fused GroupNorm-backward sums: fp16 dense output, N % 32 == 0, no forward statistics");
   ISHAP_REQUIRE(a.ldx % 8 == 0 && a.ldw % 8 == 0, "row strides must keep 16-byte alignment");
   const bool k64 = a.conv3 ? (a.Cin % 64 == 0) : (a.K % 64 == 0);
   const bool big = igemm_use_big(a.M, a.N, a.nbatch);

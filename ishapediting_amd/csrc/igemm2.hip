@@ -237,5 +237,8 @@ static int launch2(const IgemmArgs& a, hipStream_t s) {
 // main kernel only (the caller adds the split-K reduce); big = 128x128 tile, else 64x64
 int igemm2_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
   if (big) return a.conv3 ? launch2<128, 128, 4, true>(a, s) : launch2<128, 128, 4, false>(a, s);
-  return a.conv3 ? launch2<64, 64, 4, true>(a, s) : launch2<64, 64, 4, false>(a, s);
+#ifndef IG2_SMALL_NST
+#define IG2_SMALL_NST 4
+#endif
+  return a.conv3 ? launch2<64, 64, IG2_SMALL_NST, true>(a, s) : launch2<64, 64, IG2_SMALL_NST, false>(a, s);
 }

@@ -5,6 +5,7 @@
 // separate pass has to re-read the tensor.
 #pragma once
 #include "common.h"
+#include "gn_bwd_terms.h"
 
 template <int MT, int NT, int TMW, int TNW, int BN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[NT][MT], int m0, int n0, int wm, int wn,
@@ -52,6 +53,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 #pragma unroll
           for (int c = 0; c < 4; ++c) { float f = (float)o[c]; ssum[i][c] += f; ssq[i][c] += f * f; }
         }
+        if (a.gb_x) acc[i][j] = (f32x4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};   // the stored gradient, for the pass below
       } else if (a.out_mode == IG_OUT_F32) {
         *reinterpret_cast<f32x4*>((float*)a.out + (long long)batch * a.bso + (long long)m * a.ldo + n) = v;
       } else {
@@ -61,7 +63,42 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
       }
     }
   }
-  if (a.stat_out && a.ksplit == 1) {
+  if (a.gb_x && a.ksplit == 1 && active) {
+    // GroupNorm-backward sums of this gradient tile (see common.h): channel parameters once per i, pixels over j
+    const int n_img = m0 / HW;
+    const int cpg = a.N / 32;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = n0 + wn * TNW + i * 16 + (lane >> 4) * 4;
+      if (n >= a.N) continue;
+      float mu[4], rs[4], gam[4], bet[4], esc[4], esh[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int g = (n + c) / cpg;
+        mu[c] = a.gb_stats[(n_img * 32 + g) * 2];
+        rs[c] = a.gb_stats[(n_img * 32 + g) * 2 + 1];
+        gam[c] = a.gb_gamma[n + c];
+        bet[c] = a.gb_beta[n + c];
+        esc[c] = a.gb_film ? a.gb_emb[(long long)n_img * a.gb_emb_ld + n + c] : 0.f;
+        esh[c] = a.gb_film ? a.gb_emb[(long long)n_img * a.gb_emb_ld + a.N + n + c] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int m = m0 + wm * TMW + j * 16 + (lane & 15);
+        const half4 xv = *reinterpret_cast<const half4*>(a.gb_x + (long long)m * a.N + n);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float dyh, xhat;
+          gn_bwd_term(acc[i][j][c], (float)xv[c], mu[c], rs[c], gam[c], bet[c], esc[c], esh[c], a.gb_film != 0, a.gb_act != 0, dyh, xhat);
+          ssum[i][c] += dyh;
+          ssq[i][c] += dyh * xhat;
+        }
+      }
+    }
+  }
+  if ((a.stat_out || a.gb_x) && a.ksplit == 1) {
+    long long* const sdst = a.gb_x ? a.gb_csums : a.stat_out;
+    const float scale_q = a.gb_x ? STAT_SCALE_SUM : STAT_SCALE_SQ;
     // reduce over the 16 pixel-lanes, stage per-wave channel sums in LDS, one atomic per (channel, stat) per block
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -90,8 +127,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
       if (n0 + nl < a.N) {
         const float v = lds_f[t] + lds_f[BN * 2 + t];                   // the two wm waves
         const int n_img = m0 / HW;                                        // a tile never straddles images (HW % BM == 0)
-        const long long fx = __float2ll_rn(v * ((t & 1) ? STAT_SCALE_SQ : STAT_SCALE_SUM));
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stat_out + ((long long)n_img * a.N + n0 + nl) * 2 + (t & 1)),
+        const long long fx = __float2ll_rn(v * ((t & 1) ? scale_q : STAT_SCALE_SUM));
+        atomicAdd(reinterpret_cast<unsigned long long*>(sdst + ((long long)n_img * a.N + n0 + nl) * 2 + (t & 1)),
                   (unsigned long long)fx);
       }
     }

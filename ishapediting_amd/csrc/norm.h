@@ -46,5 +46,6 @@ struct GnBwdArgs {
   long long* csums = nullptr;     // zeroed scratch [N][C][2]: per-channel (sum dyh, sum dyh*xh) in 64-bit fixed point
   int N = 1, H = 0, W = 0, C = 0;
   int film = 0, act = 1, gmode = GB_SAME;
+  int sums_ready = 0;             // csums were already accumulated by the producing implicit-GEMM epilogue: apply pass only
 };
 int gn_backward_launch(const GnBwdArgs& a, hipStream_t s);

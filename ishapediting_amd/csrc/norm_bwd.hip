@@ -4,12 +4,7 @@
 // Same two-stage deterministic reduction as the forward statistics; the forward's activations are
 // recomputed from the saved GN input and (mean, rstd) instead of being stored.
 #include "norm.h"
-
-__device__ __forceinline__ float rh_(float v) { return (float)(half_t)v; }
-__device__ __forceinline__ float silu_grad(float v) {
-  float sg = 1.f / (1.f + __expf(-v));
-  return sg * (1.f + v * (1.f - sg));
-}
+#include "gn_bwd_terms.h"
 
 // gradient arriving at pixel (n, y, x) of the GN-input resolution, 8 channels
 __device__ __forceinline__ void load_upstream(const half_t* g, int gmode, int n, int y, int x, int H, int W, int C, int c0,
@@ -49,22 +44,9 @@ __device__ __forceinline__ void bwd_terms(const GnBwdArgs& a, int n, int y, int 
     const int c = c0 + i;
     const int g = c / cpg;
     const float mu = a.stats[(n * 32 + g) * 2], rs = a.stats[(n * 32 + g) * 2 + 1];
-    const float gam = a.gamma[c];
-    const float xhat = ((float)xv[i] - mu) * rs;
-    float u = up[i];
-    float mult = gam;
-    if (FILM || ACT) {
-      float pre = rh_(xhat * gam + a.beta[c]);
-      if (FILM) {
-        const float sc = rh_(1.f + rh_(a.emb[(long long)n * a.emb_ld + c]));
-        const float sh = rh_(a.emb[(long long)n * a.emb_ld + a.C + c]);
-        pre = rh_(rh_(pre * sc) + sh);
-        mult *= sc;
-      }
-      if (ACT) u *= silu_grad(pre);
-    }
-    dyh[i] = u * mult;
-    xh[i] = xhat;
+    gn_bwd_term(up[i], (float)xv[i], mu, rs, a.gamma[c], (FILM || ACT) ? a.beta[c] : 0.f,
+                FILM ? a.emb[(long long)n * a.emb_ld + c] : 0.f, FILM ? a.emb[(long long)n * a.emb_ld + a.C + c] : 0.f, FILM, ACT,
+                dyh[i], xh[i]);
   }
 }
 
@@ -159,7 +141,8 @@ int gn_backward_launch(const GnBwdArgs& a, hipStream_t s) {
   if (blocks > 1024) blocks = 1024;
 #define GB_LAUNCH(F, A)                                                                                             \
   do {                                                                                                              \
-    hipLaunchKernelGGL((gn_bwd_partial_kernel<F, A>), dim3(nblk, a.N), dim3(256), smem, s, a, rpb);                 \
+    if (!a.sums_ready)                                                                                              \
+      hipLaunchKernelGGL((gn_bwd_partial_kernel<F, A>), dim3(nblk, a.N), dim3(256), smem, s, a, rpb);               \
     hipLaunchKernelGGL((gn_bwd_apply_kernel<F, A>), dim3(blocks), dim3(256), 0, s, a);                              \
   } while (0)
   if (a.film) GB_LAUNCH(true, true);

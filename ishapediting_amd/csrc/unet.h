@@ -155,7 +155,7 @@ static inline T* aalloc(Exec& e, size_t count) { return (T*)e.u->arena.alloc(cou
 // X [N,H,W,ldx] (*) Wt -> out; taps 9 (3x3, pad 1) or 1; picks split-K and uses the context workspace
 int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps, int cout,
             const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups, int res_ups,
-            long long* stat_out = nullptr);
+            long long* stat_out = nullptr, const struct GnBwdArgs* gb = nullptr);
 long long* salloc(Exec& e, size_t count);   // from the stats arena
 int gn_stats_op(Exec& e, const Tensor& x, float* stats);
 

@@ -249,9 +249,13 @@ long long* salloc(Exec& e, size_t count) {
 
 int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps,
                    int cout, const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups,
-                   int res_ups, long long* stat_out) {
+                   int res_ups, long long* stat_out, const GnBwdArgs* gb) {
   IgemmArgs a;
   a.stat_out = stat_out;
+  if (gb) {       // this launch produces the gradient arriving at act(film(GN(x))): accumulate the GN-backward sums in its epilogue
+    a.gb_x = gb->x; a.gb_stats = gb->stats; a.gb_gamma = gb->gamma; a.gb_beta = gb->beta; a.gb_emb = gb->emb;
+    a.gb_emb_ld = gb->emb_ld; a.gb_film = gb->film; a.gb_act = gb->act; a.gb_csums = gb->csums;
+  }
   a.X = X; a.Wt = Wt; a.out = out; a.bias = bias; a.res = res;
   a.M = N * H * W; a.N = cout; a.K = taps * kpad;
   a.conv3 = taps == 9; a.Cin = kpad;
