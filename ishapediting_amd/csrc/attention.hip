@@ -24,18 +24,34 @@ __device__ __forceinline__ half8 ld_frag(const half_t* tile, int stride, int i0,
   return *reinterpret_cast<const half8*>(tile + (i0 + (lane & 15)) * stride + k0 + 8 * (lane >> 4));
 }
 
-// copy 64 rows x D halfs (row-major, global row stride ld) into LDS, row-major and/or transposed
-template <int D, bool ROWS, bool TRANS>
-__device__ __forceinline__ void stage_tile(const half_t* __restrict__ src, int ld, half_t* rows, half_t* trans, int tid) {
+// A 64 x D tile (row-major, global row stride ld) travels global -> registers -> LDS in two halves so the loads of
+// the NEXT tile are in flight while the current one is being multiplied (software prefetch; 64*D/8/256 chunks a thread).
+template <int D>
+struct TileRegs { half8 v[(64 * (D / 8) + 255) / 256]; };
+
+template <int D>
+__device__ __forceinline__ void load_tile(const half_t* __restrict__ src, int ld, TileRegs<D>& t, int tid) {
   constexpr int CPR = D / 8;
 #pragma unroll
-  for (int c = tid; c < 64 * CPR; c += 256) {
-    const int r = c / CPR, ch = c % CPR;
-    const half8 v = *reinterpret_cast<const half8*>(src + (long long)r * ld + ch * 8);
-    if (ROWS) *reinterpret_cast<half8*>(rows + r * (D + 8) + ch * 8) = v;
-    if (TRANS) {
+  for (int i = 0; i < (64 * CPR + 255) / 256; ++i) {
+    const int c = tid + i * 256;
+    if (c < 64 * CPR) t.v[i] = *reinterpret_cast<const half8*>(src + (long long)(c / CPR) * ld + (c % CPR) * 8);
+  }
+}
+// registers -> LDS, row-major and/or transposed
+template <int D, bool ROWS, bool TRANS>
+__device__ __forceinline__ void store_tile(const TileRegs<D>& t, half_t* rows, half_t* trans, int tid) {
+  constexpr int CPR = D / 8;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) trans[(ch * 8 + e) * TS + r] = v[e];
+  for (int i = 0; i < (64 * CPR + 255) / 256; ++i) {
+    const int c = tid + i * 256;
+    if (c < 64 * CPR) {
+      const int r = c / CPR, ch = c % CPR;
+      if (ROWS) *reinterpret_cast<half8*>(rows + r * (D + 8) + ch * 8) = t.v[i];
+      if (TRANS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) trans[(ch * 8 + e) * TS + r] = t.v[i][e];
+      }
     }
   }
 }
@@ -72,10 +88,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   for (int r = 0; r < 4; ++r) { m[r] = -1e30f; lsum[r] = 0.f; }
 #pragma unroll
   for (int i = 0; i < DS; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  TileRegs<D> rk, rv;
+  load_tile<D>(base + D, ld, rk, tid);
+  load_tile<D>(base + 2 * D, ld, rv, tid);
   for (int kt = 0; kt < a.T; kt += 64) {
     __syncthreads();
-    stage_tile<D, true, false>(base + (long long)kt * ld + D, ld, sK, nullptr, tid);
-    stage_tile<D, false, true>(base + (long long)kt * ld + 2 * D, ld, nullptr, sVt, tid);
+    store_tile<D, true, false>(rk, sK, nullptr, tid);
+    store_tile<D, false, true>(rv, nullptr, sVt, tid);
+    if (kt + 64 < a.T) {
+      load_tile<D>(base + (long long)(kt + 64) * ld + D, ld, rk, tid);
+      load_tile<D>(base + (long long)(kt + 64) * ld + 2 * D, ld, rv, tid);
+    }
     __syncthreads();
     f32x4 s[4];
 #pragma unroll
@@ -164,10 +187,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   f32x4 dq[DS];
 #pragma unroll
   for (int i = 0; i < DS; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  TileRegs<D> rk, rv;
+  load_tile<D>(base + D, ld, rk, tid);
+  load_tile<D>(base + 2 * D, ld, rv, tid);
   for (int kt = 0; kt < a.T; kt += 64) {
     __syncthreads();
-    stage_tile<D, true, true>(base + (long long)kt * ld + D, ld, sK, sKt, tid);
-    stage_tile<D, true, false>(base + (long long)kt * ld + 2 * D, ld, sV, nullptr, tid);
+    store_tile<D, true, true>(rk, sK, sKt, tid);
+    store_tile<D, true, false>(rv, sV, nullptr, tid);
+    if (kt + 64 < a.T) {
+      load_tile<D>(base + (long long)(kt + 64) * ld + D, ld, rk, tid);
+      load_tile<D>(base + (long long)(kt + 64) * ld + 2 * D, ld, rv, tid);
+    }
     __syncthreads();
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
@@ -226,10 +256,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   f32x4 dk[DS], dv[DS];
 #pragma unroll
   for (int i = 0; i < DS; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  TileRegs<D> rq, ra;
+  float lse_n[4], dq_n[4];                  // per-query lse and D of the tile being prefetched (this lane's 4 columns)
+  const half_t* abase = a.dout + (long long)n * a.T * a.C + h * D;
+  load_tile<D>(base, ld, rq, tid);
+  load_tile<D>(abase, a.C, ra, tid);
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    lse_n[sub] = a.lse[bh * a.T + sub * 16 + (lane & 15)];
+    dq_n[sub] = a.Dbuf[bh * a.T + sub * 16 + (lane & 15)];
+  }
   for (int qt = 0; qt < a.T; qt += 64) {
     __syncthreads();
-    stage_tile<D, true, true>(base + (long long)qt * ld, ld, sQ, sQt, tid);
-    stage_tile<D, true, true>(a.dout + ((long long)n * a.T + qt) * a.C + h * D, a.C, sA, sAt, tid);
+    store_tile<D, true, true>(rq, sQ, sQt, tid);
+    store_tile<D, true, true>(ra, sA, sAt, tid);
+    float lse_c[4], dq_c[4];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) { lse_c[sub] = lse_n[sub]; dq_c[sub] = dq_n[sub]; }
+    if (qt + 64 < a.T) {
+      load_tile<D>(base + (long long)(qt + 64) * ld, ld, rq, tid);
+      load_tile<D>(abase + (long long)(qt + 64) * a.C, a.C, ra, tid);
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        lse_n[sub] = a.lse[bh * a.T + qt + 64 + sub * 16 + (lane & 15)];
+        dq_n[sub] = a.Dbuf[bh * a.T + qt + 64 + sub * 16 + (lane & 15)];
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
@@ -239,8 +291,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kk], ld_frag(sQ, RS, sub * 16, kk * 32, lane), st, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[kk], ld_frag(sA, RS, sub * 16, kk * 32, lane), dp, 0, 0, 0);
       }
-      const int q = qt + sub * 16 + (lane & 15);           // this lane's column
-      const float lse = a.lse[bh * a.T + q], Dq = a.Dbuf[bh * a.T + q];
+      const float lse = lse_c[sub], Dq = dq_c[sub];        // this lane's column q = qt + sub*16 + (lane & 15)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = __expf(st[r] * a.alpha - lse);
