@@ -39,7 +39,7 @@ __device__ __forceinline__ void load_tile(const half_t* __restrict__ src, int ld
   }
 }
 // registers -> LDS, row-major and/or transposed
-template <int D, bool ROWS, bool TRANS>
+template <int D, bool ROWS, bool TRANS, int RSTRIDE = D + 8>
 __device__ __forceinline__ void store_tile(const TileRegs<D>& t, half_t* rows, half_t* trans, int tid) {
   constexpr int CPR = D / 8;
 #pragma unroll
@@ -47,13 +47,21 @@ __device__ __forceinline__ void store_tile(const TileRegs<D>& t, half_t* rows, h
     const int c = tid + i * 256;
     if (c < 64 * CPR) {
       const int r = c / CPR, ch = c % CPR;
-      if (ROWS) *reinterpret_cast<half8*>(rows + r * (D + 8) + ch * 8) = t.v[i];
+      if (ROWS) *reinterpret_cast<half8*>(rows + r * RSTRIDE + ch * 8) = t.v[i];
       if (TRANS) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) trans[(ch * 8 + e) * TS + r] = t.v[i][e];
       }
     }
   }
+}
+
+// gfx950 transposed LDS read: within each 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
+// 4-row x 16-column block of halfs; lane i receives column i of the 4 rows.  On a row-major [key][d] tile this hands
+// lane i four consecutive keys of column d0+i -- a piece of a V^T fragment without a transposed copy.  EXEC must be full.
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ half4 lds_read_tr4(const half_t* p) {
+  return __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
 }
 
 __device__ __forceinline__ float group16_max(float v) {
@@ -68,84 +76,95 @@ __device__ __forceinline__ float group16_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Forward.  Scores are produced TRANSPOSED (S^T = K Q^T: accumulator row = key, column = query), so a lane owns ONE
+// query (column l&15) and 16 of the tile's 64 keys: the running max / sum are per-lane scalars finished with two
+// cross-lane steps (the 4 lanes sharing a column), and the probabilities already sit in the registers in the shape
+// of a B operand (8 keys of one query per lane) for O^T = V^T P^T -- they never visit LDS.  The MFMA contraction
+// slots (group g = l>>4, j < 8) stand for keys {sub_a*16 + 4g + j, sub_b*16 + 4g + j-4}; the V^T fragment is read
+// with the same assignment by two transposed LDS reads of the row-major V tile (lds_read_tr4).
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
+  constexpr int VS = D + 16;                 // V row stride: 160-byte rows keep the transposed reads conflict-free
   __shared__ __attribute__((aligned(16))) half_t sK[64 * RS];
-  __shared__ __attribute__((aligned(16))) half_t sVt[D * TS];
-  __shared__ __attribute__((aligned(16))) half_t sP[4][16 * TS];
+  __shared__ __attribute__((aligned(16))) half_t sV[64 * VS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
   const int ld = 3 * a.C;
+  const int g = lane >> 4, col = lane & 15;
   const half_t* base = a.qkv + (long long)n * a.T * ld + h * 3 * D;
   half8 qf[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk)
-    qf[kk] = *reinterpret_cast<const half8*>(base + (long long)(q0 + wave * 16 + (lane & 15)) * ld + kk * 32 + 8 * (lane >> 4));
-  float m[4], lsum[4];
-  f32x4 o[DS];
+    qf[kk] = *reinterpret_cast<const half8*>(base + (long long)(q0 + wave * 16 + col) * ld + kk * 32 + 8 * g);
+  float m = -1e30f, lsum = 0.f;
+  f32x4 ot[DS];                              // O^T: row d = i*16 + 4g + r, column = this lane's query
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { m[r] = -1e30f; lsum[r] = 0.f; }
-#pragma unroll
-  for (int i = 0; i < DS; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < DS; ++i) ot[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   TileRegs<D> rk, rv;
   load_tile<D>(base + D, ld, rk, tid);
   load_tile<D>(base + 2 * D, ld, rv, tid);
   for (int kt = 0; kt < a.T; kt += 64) {
     __syncthreads();
     store_tile<D, true, false>(rk, sK, nullptr, tid);
-    store_tile<D, false, true>(rv, nullptr, sVt, tid);
+    store_tile<D, true, false, VS>(rv, sV, nullptr, tid);
     if (kt + 64 < a.T) {
       load_tile<D>(base + (long long)(kt + 64) * ld + D, ld, rk, tid);
       load_tile<D>(base + (long long)(kt + 64) * ld + 2 * D, ld, rv, tid);
     }
     __syncthreads();
-    f32x4 s[4];
+    f32x4 st[4];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
-      s[sub] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      st[sub] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
-        s[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[kk], ld_frag(sK, RS, sub * 16, kk * 32, lane), s[sub], 0, 0, 0);
+        st[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sK, RS, sub * 16, kk * 32, lane), qf[kk], st[sub], 0, 0, 0);
     }
+    float mx = -1e30f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float mx = -1e30f;
+    for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-      for (int sub = 0; sub < 4; ++sub) { s[sub][r] *= a.alpha; mx = fmaxf(mx, s[sub][r]); }
-      mx = group16_max(mx);
-      const float mn = fmaxf(m[r], mx);
-      const float corr = __expf(m[r] - mn);
-      float rs = 0.f;
+      for (int r = 0; r < 4; ++r) { st[sub][r] *= a.alpha; mx = fmaxf(mx, st[sub][r]); }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m, mx);
+    const float corr = __expf(m - mn);
+    float rs = 0.f;
+    half8 pb[2];
 #pragma unroll
-      for (int sub = 0; sub < 4; ++sub) {
-        const float p = __expf(s[sub][r] - mn);
-        rs += p;
-        sP[wave][((lane >> 4) * 4 + r) * TS + sub * 16 + (lane & 15)] = (half_t)p;
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __expf(st[sub][r] - mn);
+        rs += pv;
+        pb[sub >> 1][(sub & 1) * 4 + r] = (half_t)pv;
       }
-      rs = group16_sum(rs);
-      lsum[r] = lsum[r] * corr + rs;
-      m[r] = mn;
+    rs += __shfl_xor(rs, 16);
+    rs += __shfl_xor(rs, 32);
+    lsum = lsum * corr + rs;
+    m = mn;
 #pragma unroll
-      for (int i = 0; i < DS; ++i) o[i][r] *= corr;
+    for (int i = 0; i < DS; ++i) {
+      ot[i] *= corr;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const half_t* vb = sV + (4 * g + (col >> 2)) * VS + i * 16 + 4 * (col & 3);   // this lane's address in the 4-key block
+        const half4 lo = lds_read_tr4(vb + (2 * pr) * 16 * VS);
+        const half4 hi = lds_read_tr4(vb + (2 * pr + 1) * 16 * VS);
+        const half8 va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        ot[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[pr], ot[i], 0, 0, 0);
+      }
     }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < DS; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        o[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sP[wave], TS, 0, kk * 32, lane),
-                                                      ld_frag(sVt, TS, i * 16, kk * 32, lane), o[i], 0, 0, 0);
   }
+  const int q = q0 + wave * 16 + col;
+  const float inv = 1.f / lsum;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int q = q0 + wave * 16 + (lane >> 4) * 4 + r;
-    const float inv = 1.f / lsum[r];
-#pragma unroll
-    for (int i = 0; i < DS; ++i)
-      a.out[((long long)n * a.T + q) * a.C + h * D + i * 16 + (lane & 15)] = (half_t)(o[i][r] * inv);
-    if ((lane & 15) == 0) a.lse[((long long)n * a.heads + h) * a.T + q] = m[r] + __logf(lsum[r]);
+  for (int i = 0; i < DS; ++i) {
+    const half4 o4 = {(half_t)(ot[i][0] * inv), (half_t)(ot[i][1] * inv), (half_t)(ot[i][2] * inv), (half_t)(ot[i][3] * inv)};
+    *reinterpret_cast<half4*>(a.out + ((long long)n * a.T + q) * a.C + h * D + i * 16 + 4 * g) = o4;
   }
+  if (g == 0) a.lse[((long long)n * a.heads + h) * a.T + q] = m + __logf(lsum);
 }
 
 // ------------------------------------------------------------------------------------------------------------
