@@ -8,17 +8,11 @@
 // All products run on v_mfma_f32_16x16x32_f16.  Operand convention used throughout: for a row-major matrix R[idx][k]
 // (k contiguous) lane l loads R[i0 + (l&15)][k0 + 8*(l>>4) .. +7] -- this is the A fragment when idx is the output row
 // and the B fragment when idx is the output column.  The accumulator holds C[row=(l>>4)*4+r][col=l&15].
-// Probabilities / dS go through a per-wave LDS tile to turn that accumulator layout back into an operand; operands
-// that are contracted over their row index (V, K, Q^T, dA^T) are staged into LDS transposed.
+// Probabilities / dS never leave the registers: the score products are oriented so that the accumulator (4 consecutive
+// rows of one column per lane) is already a piece of the next product's B operand; operands contracted over their row
+// index (V, K, Q, dA as "transposed" A operands) are read from the row-major LDS tiles with ds_read_b64_tr_b16.
 // qkv layout (legacy order): token row of 3C halfs, head h at [h*3d, (h+1)*3d): q | k | v.
 #include "attention.h"
-
-#define TS 72   // row stride (halfs) of 64-wide LDS tiles: 144 B rows -> conflict-free 16-byte fragment reads
-
-template <int D>
-struct Tiles {
-  static constexpr int RS = D + 8;          // row stride of [64][D] row-major tiles
-};
 
 __device__ __forceinline__ half8 ld_frag(const half_t* tile, int stride, int i0, int k0, int lane) {
   return *reinterpret_cast<const half8*>(tile + (i0 + (lane & 15)) * stride + k0 + 8 * (lane >> 4));
@@ -38,20 +32,16 @@ __device__ __forceinline__ void load_tile(const half_t* __restrict__ src, int ld
     if (c < 64 * CPR) t.v[i] = *reinterpret_cast<const half8*>(src + (long long)(c / CPR) * ld + (c % CPR) * 8);
   }
 }
-// registers -> LDS, row-major and/or transposed
-template <int D, bool ROWS, bool TRANS, int RSTRIDE = D + 8>
-__device__ __forceinline__ void store_tile(const TileRegs<D>& t, half_t* rows, half_t* trans, int tid) {
+// registers -> LDS, row-major (16-byte writes)
+template <int D, int RSTRIDE = D + 8>
+__device__ __forceinline__ void store_tile(const TileRegs<D>& t, half_t* rows, int tid) {
   constexpr int CPR = D / 8;
 #pragma unroll
   for (int i = 0; i < (64 * CPR + 255) / 256; ++i) {
     const int c = tid + i * 256;
     if (c < 64 * CPR) {
       const int r = c / CPR, ch = c % CPR;
-      if (ROWS) *reinterpret_cast<half8*>(rows + r * RSTRIDE + ch * 8) = t.v[i];
-      if (TRANS) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) trans[(ch * 8 + e) * TS + r] = t.v[i][e];
-      }
+      *reinterpret_cast<half8*>(rows + r * RSTRIDE + ch * 8) = t.v[i];
     }
   }
 }
@@ -62,17 +52,6 @@ __device__ __forceinline__ void store_tile(const TileRegs<D>& t, half_t* rows, h
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 __device__ __forceinline__ half4 lds_read_tr4(const half_t* p) {
   return __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
-}
-
-__device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
-  return v;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -106,8 +85,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   load_tile<D>(base + 2 * D, ld, rv, tid);
   for (int kt = 0; kt < a.T; kt += 64) {
     __syncthreads();
-    store_tile<D, true, false>(rk, sK, nullptr, tid);
-    store_tile<D, true, false, VS>(rv, sV, nullptr, tid);
+    store_tile<D>(rk, sK, tid);
+    store_tile<D, VS>(rv, sV, tid);
     if (kt + 64 < a.T) {
       load_tile<D>(base + (long long)(kt + 64) * ld + D, ld, rk, tid);
       load_tile<D>(base + (long long)(kt + 64) * ld + 2 * D, ld, rv, tid);
@@ -169,127 +148,130 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------------------
 // dQ[q][:] = sum_key dS[q][key] K[key][:],  dS = alpha * P * (dP - D_q),  dP = dA V^T.   Also writes D_q.
+// Same transposed arrangement as the forward: S^T = K Q^T and dP^T = V dA^T put one query in a lane (lse and D_q are
+// per-lane scalars), dS^T is packed in registers as the B operand of dQ^T = K^T dS^T, and K^T comes from the row-major
+// K tile through the transposed LDS read.  Nothing is staged transposed and nothing round-trips through LDS.
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
   __shared__ __attribute__((aligned(16))) half_t sK[64 * RS];
-  __shared__ __attribute__((aligned(16))) half_t sKt[D * TS];
   __shared__ __attribute__((aligned(16))) half_t sV[64 * RS];
-  __shared__ __attribute__((aligned(16))) half_t sS[4][16 * TS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
   const int ld = 3 * a.C;
+  const int g = lane >> 4, col = lane & 15;
   const half_t* base = a.qkv + (long long)n * a.T * ld + h * 3 * D;
   const long long bh = (long long)n * a.heads + h;
+  const int q = q0 + wave * 16 + col;        // this lane's query
   half8 qf[KK], daf[KK];
-  float dpart = 0.f;
+  float Dq = 0.f;
   {
-    const long long row = (long long)n * a.T + q0 + wave * 16 + (lane & 15);
+    const long long row = (long long)n * a.T + q;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
-      qf[kk] = *reinterpret_cast<const half8*>(base + (long long)(q0 + wave * 16 + (lane & 15)) * ld + kk * 32 + 8 * (lane >> 4));
-      daf[kk] = *reinterpret_cast<const half8*>(a.dout + row * a.C + h * D + kk * 32 + 8 * (lane >> 4));
-      const half8 av = *reinterpret_cast<const half8*>(a.out + row * a.C + h * D + kk * 32 + 8 * (lane >> 4));
+      qf[kk] = *reinterpret_cast<const half8*>(base + (long long)q * ld + kk * 32 + 8 * g);
+      daf[kk] = *reinterpret_cast<const half8*>(a.dout + row * a.C + h * D + kk * 32 + 8 * g);
+      const half8 av = *reinterpret_cast<const half8*>(a.out + row * a.C + h * D + kk * 32 + 8 * g);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dpart += (float)daf[kk][j] * (float)av[j];
+      for (int j = 0; j < 8; ++j) Dq += (float)daf[kk][j] * (float)av[j];
     }
   }
-  dpart += __shfl_xor(dpart, 16);
-  dpart += __shfl_xor(dpart, 32);            // D of row (lane & 15), in every lane of that column group
-  float Dr[4], lser[4];
+  Dq += __shfl_xor(Dq, 16);
+  Dq += __shfl_xor(Dq, 32);                  // D of query `col`, in all four lanes of the column
+  const float lse = a.lse[bh * a.T + q];
+  if (g == 0) a.Dbuf[bh * a.T + q] = Dq;
+  f32x4 dqt[DS];                             // dQ^T: row d = i*16 + 4g + r, column = this lane's query
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    Dr[r] = __shfl(dpart, (lane >> 4) * 4 + r);
-    lser[r] = a.lse[bh * a.T + q0 + wave * 16 + (lane >> 4) * 4 + r];
-  }
-  if (lane < 16) a.Dbuf[bh * a.T + q0 + wave * 16 + lane] = dpart;
-  f32x4 dq[DS];
-#pragma unroll
-  for (int i = 0; i < DS; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < DS; ++i) dqt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   TileRegs<D> rk, rv;
   load_tile<D>(base + D, ld, rk, tid);
   load_tile<D>(base + 2 * D, ld, rv, tid);
   for (int kt = 0; kt < a.T; kt += 64) {
     __syncthreads();
-    store_tile<D, true, true>(rk, sK, sKt, tid);
-    store_tile<D, true, false>(rv, sV, nullptr, tid);
+    store_tile<D>(rk, sK, tid);
+    store_tile<D>(rv, sV, tid);
     if (kt + 64 < a.T) {
       load_tile<D>(base + (long long)(kt + 64) * ld + D, ld, rk, tid);
       load_tile<D>(base + (long long)(kt + 64) * ld + 2 * D, ld, rv, tid);
     }
     __syncthreads();
+    half8 sb[2];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[kk], ld_frag(sK, RS, sub * 16, kk * 32, lane), s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(daf[kk], ld_frag(sV, RS, sub * 16, kk * 32, lane), dp, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sK, RS, sub * 16, kk * 32, lane), qf[kk], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sV, RS, sub * 16, kk * 32, lane), daf[kk], dp, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __expf(s[r] * a.alpha - lser[r]);
-        sS[wave][((lane >> 4) * 4 + r) * TS + sub * 16 + (lane & 15)] = (half_t)(a.alpha * p * (dp[r] - Dr[r]));
+        const float pv = __expf(st[r] * a.alpha - lse);
+        sb[sub >> 1][(sub & 1) * 4 + r] = (half_t)(a.alpha * pv * (dp[r] - Dq));
       }
     }
-    __syncthreads();
 #pragma unroll
     for (int i = 0; i < DS; ++i)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        dq[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sS[wave], TS, 0, kk * 32, lane),
-                                                       ld_frag(sKt, TS, i * 16, kk * 32, lane), dq[i], 0, 0, 0);
+      for (int pr = 0; pr < 2; ++pr) {
+        const half_t* kb = sK + (4 * g + (col >> 2)) * RS + i * 16 + 4 * (col & 3);
+        const half4 lo = lds_read_tr4(kb + (2 * pr) * 16 * RS);
+        const half4 hi = lds_read_tr4(kb + (2 * pr + 1) * 16 * RS);
+        const half8 ka = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        dqt[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, sb[pr], dqt[i], 0, 0, 0);
+      }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int q = q0 + wave * 16 + (lane >> 4) * 4 + r;
-#pragma unroll
-    for (int i = 0; i < DS; ++i)
-      a.dqkv[((long long)n * a.T + q) * ld + h * 3 * D + i * 16 + (lane & 15)] = (half_t)dq[i][r];
+  for (int i = 0; i < DS; ++i) {
+    const half4 o4 = {(half_t)dqt[i][0], (half_t)dqt[i][1], (half_t)dqt[i][2], (half_t)dqt[i][3]};
+    *reinterpret_cast<half4*>(a.dqkv + ((long long)n * a.T + q) * ld + h * 3 * D + i * 16 + 4 * g) = o4;
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // One workgroup = 64 keys: dV[key][:] = sum_q P[q][key] dA[q][:],  dK[key][:] = sum_q dS[q][key] Q[q][:].
+// Here the scores are produced UN-transposed (S = Q K^T, dP = dA V^T: accumulator row = query, column = key) so a lane
+// owns one key and 16 queries of the tile: P and dS are packed in registers as the B operands of dV^T = dA^T P and
+// dK^T = Q^T dS, whose A operands come from the row-major dA / Q tiles through the transposed LDS read.
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
   __shared__ __attribute__((aligned(16))) half_t sQ[64 * RS];
-  __shared__ __attribute__((aligned(16))) half_t sQt[D * TS];
   __shared__ __attribute__((aligned(16))) half_t sA[64 * RS];
-  __shared__ __attribute__((aligned(16))) half_t sAt[D * TS];
-  __shared__ __attribute__((aligned(16))) half_t sPT[4][16 * TS];
-  __shared__ __attribute__((aligned(16))) half_t sST[4][16 * TS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
   const int ld = 3 * a.C;
+  const int g = lane >> 4, col = lane & 15;
   const half_t* base = a.qkv + (long long)n * a.T * ld + h * 3 * D;
   const long long bh = (long long)n * a.heads + h;
+  const int key = k0 + wave * 16 + col;      // this lane's key
   half8 kf[KK], vf[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
-    const half_t* row = base + (long long)(k0 + wave * 16 + (lane & 15)) * ld + kk * 32 + 8 * (lane >> 4);
+    const half_t* row = base + (long long)key * ld + kk * 32 + 8 * g;
     kf[kk] = *reinterpret_cast<const half8*>(row + D);
     vf[kk] = *reinterpret_cast<const half8*>(row + 2 * D);
   }
-  f32x4 dk[DS], dv[DS];
+  f32x4 dkt[DS], dvt[DS];                    // dK^T / dV^T: row d = i*16 + 4g + r, column = this lane's key
 #pragma unroll
-  for (int i = 0; i < DS; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < DS; ++i) { dkt[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvt[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   TileRegs<D> rq, ra;
-  float lse_n[4], dq_n[4];                  // per-query lse and D of the tile being prefetched (this lane's 4 columns)
+  f32x4 lse_n[4], dq_n[4];                   // lse / D of the prefetched tile's queries sub*16 + 4g + (0..3)
   const half_t* abase = a.dout + (long long)n * a.T * a.C + h * D;
+  const float* lsep = a.lse + bh * a.T + 4 * g;
+  const float* dqp = a.Dbuf + bh * a.T + 4 * g;
   load_tile<D>(base, ld, rq, tid);
   load_tile<D>(abase, a.C, ra, tid);
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub) {
-    lse_n[sub] = a.lse[bh * a.T + sub * 16 + (lane & 15)];
-    dq_n[sub] = a.Dbuf[bh * a.T + sub * 16 + (lane & 15)];
+    lse_n[sub] = *reinterpret_cast<const f32x4*>(lsep + sub * 16);
+    dq_n[sub] = *reinterpret_cast<const f32x4*>(dqp + sub * 16);
   }
   for (int qt = 0; qt < a.T; qt += 64) {
     __syncthreads();
-    store_tile<D, true, true>(rq, sQ, sQt, tid);
-    store_tile<D, true, true>(ra, sA, sAt, tid);
-    float lse_c[4], dq_c[4];
+    store_tile<D>(rq, sQ, tid);
+    store_tile<D>(ra, sA, tid);
+    f32x4 lse_c[4], dq_c[4];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) { lse_c[sub] = lse_n[sub]; dq_c[sub] = dq_n[sub]; }
     if (qt + 64 < a.T) {
@@ -297,48 +279,47 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
       load_tile<D>(abase + (long long)(qt + 64) * a.C, a.C, ra, tid);
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
-        lse_n[sub] = a.lse[bh * a.T + qt + 64 + sub * 16 + (lane & 15)];
-        dq_n[sub] = a.Dbuf[bh * a.T + qt + 64 + sub * 16 + (lane & 15)];
+        lse_n[sub] = *reinterpret_cast<const f32x4*>(lsep + qt + 64 + sub * 16);
+        dq_n[sub] = *reinterpret_cast<const f32x4*>(dqp + qt + 64 + sub * 16);
       }
     }
     __syncthreads();
+    half8 pb[2], sb[2];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
-      f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kk], ld_frag(sQ, RS, sub * 16, kk * 32, lane), st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[kk], ld_frag(sA, RS, sub * 16, kk * 32, lane), dp, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sQ, RS, sub * 16, kk * 32, lane), kf[kk], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sA, RS, sub * 16, kk * 32, lane), vf[kk], dp, 0, 0, 0);
       }
-      const float lse = lse_c[sub], Dq = dq_c[sub];        // this lane's column q = qt + sub*16 + (lane & 15)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __expf(st[r] * a.alpha - lse);
-        const int o = ((lane >> 4) * 4 + r) * TS + sub * 16 + (lane & 15);
-        sPT[wave][o] = (half_t)p;
-        sST[wave][o] = (half_t)(a.alpha * p * (dp[r] - Dq));
+        const float pv = __expf(sc[r] * a.alpha - lse_c[sub][r]);
+        pb[sub >> 1][(sub & 1) * 4 + r] = (half_t)pv;
+        sb[sub >> 1][(sub & 1) * 4 + r] = (half_t)(a.alpha * pv * (dp[r] - dq_c[sub][r]));
       }
     }
-    __syncthreads();
 #pragma unroll
     for (int i = 0; i < DS; ++i)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sPT[wave], TS, 0, kk * 32, lane),
-                                                       ld_frag(sAt, TS, i * 16, kk * 32, lane), dv[i], 0, 0, 0);
-        dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sST[wave], TS, 0, kk * 32, lane),
-                                                       ld_frag(sQt, TS, i * 16, kk * 32, lane), dk[i], 0, 0, 0);
+      for (int pr = 0; pr < 2; ++pr) {
+        const int off = (4 * g + (col >> 2)) * RS + i * 16 + 4 * (col & 3);
+        const half4 alo = lds_read_tr4(sA + off + (2 * pr) * 16 * RS), ahi = lds_read_tr4(sA + off + (2 * pr + 1) * 16 * RS);
+        const half4 qlo = lds_read_tr4(sQ + off + (2 * pr) * 16 * RS), qhi = lds_read_tr4(sQ + off + (2 * pr + 1) * 16 * RS);
+        const half8 aa = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+        const half8 qa = {qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+        dvt[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aa, pb[pr], dvt[i], 0, 0, 0);
+        dkt[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, sb[pr], dkt[i], 0, 0, 0);
       }
   }
+  half_t* row = a.dqkv + ((long long)n * a.T + key) * ld + h * 3 * D;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int key = k0 + wave * 16 + (lane >> 4) * 4 + r;
-    half_t* row = a.dqkv + ((long long)n * a.T + key) * ld + h * 3 * D;
-#pragma unroll
-    for (int i = 0; i < DS; ++i) {
-      row[D + i * 16 + (lane & 15)] = (half_t)dk[i][r];
-      row[2 * D + i * 16 + (lane & 15)] = (half_t)dv[i][r];
-    }
+  for (int i = 0; i < DS; ++i) {
+    const half4 k4 = {(half_t)dkt[i][0], (half_t)dkt[i][1], (half_t)dkt[i][2], (half_t)dkt[i][3]};
+    const half4 v4 = {(half_t)dvt[i][0], (half_t)dvt[i][1], (half_t)dvt[i][2], (half_t)dvt[i][3]};
+    *reinterpret_cast<half4*>(row + D + i * 16 + 4 * g) = k4;
+    *reinterpret_cast<half4*>(row + 2 * D + i * 16 + 4 * g) = v4;
   }
 }
 
