@@ -51,6 +51,20 @@ static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; 
 // ---------------------------------------------------------------------------------------
 enum { IG_OUT_F16 = 0, IG_OUT_F32 = 1, IG_OUT_NCHW_F32 = 2 };
 
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: four v_add_f32 with DPP operands
+// (quad swaps, half-row mirror, row mirror) instead of four ds_bpermute round trips through the LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_move<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);    // row_half_mirror
+  v += dpp_move<0x140>(v);    // row_mirror
+  return v;
+}
+
 struct IgemmArgs {
   const half_t* X = nullptr;   // activations
   const half_t* Wt = nullptr;  // [Npad][K] (K contiguous), rows >= N are zero

@@ -104,10 +104,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        float s = ssum[i][c], q = ssq[i][c];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-        ssum[i][c] = s; ssq[i][c] = q;
+        ssum[i][c] = row16_sum(ssum[i][c]);
+        ssq[i][c] = row16_sum(ssq[i][c]);
       }
     __syncthreads();                       // the K-loop's LDS tiles are dead from here on
     if (active && (lane & 15) == 0) {

@@ -12,6 +12,7 @@ int main(int argc, char** argv) {
   int H = argc > 1 ? atoi(argv[1]) : 128, Cin = argc > 2 ? atoi(argv[2]) : 256, Cout = argc > 3 ? atoi(argv[3]) : 256;
   int big = argc > 4 ? atoi(argv[4]) : 1, ksplit = argc > 5 ? atoi(argv[5]) : 1, gen = argc > 6 ? atoi(argv[6]) : 2;
   int ksize = argc > 7 ? atoi(argv[7]) : 3;
+  int stats = argc > 8 ? atoi(argv[8]) : 0;      // 1: accumulate the per-channel GroupNorm statistics in the epilogue
   int M = H * H, K = ksize * ksize * Cin;
   half_t *X, *W, *O; float* ws;
   hipMalloc(&X, (size_t)M * Cin * 2); hipMalloc(&W, (size_t)((Cout + 127) / 128 * 128) * K * 2); hipMalloc(&O, (size_t)M * Cout * 2);
@@ -24,6 +25,8 @@ int main(int argc, char** argv) {
   IgemmArgs a;
   a.X = X; a.Wt = W; a.out = O; a.M = M; a.N = Cout; a.K = K; a.conv3 = ksize == 3; a.Cin = Cin; a.ldx = Cin; a.ldw = K; a.ldo = Cout;
   a.H = H; a.W = H; a.ksplit = ksplit; a.ws = ws;
+  long long* st = nullptr;
+  if (stats) { hipMalloc(&st, (size_t)Cout * 2 * 8); hipMemset(st, 0, (size_t)Cout * 2 * 8); a.stat_out = st; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto run = [&]() { if (gen == 3 && igemm3_applicable(a, big)) igemm3_launch_main(a, big, 0); else igemm2_launch_main(a, big, 0); };
   for (int i = 0; i < 5; ++i) run();
@@ -35,6 +38,6 @@ int main(int argc, char** argv) {
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   double us = ms * 1e3 / it, tf = 2.0 * M * Cout * K / (us * 1e-6) / 1e12;
-  printf("gen%d H=%d Cin=%d Cout=%d big=%d ksplit=%d : %.2f us  %.1f TFLOP/s\n", gen, H, Cin, Cout, big, ksplit, us, tf);
+  printf("gen%d H=%d Cin=%d Cout=%d big=%d ksplit=%d stats=%d : %.2f us  %.1f TFLOP/s\n", gen, H, Cin, Cout, big, ksplit, stats, us, tf);
   return 0;
 }
