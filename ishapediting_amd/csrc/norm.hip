@@ -147,25 +147,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
     __syncthreads();
     stats = sh_stats;
   }
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int cv = (int)(idx % CV);
-    const long long pix = idx / CV;
+  // The launcher makes the thread count a multiple of CV, so a thread keeps ONE 8-channel vector for all its pixels:
+  // gamma/beta are loaded once, the per-image values (mean, rstd, FiLM) only when the image changes.
+  const long long tg = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nth = (long long)gridDim.x * blockDim.x;
+  const int cv = (int)(tg % CV), c0 = cv * 8;
+  const long long pstep = nth / CV, npix = (long long)a.N * HWo;
+  float gam[8], bet[8], mu[8], rs[8], sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { gam[i] = a.gamma[c0 + i]; bet[i] = a.beta[c0 + i]; }
+  int cur_n = -1;
+  for (long long pix = tg / CV; pix < npix; pix += pstep) {
     const int n = (int)(pix / HWo);
     const int p = (int)(pix % HWo);
-    const int c0 = cv * 8;
-    float gam[8], bet[8], mu[8], rs[8], sc[8], sh[8];
+    if (n != cur_n) {
+      cur_n = n;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int c = c0 + i;
-      int g = c / cpg;
-      gam[i] = a.gamma[c];
-      bet[i] = a.beta[c];
-      mu[i] = stats[(n * 32 + g) * 2];
-      rs[i] = stats[(n * 32 + g) * 2 + 1];
-      if (FILM) {
-        sc[i] = rh(1.f + rh(a.emb[(long long)n * a.emb_ld + c]));
-        sh[i] = rh(a.emb[(long long)n * a.emb_ld + a.C + c]);
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i, g = c / cpg;
+        mu[i] = stats[(n * 32 + g) * 2];
+        rs[i] = stats[(n * 32 + g) * 2 + 1];
+        if (FILM) {
+          sc[i] = rh(1.f + rh(a.emb[(long long)n * a.emb_ld + c]));
+          sh[i] = rh(a.emb[(long long)n * a.emb_ld + a.C + c]);
+        }
       }
     }
     auto one = [&](const half8& v, float* o) {
@@ -225,6 +230,12 @@ int gn_apply_launch(const GnApplyArgs& a, hipStream_t s) {
   long long total = (long long)a.N * HWo * (a.C / 8);
   int blocks = (int)((total + 255) / 256);
   if (blocks > (a.sums ? 1024 : 4096)) blocks = a.sums ? 1024 : 4096;   // fewer, fatter blocks amortise the finalise prologue
+  // thread count = multiple of CV (a thread owns one 8-channel vector): blocks = multiple of CV / gcd(CV, 256)
+  const int CV = a.C / 8;
+  int gcd = CV, r256 = 256;
+  while (r256) { const int t = gcd % r256; gcd = r256; r256 = t; }
+  const int unit = CV / gcd;
+  blocks = blocks < unit ? unit : blocks / unit * unit;
   dim3 g(blocks), b(256);
   if (a.split) hipLaunchKernelGGL((gn_apply_kernel<false, true, false, true>), g, b, 0, s, a);
   else if (a.pool) hipLaunchKernelGGL((gn_apply_kernel<false, true, true, false>), g, b, 0, s, a);

@@ -107,22 +107,40 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
     }
     __syncthreads();
   }
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int cv = (int)(idx % CV);
-    const long long pix = idx / CV;
+  // thread count is a multiple of CV (launcher): one 8-channel vector per thread, parameters loaded once per image
+  const long long tg = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nth = (long long)gridDim.x * blockDim.x;
+  const int cv = (int)(tg % CV), c0 = cv * 8;
+  const long long pstep = nth / CV, npix = (long long)a.N * HW;
+  float gam[8], bet[8], mu[8], rs[8], esc[8], esh[8], m1[8], m2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { gam[i] = a.gamma[c0 + i]; bet[i] = (FILM || ACT) ? a.beta[c0 + i] : 0.f; esc[i] = 0.f; esh[i] = 0.f; }
+  int cur_n = -1;
+  for (long long pix = tg / CV; pix < npix; pix += pstep) {
     const int n = (int)(pix / HW), p = (int)(pix % HW);
-    const int y = p / a.W, x = p % a.W, c0 = cv * 8;
-    float dyh[8], xh[8], ad[8];
-    bwd_terms<FILM, ACT>(a, n, y, x, c0, dyh, xh);
+    const int y = p / a.W, x = p % a.W;
+    if (n != cur_n) {
+      cur_n = n;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i, g = c / cpg;
+        mu[i] = a.stats[(n * 32 + g) * 2];
+        rs[i] = a.stats[(n * 32 + g) * 2 + 1];
+        m1[i] = sh_m[(n * 32 + g) * 2];
+        m2[i] = sh_m[(n * 32 + g) * 2 + 1];
+        if (FILM) { esc[i] = a.emb[(long long)n * a.emb_ld + c]; esh[i] = a.emb[(long long)n * a.emb_ld + a.C + c]; }
+      }
+    }
+    float up[8], ad[8];
+    load_upstream(a.g, a.gmode, n, y, x, a.H, a.W, a.C, c0, up);
+    const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.C + c0);
     if (a.add) load_upstream(a.add, a.gmode, n, y, x, a.H, a.W, a.C, c0, ad);
     half8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int g = (c0 + i) / cpg;
-      const float rs = a.stats[(n * 32 + g) * 2 + 1];
-      const float m1 = sh_m[(n * 32 + g) * 2], m2 = sh_m[(n * 32 + g) * 2 + 1];
-      float v = rs * (dyh[i] - m1 - xh[i] * m2);
+      float dyh, xh;
+      gn_bwd_term(up[i], (float)xv[i], mu[i], rs[i], gam[i], bet[i], esc[i], esh[i], FILM, ACT, dyh, xh);
+      float v = rs[i] * (dyh - m1[i] - xh * m2[i]);
       if (a.add) v += ad[i];
       o[i] = (half_t)v;
     }
@@ -139,6 +157,10 @@ int gn_backward_launch(const GnBwdArgs& a, hipStream_t s) {
   long long total = (long long)a.N * HW * CV;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 1024) blocks = 1024;
+  int gcd = CV, r256 = 256;                      // apply kernel: thread count = multiple of CV
+  while (r256) { const int t = gcd % r256; gcd = r256; r256 = t; }
+  const int unit = CV / gcd;
+  blocks = blocks < unit ? unit : blocks / unit * unit;
 #define GB_LAUNCH(F, A)                                                                                             \
   do {                                                                                                              \
     if (!a.sums_ready)                                                                                              \
