@@ -168,8 +168,19 @@ def main():
         v = max(range(4), key=lambda i: out[i * 3 + 1])
         launches, ms, flops = out[v * 3], out[v * 3 + 1], out[v * 3 + 2]
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # HBM-side bytes per launch of that kernel from the committed PMC passes (profiles/pmc_traffic.json, produced by
+        # tools/pmc_only.sh + tools/pmc_summary.py: counters cannot be collected from inside this process)
+        traffic = None
+        rocprof_name = ["void igemm2_kernel<128, 128, 4, true>", "void igemm2_kernel<64, 64, 4, true>",
+                        "void igemm2_kernel<128, 128, 4, false>", "void igemm2_kernel<64, 64, 4, false>"][v]
+        try:
+            k = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"][rocprof_name]
+            traffic = k["FETCH_SIZE"]["bytes_per_launch"] + k["WRITE_SIZE"]["bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": None, "kernel": names[v],
+                    "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": traffic, "kernel": names[v],
+                    "rocprof_kernel": rocprof_name,
                     "launches_per_edit": int(launches), "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
                     "flops_per_launch_avg": flops / max(launches, 1),
                     "share_of_edit_time": round(ms * 1e-3 / sec_per_shape / max(world, 1), 3) if world == 1 else None,

@@ -1,6 +1,7 @@
 // Shared declarations for libishap_hip.so (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 
@@ -99,6 +100,9 @@ struct IgemmArgs {
   int gb_film = 0, gb_act = 0;
   long long* gb_csums = nullptr;
 };
+// set (non-null) by igemm.hip around a launch while ishap_profile_begin/end is active: the kernel launchers then attach
+// these events to the dispatch itself (hipExtLaunchKernelGGL), so their elapsed time is the kernel's own duration
+extern hipEvent_t g_igemm_prof_start, g_igemm_prof_stop;
 int igemm_launch(const IgemmArgs& a, hipStream_t s);
 // picks a split so the grid fills the chip; returns workspace floats needed
 int igemm_pick_ksplit(int M, int N, int K, int nbatch);

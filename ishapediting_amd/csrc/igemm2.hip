@@ -229,7 +229,8 @@ static int launch2(const IgemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
-  hipLaunchKernelGGL(kern, grid, dim3(256 + 64 * IG2_LOADERS), smem, s, a);
+  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(256 + 64 * IG2_LOADERS), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a);
+  else hipLaunchKernelGGL(kern, grid, dim3(256 + 64 * IG2_LOADERS), smem, s, a);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -173,7 +173,8 @@ static int launch3(const IgemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.ksplit);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(256), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a);
+  else hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

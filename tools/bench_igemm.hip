@@ -6,6 +6,7 @@
 #include <vector>
 #include "../ishapediting_amd/csrc/igemm2.hip"
 #include "../ishapediting_amd/csrc/igemm3.hip"
+hipEvent_t g_igemm_prof_start = nullptr, g_igemm_prof_stop = nullptr;
 void ishap_set_error(const std::string& m) { fprintf(stderr, "ERR %s\n", m.c_str()); }
 
 int main(int argc, char** argv) {

@@ -1,0 +1,15 @@
+#!/bin/bash
+# One GPU call producing the round's measurement artefacts under gpurun_out/final/ (copy into profiles/ afterwards).
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/final
+mkdir -p $O
+cd $R
+timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
+tail -c 400 $O/bench.json
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --shape-profile $O/shapes.csv > $O/trace_bench.json 2> $O/trace.err || exit 1
+f=$(find $O/trace -name "*kernel_trace.csv"); python3 $R/tools/trace_by_grid.py $f > $O/kernel_by_grid.txt; rm -f $f
+cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
+echo trace done
+rm -rf $O/trace
