@@ -120,7 +120,9 @@ typedef struct {
   int l1;               /* loss_type == 'l1' */
   unsigned char* touched; /* device scratch [3*W*W] */
   int* nmask;             /* device scratch [1] */
-  float* acc;             /* device scratch [2] */
+  void* acc;              /* device scratch, 16 bytes (two 64-bit fixed-point loss sums) */
+  void* grad_fx;          /* device scratch, W*W*ld*8 bytes: the gradient scatter accumulates in 64-bit fixed point so
+                           * that repeated edits are bitwise identical (integer atomics commute) */
 } ishap_drag_args;
 /* once per edit: rounded-texel bitmap and complement count (drag_utils.py:322-334) */
 int ishap_drag_setup(const ishap_drag_args* a, void* stream);

@@ -31,7 +31,7 @@ class StepCoefs(C.Structure):
 class DragArgsC(C.Structure):
     _fields_ = [("W", C.c_int), ("ld", C.c_int), ("Cc", C.c_int), ("chmap", c_void_p), ("sources", c_void_p),
                 ("targets", c_void_p), ("B", C.c_int), ("r", C.c_int), ("voxel", C.c_float), ("cof", C.c_float),
-                ("l1", C.c_int), ("touched", c_void_p), ("nmask", c_void_p), ("acc", c_void_p)]
+                ("l1", C.c_int), ("touched", c_void_p), ("nmask", c_void_p), ("acc", c_void_p), ("grad_fx", c_void_p)]
 
 
 class DecoderWeightsC(C.Structure):

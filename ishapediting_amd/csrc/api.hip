@@ -39,11 +39,11 @@ int ishap_axpby(const float* x, const float* y, float a, float b, long long nume
 }
 
 static int fill_drag(const ishap_drag_args* a, DragArgs& d) {
-  ISHAP_REQUIRE(a && a->chmap && a->sources && a->targets && a->touched && a->nmask && a->acc, "null argument");
+  ISHAP_REQUIRE(a && a->chmap && a->sources && a->targets && a->touched && a->nmask && a->acc && a->grad_fx, "null argument");
   ISHAP_REQUIRE(a->W > 1 && a->B >= 1 && a->r >= 0 && a->Cc >= 1 && a->ld >= 1, "drag dims");
   d.W = a->W; d.ld = a->ld; d.Cc = a->Cc; d.chmap = a->chmap; d.sources = a->sources; d.targets = a->targets;
   d.B = a->B; d.r = a->r; d.voxel = a->voxel; d.cof = a->cof; d.l1 = a->l1;
-  d.touched = a->touched; d.nmask = a->nmask; d.acc = a->acc;
+  d.touched = a->touched; d.nmask = a->nmask; d.acc = (long long*)a->acc; d.gfx = (long long*)a->grad_fx;
   return 0;
 }
 

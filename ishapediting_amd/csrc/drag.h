@@ -16,9 +16,13 @@ struct DragArgs {
   unsigned char* touched = nullptr;  // [3][W][W]
   int* nmask = nullptr;              // [1]
   float* grad = nullptr;             // fp32 [W*W][ld] (d loss / d tap)
-  float* acc = nullptr;              // [2] scratch sums
+  long long* gfx = nullptr;          // scratch [W*W][ld]: the scatter accumulates here in 64-bit fixed point (DRAG_FX_SCALE)
+  long long* acc = nullptr;          // [2] loss sums, 64-bit fixed point (DRAG_ACC_SCALE)
   float* loss = nullptr;             // [1]
 };
+// Integer atomics commute, so the scattered gradient and the loss are bitwise reproducible (fp32 atomics are not).
+constexpr float DRAG_FX_SCALE = 17592186044416.f;    // 2^44: |sum| < 5e5, resolution 6e-14
+constexpr float DRAG_ACC_SCALE = 16777216.f;         // 2^24
 int drag_setup_launch(const DragArgs& a, hipStream_t s);        // touched bitmap + mask count (once per edit)
 int drag_loss_grad_launch(const DragArgs& a, hipStream_t s);
 int grad_to_scaled_f16_launch(const float* g, half_t* o, unsigned* bits, float* scale2, long long n, hipStream_t s);

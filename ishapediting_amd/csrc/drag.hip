@@ -32,12 +32,15 @@ __device__ __forceinline__ Bilin bilin_setup(float u, float v, int W) {
 
 // workgroup sum of the per-lane loss terms, then ONE atomic on the accumulator (thousands of same-address atomics
 // -- one per wave -- were the whole run time of these kernels)
-__device__ __forceinline__ void block_loss_add(float lsum, float* dst) {
+__device__ __forceinline__ void fx_add(long long* dst, float v, float scale) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__float2ll_rn(v * scale));
+}
+__device__ __forceinline__ void block_loss_add(float lsum, long long* dst) {
   __shared__ float red[4];
   for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(dst, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) fx_add(dst, red[0] + red[1] + red[2] + red[3], DRAG_ACC_SCALE);
 }
 
 __global__ __launch_bounds__(256) void drag_motion_kernel(DragArgs a) {
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void drag_motion_kernel(DragArgs a) {
     for (int q = 0; q < 4; ++q) {
       int xt = bt.x0 + (q & 1), yt = bt.y0 + (q >> 1);
       if (xt >= 0 && xt < a.W && yt >= 0 && yt < a.W)
-        atomicAdd(a.grad + ((long long)yt * a.W + xt) * a.ld + ch, bt.w[q] * g);
+        fx_add(a.gfx + ((long long)yt * a.W + xt) * a.ld + ch, bt.w[q] * g, DRAG_FX_SCALE);
     }
   }
   }
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void drag_mask_kernel(DragArgs a) {
     float g;
     if (a.l1) { lsum += fabsf(d); g = -a.cof * (float)((d > 0.f) - (d < 0.f)) / denom; }
     else { lsum += d * d; g = -a.cof * 2.f * d / denom; }
-    atomicAdd(a.grad + o, g);   // (plane, c) -> unique ch, but chmap may repeat a channel (nearest resize)
+    fx_add(a.gfx + o, g, DRAG_FX_SCALE);   // (plane, c) -> unique ch, but chmap may repeat a channel (nearest resize)
   }
   }
   block_loss_add(lsum, a.acc + 1);
@@ -141,9 +144,15 @@ __global__ __launch_bounds__(256) void drag_mask_kernel(DragArgs a) {
 __global__ void drag_finish_kernel(DragArgs a) {
   const int side = 2 * a.r + 1;
   const float ntot = 3.f * (float)a.Cc * (float)a.B * (float)side * (float)side * (float)side;
-  float loss = -a.acc[0] / ntot;
-  if (a.cof > 0.f) loss -= a.cof * a.acc[1] / ((float)a.Cc * (float)a.nmask[0]);
+  float loss = -((float)a.acc[0] * (1.f / DRAG_ACC_SCALE)) / ntot;
+  if (a.cof > 0.f) loss -= a.cof * ((float)a.acc[1] * (1.f / DRAG_ACC_SCALE)) / ((float)a.Cc * (float)a.nmask[0]);
   a.loss[0] = loss;
+}
+
+// fixed-point scatter buffer -> the fp32 gradient the ABI returns
+__global__ void drag_grad_out_kernel(const long long* __restrict__ gfx, float* __restrict__ grad, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    grad[i] = (float)gfx[i] * (1.f / DRAG_FX_SCALE);
 }
 
 int drag_setup_launch(const DragArgs& a, hipStream_t s) {
@@ -158,12 +167,14 @@ int drag_setup_launch(const DragArgs& a, hipStream_t s) {
 
 int drag_loss_grad_launch(const DragArgs& a, hipStream_t s) {
   const int side = 2 * a.r + 1;
-  ISHAP_CHECK_HIP(hipMemsetAsync(a.grad, 0, (size_t)a.W * a.W * a.ld * sizeof(float), s));
-  ISHAP_CHECK_HIP(hipMemsetAsync(a.acc, 0, 2 * sizeof(float), s));
+  const long long n = (long long)a.W * a.W * a.ld;
+  ISHAP_CHECK_HIP(hipMemsetAsync(a.gfx, 0, (size_t)n * sizeof(long long), s));
+  ISHAP_CHECK_HIP(hipMemsetAsync(a.acc, 0, 2 * sizeof(long long), s));
   int npos = 3 * a.B * side * side;
   hipLaunchKernelGGL(drag_motion_kernel, dim3(min(ceil_div(npos * 64, 256), 1024)), dim3(256), 0, s, a);
   if (a.cof > 0.f) hipLaunchKernelGGL(drag_mask_kernel, dim3(min(ceil_div(3 * a.W * a.W * 64, 256), 1024)), dim3(256), 0, s, a);
   hipLaunchKernelGGL(drag_finish_kernel, dim3(1), dim3(1), 0, s, a);
+  hipLaunchKernelGGL(drag_grad_out_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0, s, a.gfx, a.grad, n);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -102,7 +102,8 @@ class DragKernels:
         self.Cc = self.chmap.shape[1]
         self.touched = th.zeros(3 * W * W, dtype=th.uint8, device=self.device)
         self.nmask = th.zeros(1, dtype=th.int32, device=self.device)
-        self.acc = th.zeros(2, dtype=th.float32, device=self.device)
+        self.acc = th.zeros(2, dtype=th.int64, device=self.device)
+        self.gfx = th.zeros(W * W * ld, dtype=th.int64, device=self.device)     # fixed-point scatter scratch
         self.grad = th.empty((W * W, ld), dtype=th.float32, device=self.device)
         self.loss = th.zeros(1, dtype=th.float32, device=self.device)
         self.cot = th.empty((W * W, ld), dtype=th.float16, device=self.device)
@@ -115,7 +116,7 @@ class DragKernels:
     def _args(self) -> _lib.DragArgsC:
         return _lib.DragArgsC(self.W, self.ld, self.Cc, self.chmap.data_ptr(), self.sources.data_ptr(),
                               self.targets.data_ptr(), self.sources.shape[0], self.r, self.voxel, float(self.cof),
-                              self.l1, self.touched.data_ptr(), self.nmask.data_ptr(), self.acc.data_ptr())
+                              self.l1, self.touched.data_ptr(), self.nmask.data_ptr(), self.acc.data_ptr(), self.gfx.data_ptr())
 
     def setup(self, sources, targets, cof: float):
         def pts(v):
