@@ -169,6 +169,24 @@ int ishap_x0_grad_to_cotangent(const float* dplanes, const float* range, const f
                                float sqrt_recip, float sqrt_recipm1, int clip_denoised, int S, float* g_direct,
                                float* cot_out, void* stream);
 
+/* ------------------------------------------------------------------ surface of the decoded volume
+ * Replaces the third-party CPU calls after the decode: mcubes.marching_cubes(volume, 0) (visualize.py:100),
+ * mesh.filter_smooth_simple(10) (drag_utils.py:300) and the nearest-neighbour part of meshProcess.py:18-35.
+ * The surface is extracted with marching tetrahedra (6 per cell, shared vertices on grid edges at the linear zero
+ * crossing, grid coordinates, deterministic voxel order).  volume: device float[res^3], x slowest.
+ * Two calls because the caller allocates the outputs: count -> read counts -> emit. */
+long long ishap_surface_scratch_bytes(int res);
+/* counts: device unsigned[2] = {vertices, triangles} */
+int ishap_surface_count(const float* volume, int res, float level, void* scratch, unsigned* counts, void* stream);
+/* verts: device float[3*vertices]; tris: device int[3*triangles]; same volume / level / scratch as the count call */
+int ishap_surface_emit(const float* volume, int res, float level, void* scratch, float* verts, int* tris, void* stream);
+/* in place: v <- (v + sum of neighbours) / (1 + number of neighbours), `iterations` Jacobi sweeps; scratch: 28*nverts bytes */
+int ishap_mesh_smooth(float* verts, long long nverts, const int* tris, long long ntris, int iterations, void* scratch,
+                      void* stream);
+/* out2[0] = mean over a of min_b |a-b|^2, out2[1] = mean over b of min_a |a-b|^2 (device floats; their sum is the
+ * reference's chamfer distance); nearest: device scratch float[max(na, nb)] */
+int ishap_chamfer(const float* a, long long na, const float* b, long long nb, float* nearest, float* out2, void* stream);
+
 /* ------------------------------------------------------------------ measurement aid (bench.py roofline leg)
  * Brackets every implicit-GEMM launch with HIP events on its own stream between begin and end.
  * out[v*3+{0,1,2}] = {launches, total ms, algorithmic FLOPs}; v: 0 conv3x3 128^2 tile, 1 conv3x3 64^2 tile,

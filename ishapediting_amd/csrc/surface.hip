@@ -1,0 +1,365 @@
+// Level-set surface of the decoded occupancy volume, on the device.
+// Reference: triplane_decoder/visualize.py:100-104 (PyMCubes marching cubes at level 0, third-party, absent here),
+// drag_utils.py:300 (Open3D filter_smooth_simple, 10 iterations), meshProcess.py:18-35 (Chamfer distance).
+// PyMCubes' triangulation tables are not reproduced; the surface is extracted with MARCHING TETRAHEDRA: every grid cell
+// is cut into the 6 tetrahedra around its main diagonal, each tetrahedron emits 0/1/2 triangles (16-case table).  The
+// vertex SET is the one marching cubes produces on the 12 cube edges plus the crossings on face / body diagonals; every
+// vertex sits on a grid edge at the linear zero crossing, is owned by the edge's lower end point, and is shared by all
+// the triangles around it (indexed mesh, watertight inside the volume).
+// Pipeline (HBM-bound scans over res^3 voxels, deterministic output order = voxel order):
+//   count : per voxel, the 7 owned edges (+x, +y, +xy, +z, +xz, +yz, +xyz) that cross the level -> bit mask; per cell, the
+//           number of triangles; per-block sums          -> one-block exclusive scan of the block sums
+//   emit  : vertices (block-local scan + block offset), per-voxel vertex offsets, then triangles through the
+//           (owner voxel, edge type) -> vertex index lookup.
+#include "common.h"
+
+namespace {
+
+constexpr int SB_THREADS = 256;
+constexpr int SB_ITEMS = 8;                       // voxels per thread
+constexpr int SB_TILE = SB_THREADS * SB_ITEMS;    // voxels per workgroup
+
+// cube corner i = (i & 1, (i >> 1) & 1, (i >> 2) & 1) -> (dx, dy, dz); the 6 tetrahedra share the diagonal 0-7
+__constant__ unsigned char c_cube_tets[6][4] = {{0, 1, 3, 7}, {0, 3, 2, 7}, {0, 2, 6, 7}, {0, 6, 4, 7}, {0, 4, 5, 7}, {0, 5, 1, 7}};
+__constant__ unsigned char c_tet_edges[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+__constant__ signed char c_tet_tri[16][6] = {{-1, -1, -1, -1, -1, -1}, {1, 0, 2, -1, -1, -1}, {4, 0, 3, -1, -1, -1}, {1, 4, 2, 1, 3, 4},
+                                             {3, 1, 5, -1, -1, -1},   {2, 3, 0, 2, 5, 3},   {1, 4, 0, 1, 5, 4},   {4, 2, 5, -1, -1, -1},
+                                             {4, 5, 2, -1, -1, -1},   {4, 1, 0, 4, 5, 1},   {3, 2, 0, 3, 5, 2},   {1, 3, 5, -1, -1, -1},
+                                             {4, 1, 2, 4, 3, 1},      {3, 0, 4, -1, -1, -1}, {2, 0, 1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1}};
+__constant__ unsigned char c_tet_ntri[16] = {0, 1, 1, 2, 1, 2, 2, 1, 1, 2, 2, 1, 2, 1, 1, 0};
+
+struct SurfArgs {
+  const float* vol;
+  int res;
+  float level;
+  long long n;              // res^3
+  unsigned char* emask;     // [n] crossing owned edges, bit (d-1) for direction bits d = dx | dy<<1 | dz<<2
+  unsigned char* tcnt;      // [n] triangles of the cell whose lower corner is this voxel
+  unsigned* voff;           // [n] index of the voxel's first vertex
+  unsigned* bsum;           // [2][nblocks] per-block (vertices, triangles) -> exclusive prefix after the scan
+  unsigned* counts;         // [2] totals
+  int nblocks;
+};
+
+// inside bits of the 8 corners of the cell at (x, y, z); corners outside the grid read as "same as the voxel itself",
+// which makes their edges non-crossing
+__device__ __forceinline__ unsigned corner_bits(const SurfArgs& a, int x, int y, int z, bool& cell) {
+  const int r = a.res;
+  const long long p = ((long long)x * r + y) * r + z;
+  const bool in0 = a.vol[p] - a.level > 0.f;
+  const bool hx = x + 1 < r, hy = y + 1 < r, hz = z + 1 < r;
+  cell = hx && hy && hz;
+  unsigned bits = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const bool ok = (!(c & 1) || hx) && (!(c & 2) || hy) && (!(c & 4) || hz);
+    bool in = in0;
+    if (ok && c) in = a.vol[p + ((long long)(c & 1) * r + ((c >> 1) & 1)) * r + ((c >> 2) & 1)] - a.level > 0.f;
+    bits |= (in ? 1u : 0u) << c;
+  }
+  return bits;
+}
+
+__device__ __forceinline__ int cell_triangles(unsigned bits) {
+  if (bits == 0u || bits == 255u) return 0;
+  int n = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    unsigned code = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) code |= ((bits >> c_cube_tets[k][i]) & 1u) << i;
+    n += c_tet_ntri[code];
+  }
+  return n;
+}
+
+// workgroup exclusive scan of one value per thread; returns the prefix and leaves the total in *total
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* lds, unsigned* total) {
+  const int t = threadIdx.x;
+  lds[t] = v;
+  __syncthreads();
+  for (int o = 1; o < SB_THREADS; o <<= 1) {
+    unsigned add = t >= o ? lds[t - o] : 0u;
+    __syncthreads();
+    lds[t] += add;
+    __syncthreads();
+  }
+  const unsigned incl = lds[t];
+  *total = lds[SB_THREADS - 1];
+  __syncthreads();
+  return incl - v;
+}
+
+__global__ __launch_bounds__(SB_THREADS) void surf_count_kernel(SurfArgs a) {
+  __shared__ unsigned red[2][SB_THREADS];
+  const int r = a.res;
+  unsigned nv = 0, nt = 0;
+  const long long base = (long long)blockIdx.x * SB_TILE + (long long)threadIdx.x * SB_ITEMS;
+#pragma unroll
+  for (int i = 0; i < SB_ITEMS; ++i) {
+    const long long p = base + i;
+    if (p >= a.n) break;
+    const int z = (int)(p % r), y = (int)((p / r) % r), x = (int)(p / ((long long)r * r));
+    bool cell;
+    const unsigned bits = corner_bits(a, x, y, z, cell);
+    const unsigned in0 = bits & 1u;
+    unsigned m = 0;
+#pragma unroll
+    for (int d = 1; d < 8; ++d) m |= ((((bits >> d) & 1u) ^ in0) & 1u) << (d - 1);   // out-of-grid corners equal in0: never cross
+    const int tc = cell ? cell_triangles(bits) : 0;
+    a.emask[p] = (unsigned char)m;
+    a.tcnt[p] = (unsigned char)tc;
+    nv += __popc(m);
+    nt += tc;
+  }
+  red[0][threadIdx.x] = nv;
+  red[1][threadIdx.x] = nt;
+  __syncthreads();
+  for (int o = SB_THREADS / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { a.bsum[blockIdx.x] = red[0][0]; a.bsum[a.nblocks + blockIdx.x] = red[1][0]; }
+}
+
+// one workgroup: exclusive scan of the per-block sums (both arrays), totals -> counts
+__global__ __launch_bounds__(1024) void surf_scan_blocks_kernel(SurfArgs a) {
+  __shared__ unsigned part[1024];
+  for (int arr = 0; arr < 2; ++arr) {
+    unsigned* s = a.bsum + (long long)arr * a.nblocks;
+    const int per = (a.nblocks + 1023) / 1024;
+    const int b0 = threadIdx.x * per, b1 = min(a.nblocks, b0 + per);
+    unsigned sum = 0;
+    for (int i = b0; i < b1; ++i) sum += s[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      unsigned add = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - sum;
+    if (threadIdx.x == 1023) a.counts[arr] = part[1023];
+    for (int i = b0; i < b1; ++i) { const unsigned v = s[i]; s[i] = run; run += v; }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(SB_THREADS) void surf_emit_vertices_kernel(SurfArgs a, float* __restrict__ verts) {
+  __shared__ unsigned lds[SB_THREADS];
+  const int r = a.res;
+  const long long base = (long long)blockIdx.x * SB_TILE + (long long)threadIdx.x * SB_ITEMS;
+  unsigned cnt = 0;
+  unsigned char m[SB_ITEMS];
+#pragma unroll
+  for (int i = 0; i < SB_ITEMS; ++i) {
+    m[i] = base + i < a.n ? a.emask[base + i] : 0;
+    cnt += __popc((unsigned)m[i]);
+  }
+  unsigned total;
+  unsigned idx = a.bsum[blockIdx.x] + block_exclusive_scan(cnt, lds, &total);
+#pragma unroll
+  for (int i = 0; i < SB_ITEMS; ++i) {
+    const long long p = base + i;
+    if (p >= a.n) break;
+    a.voff[p] = idx;
+    if (!m[i]) continue;
+    const int z = (int)(p % r), y = (int)((p / r) % r), x = (int)(p / ((long long)r * r));
+    const float va = a.vol[p] - a.level;
+#pragma unroll
+    for (int d = 1; d < 8; ++d) {
+      if (!((m[i] >> (d - 1)) & 1)) continue;
+      const int dx = d & 1, dy = (d >> 1) & 1, dz = (d >> 2) & 1;
+      const float vb = a.vol[p + ((long long)dx * r + dy) * r + dz] - a.level;
+      const float t = va / (va - vb);
+      verts[3LL * idx + 0] = (float)x + t * (float)dx;
+      verts[3LL * idx + 1] = (float)y + t * (float)dy;
+      verts[3LL * idx + 2] = (float)z + t * (float)dz;
+      ++idx;
+    }
+  }
+}
+
+__global__ __launch_bounds__(SB_THREADS) void surf_emit_triangles_kernel(SurfArgs a, int* __restrict__ tris) {
+  __shared__ unsigned lds[SB_THREADS];
+  const int r = a.res;
+  const long long base = (long long)blockIdx.x * SB_TILE + (long long)threadIdx.x * SB_ITEMS;
+  unsigned cnt = 0;
+#pragma unroll
+  for (int i = 0; i < SB_ITEMS; ++i) cnt += base + i < a.n ? a.tcnt[base + i] : 0;
+  unsigned total;
+  unsigned idx = a.bsum[a.nblocks + blockIdx.x] + block_exclusive_scan(cnt, lds, &total);
+  for (int i = 0; i < SB_ITEMS; ++i) {
+    const long long p = base + i;
+    if (p >= a.n) break;
+    if (!a.tcnt[p]) continue;
+    const int z = (int)(p % r), y = (int)((p / r) % r), x = (int)(p / ((long long)r * r));
+    bool cell;
+    const unsigned bits = corner_bits(a, x, y, z, cell);
+    for (int k = 0; k < 6; ++k) {
+      unsigned code = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) code |= ((bits >> c_cube_tets[k][j]) & 1u) << j;
+      const int ntri = c_tet_ntri[code];
+      for (int tr = 0; tr < ntri; ++tr) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int e = c_tet_tri[code][3 * tr + c];
+          const unsigned ca = c_cube_tets[k][c_tet_edges[e][0]], cb = c_cube_tets[k][c_tet_edges[e][1]];
+          const unsigned lo = ca & cb, hi = ca | cb;          // the corners of a tetrahedron form a chain: one contains the other
+          const unsigned d = hi ^ lo;                          // direction bits of the edge, 1..7
+          const long long owner = p + ((long long)(lo & 1) * r + ((lo >> 1) & 1)) * r + ((lo >> 2) & 1);
+          const unsigned below = (unsigned)a.emask[owner] & ((1u << (d - 1)) - 1u);
+          tris[3LL * idx + c] = (int)(a.voff[owner] + __popc(below));
+        }
+        ++idx;
+      }
+    }
+  }
+}
+
+// ---- filter_smooth_simple: v <- (v + sum of neighbours) / (1 + #neighbours) -------------------------------------
+// Neighbours are gathered face by face (each directed edge of a face adds its head to its tail).  Inside a closed
+// surface every undirected edge lies in exactly two faces, so each neighbour arrives twice: v <- (v + acc/2) / (1 + cnt/2).
+// Accumulation in 64-bit fixed point keeps the result independent of the atomic order.
+constexpr float SMOOTH_SCALE = 1048576.f;     // 2^20: coordinates < 2^11, valence sums < 2^20 -> < 2^51
+
+__global__ void smooth_accumulate_kernel(const float* __restrict__ v, const int* __restrict__ tris, long long ntris,
+                                         long long* __restrict__ acc, unsigned* __restrict__ cnt) {
+  const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= ntris) return;
+  const int i[3] = {tris[3 * f], tris[3 * f + 1], tris[3 * f + 2]};
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int tail = i[e];
+#pragma unroll
+    for (int o = 1; o < 3; ++o) {
+      const int head = i[(e + o) % 3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        atomicAdd(reinterpret_cast<unsigned long long*>(acc + 3LL * tail + c),
+                  (unsigned long long)__float2ll_rn(v[3LL * head + c] * SMOOTH_SCALE));
+    }
+    atomicAdd(cnt + tail, 2u);
+  }
+}
+__global__ void smooth_apply_kernel(float* __restrict__ v, long long nverts, long long* __restrict__ acc, unsigned* __restrict__ cnt) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nverts) return;
+  const float half_n = 0.5f * (float)cnt[i];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float s = (float)acc[3 * i + c] * (1.f / SMOOTH_SCALE);
+    v[3 * i + c] = (v[3 * i + c] + 0.5f * s) / (1.f + half_n);
+    acc[3 * i + c] = 0;
+  }
+  cnt[i] = 0;
+}
+
+// ---- Chamfer: for every point of A the squared distance to its nearest point of B (exact differences) ------------
+__global__ __launch_bounds__(256) void nearest_sq_kernel(const float* __restrict__ A, long long na, const float* __restrict__ B,
+                                                          long long nb, float* __restrict__ out) {
+  __shared__ float tile[1024 * 3];
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  if (i < na) { ax = A[3 * i]; ay = A[3 * i + 1]; az = A[3 * i + 2]; }
+  float best = 3.0e38f;
+  for (long long j0 = 0; j0 < nb; j0 += 1024) {
+    const int m = (int)min(1024LL, nb - j0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < m * 3; k += 256) tile[k] = B[3 * j0 + k];
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < m; ++k) {
+      const float dx = ax - tile[3 * k], dy = ay - tile[3 * k + 1], dz = az - tile[3 * k + 2];
+      best = fminf(best, dx * dx + dy * dy + dz * dz);
+    }
+  }
+  if (i < na) out[i] = best;
+}
+// mean of n floats, fixed summation order (one workgroup, double accumulators)
+__global__ __launch_bounds__(1024) void mean_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  __shared__ double red[1024];
+  double s = 0.0;
+  const long long per = (n + 1023) / 1024;
+  const long long b0 = threadIdx.x * per, b1 = min(n, b0 + per);
+  for (long long i = b0; i < b1; ++i) s += (double)x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = n > 0 ? (float)(red[0] / (double)n) : 0.f;
+}
+
+int fill(SurfArgs& a, const float* volume, int res, float level, void* scratch, unsigned* counts) {
+  ISHAP_REQUIRE(volume && scratch && res >= 2 && res <= 1024, "surface: volume, scratch and 2 <= res <= 1024");
+  a.vol = volume; a.res = res; a.level = level; a.n = (long long)res * res * res;
+  a.nblocks = (int)((a.n + SB_TILE - 1) / SB_TILE);
+  char* s = (char*)scratch;
+  a.voff = (unsigned*)s;               s += a.n * sizeof(unsigned);
+  a.bsum = (unsigned*)s;               s += 2LL * a.nblocks * sizeof(unsigned);
+  a.emask = (unsigned char*)s;         s += a.n;
+  a.tcnt = (unsigned char*)s;
+  a.counts = counts;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" long long ishap_surface_scratch_bytes(int res) {
+  const long long n = (long long)res * res * res;
+  const long long nb = (n + SB_TILE - 1) / SB_TILE;
+  return n * 6 + 2 * nb * 4 + 256;
+}
+
+extern "C" int ishap_surface_count(const float* volume, int res, float level, void* scratch, unsigned* counts, void* stream) {
+  SurfArgs a;
+  ISHAP_TRY(fill(a, volume, res, level, scratch, counts));
+  ISHAP_REQUIRE(counts, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(surf_count_kernel, dim3(a.nblocks), dim3(SB_THREADS), 0, s, a);
+  hipLaunchKernelGGL(surf_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, a);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ishap_surface_emit(const float* volume, int res, float level, void* scratch, float* verts, int* tris, void* stream) {
+  SurfArgs a;
+  ISHAP_TRY(fill(a, volume, res, level, scratch, nullptr));
+  ISHAP_REQUIRE(verts && tris, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(surf_emit_vertices_kernel, dim3(a.nblocks), dim3(SB_THREADS), 0, s, a, verts);
+  hipLaunchKernelGGL(surf_emit_triangles_kernel, dim3(a.nblocks), dim3(SB_THREADS), 0, s, a, tris);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ishap_mesh_smooth(float* verts, long long nverts, const int* tris, long long ntris, int iterations, void* scratch,
+                                 void* stream) {
+  ISHAP_REQUIRE(verts && tris && scratch && nverts >= 0 && ntris >= 0 && iterations >= 0, "mesh_smooth arguments");
+  if (nverts == 0 || ntris == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  long long* acc = (long long*)scratch;
+  unsigned* cnt = (unsigned*)(acc + 3 * nverts);
+  ISHAP_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)nverts * 28, s));
+  for (int it = 0; it < iterations; ++it) {
+    hipLaunchKernelGGL(smooth_accumulate_kernel, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, s, verts, tris, ntris, acc, cnt);
+    hipLaunchKernelGGL(smooth_apply_kernel, dim3((unsigned)((nverts + 255) / 256)), dim3(256), 0, s, verts, nverts, acc, cnt);
+  }
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ishap_chamfer(const float* a, long long na, const float* b, long long nb, float* nearest, float* out2, void* stream) {
+  ISHAP_REQUIRE(a && b && nearest && out2 && na > 0 && nb > 0, "chamfer arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(nearest_sq_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, s, a, na, b, nb, nearest);
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, nearest, na, out2);
+  hipLaunchKernelGGL(nearest_sq_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, b, nb, a, na, nearest);
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, nearest, nb, out2 + 1);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,42 +1,136 @@
-"""Mesh extraction side of get_mesh (reference: triplane_decoder/visualize.py:100-104 = PyMCubes
-marching cubes at level 0 + vertices/res*2-1; drag_utils.py:300 = Open3D filter_smooth_simple(10)).
+"""Mesh side of get_mesh (reference: triplane_decoder/visualize.py:100-104 = PyMCubes marching cubes at level 0 +
+vertices/res*2-1; drag_utils.py:300 = Open3D filter_smooth_simple(10); meshProcess.py:18-35 = Chamfer distance).
 
-Both are third-party CPU code outside the kernel path ("next").  When PyMCubes
-and Open3D are importable the reference's exact calls are used; otherwise the decoded volume is
-returned wrapped in `OccupancyMesh`, which keeps the device volume and exposes the surface-crossing
-voxel count so callers (bench, tests) still have a size-independent summary.
+Those are third-party CPU calls outside the kernel path.  When PyMCubes and Open3D are
+importable the reference's exact calls are used.  Otherwise the surface is produced ON THE DEVICE by
+csrc/surface.hip (marching tetrahedra on the resident volume, smoothing, nearest-neighbour Chamfer) through the C ABI
+(ishap_surface_count / _emit, ishap_mesh_smooth, ishap_chamfer); this module only allocates the outputs.
 """
 from __future__ import annotations
 
-import copy
+import ctypes as C
 
 import numpy as np
 import torch
 
+from . import _lib
+
+
+def _need_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} runs on the GPU (libishap_hip.so); there is no CPU fallback")
+
+
+def extract_surface(volume: torch.Tensor, level: float = 0.0):
+    """Level-`level` triangle mesh of a [res,res,res] volume: (vertices [V,3] float32 in grid coordinates,
+    triangles [F,3] int32), both on the device, in voxel order (deterministic)."""
+    _need_gpu(volume, "extract_surface")
+    assert volume.dim() == 3 and volume.shape[0] == volume.shape[1] == volume.shape[2]
+    res = volume.shape[0]
+    dev = volume.device
+    vol = volume.detach().to(torch.float32).contiguous()
+    L = _lib.lib()
+    scratch = torch.empty(int(L.ishap_surface_scratch_bytes(res)), dtype=torch.uint8, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        s = _lib.stream_ptr(dev)
+        _lib.check(L.ishap_surface_count(vol.data_ptr(), res, float(level), scratch.data_ptr(), counts.data_ptr(), s))
+        nv, nt = (int(c) for c in counts.tolist())                 # the one host read-back: output sizes
+        verts = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+        tris = torch.empty((nt, 3), dtype=torch.int32, device=dev)
+        if nv and nt:
+            _lib.check(L.ishap_surface_emit(vol.data_ptr(), res, float(level), scratch.data_ptr(), verts.data_ptr(),
+                                            tris.data_ptr(), s))
+    return verts, tris
+
+
+def surface_counts(volume: torch.Tensor, level: float = 0.0):
+    """(vertices, triangles) of the level surface without emitting it."""
+    _need_gpu(volume, "surface_counts")
+    res = volume.shape[0]
+    dev = volume.device
+    vol = volume.detach().to(torch.float32).contiguous()
+    L = _lib.lib()
+    scratch = torch.empty(int(L.ishap_surface_scratch_bytes(res)), dtype=torch.uint8, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.ishap_surface_count(vol.data_ptr(), res, float(level), scratch.data_ptr(), counts.data_ptr(),
+                                         _lib.stream_ptr(dev)))
+    nv, nt = counts.tolist()
+    return int(nv), int(nt)
+
+
+def smooth_mesh(verts: torch.Tensor, tris: torch.Tensor, iterations: int = 10) -> torch.Tensor:
+    """filter_smooth_simple (drag_utils.py:300) on the device; returns new vertex positions."""
+    _need_gpu(verts, "smooth_mesh")
+    out = verts.detach().to(torch.float32).contiguous().clone()
+    tris = tris.detach().to(torch.int32).contiguous()
+    if out.shape[0] == 0 or tris.shape[0] == 0 or iterations <= 0:
+        return out
+    scratch = torch.empty(out.shape[0] * 28, dtype=torch.uint8, device=out.device)
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.lib().ishap_mesh_smooth(out.data_ptr(), out.shape[0], tris.data_ptr(), tris.shape[0], int(iterations),
+                                                scratch.data_ptr(), _lib.stream_ptr(out.device)))
+    return out
+
+
+def chamfer_distance(pa: torch.Tensor, pb: torch.Tensor, point_num=20000, seed: int = 0) -> float:
+    """meshProcess.py:18-35: mean squared nearest-neighbour distance a->b plus b->a on `point_num` samples per side
+    (the reference samples mesh surfaces with Open3D; here the samples are drawn from the given point sets).
+    point_num=None uses every point (no sampling floor)."""
+    _need_gpu(pa, "chamfer_distance")
+    g = torch.Generator(device="cpu").manual_seed(seed)
+
+    def pick(p):
+        if point_num is None or p.shape[0] <= point_num:
+            return p
+        return p[torch.randperm(p.shape[0], generator=g)[:point_num].to(p.device)]
+    a = pick(pa).detach().to(torch.float32).contiguous()
+    b = pick(pb).detach().to(device=a.device, dtype=torch.float32).contiguous()
+    if a.shape[0] == 0 or b.shape[0] == 0:
+        return float("nan")
+    nearest = torch.empty(max(a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().ishap_chamfer(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], nearest.data_ptr(),
+                                            out2.data_ptr(), _lib.stream_ptr(a.device)))
+    d = out2.tolist()
+    return float(d[0] + d[1])
+
 
 class OccupancyMesh:
-    """Stand-in mesh when PyMCubes/Open3D are absent: the occupancy-logit volume itself."""
+    """The mesh get_mesh returns when PyMCubes/Open3D are absent: the device volume plus, on first use, its surface
+    (vertices in the reference's convention grid/res*2-1, visualize.py:101) after `smooth_iterations` sweeps."""
 
-    def __init__(self, volume: torch.Tensor, res: int):
+    def __init__(self, volume: torch.Tensor, res: int, smooth_iterations: int = 10):
         self.volume = volume
         self.res = res
+        self.smooth_iterations = smooth_iterations
+        self._mesh = None
 
-    def occupied_voxels(self) -> int:
-        return int((self.volume > 0).sum().item())
+    def _build(self):
+        if self._mesh is None:
+            v, t = extract_surface(self.volume, 0.0)
+            v = v / self.res * 2 - 1
+            self._mesh = (smooth_mesh(v, t, self.smooth_iterations), t)
+        return self._mesh
 
-    def surface_cells(self) -> int:
-        """Number of grid cells whose 8 corners straddle level 0 (what marching cubes would triangulate)."""
-        o = self.volume > 0
-        c = o[:-1, :-1, :-1].int()
-        for dx in (0, 1):
-            for dy in (0, 1):
-                for dz in (0, 1):
-                    if dx or dy or dz:
-                        c = c + o[dx:o.shape[0] - 1 + dx, dy:o.shape[1] - 1 + dy, dz:o.shape[2] - 1 + dz].int()
-        return int(((c > 0) & (c < 8)).sum().item())
+    @property
+    def vertices(self) -> torch.Tensor:
+        return self._build()[0]
+
+    @property
+    def triangles(self) -> torch.Tensor:
+        return self._build()[1]
+
+    def counts(self):
+        return surface_counts(self.volume, 0.0)
 
     def __deepcopy__(self, memo):
-        return OccupancyMesh(self.volume.clone(), self.res)
+        m = OccupancyMesh(self.volume.clone(), self.res, self.smooth_iterations)
+        if self._mesh is not None:
+            m._mesh = (self._mesh[0].clone(), self._mesh[1].clone())
+        return m
 
 
 def volume_to_mesh(volume: torch.Tensor, res: int, smooth_iterations: int = 10):
@@ -44,7 +138,7 @@ def volume_to_mesh(volume: torch.Tensor, res: int, smooth_iterations: int = 10):
         import mcubes           # noqa: F401
         import open3d as o3d    # noqa: F401
     except Exception:
-        return OccupancyMesh(volume, res)
+        return OccupancyMesh(volume, res, smooth_iterations)
     vertices, triangles = mcubes.marching_cubes(volume.detach().cpu().numpy(), 0)
     vertices = vertices / res * 2 - 1                      # visualize.py:101 (create_obj_o3d's own convention)
     mesh = o3d.geometry.TriangleMesh()
@@ -53,10 +147,18 @@ def volume_to_mesh(volume: torch.Tensor, res: int, smooth_iterations: int = 10):
     return mesh.filter_smooth_simple(number_of_iterations=smooth_iterations)
 
 
+def _write_obj(path, verts: torch.Tensor, tris: torch.Tensor):
+    v = verts.detach().cpu().numpy()
+    f = tris.detach().cpu().numpy() + 1
+    with open(path, "w") as fh:
+        fh.write("".join(f"v {p[0]:.6f} {p[1]:.6f} {p[2]:.6f}\n" for p in v))
+        fh.write("".join(f"f {t[0]} {t[1]} {t[2]}\n" for t in f))
+
+
 def write_mesh(path, mesh):
-    """o3d.io.write_triangle_mesh (drag_utils.py:470) when Open3D produced the mesh; the raw volume otherwise."""
+    """o3d.io.write_triangle_mesh (drag_utils.py:470) when Open3D produced the mesh; Wavefront OBJ of the device mesh otherwise."""
     if isinstance(mesh, OccupancyMesh):
-        np.save(path + ".volume.npy", mesh.volume.detach().cpu().numpy())
+        _write_obj(path, mesh.vertices, mesh.triangles)
         return
     import open3d as o3d
     o3d.io.write_triangle_mesh(path, mesh)
@@ -87,114 +189,9 @@ def sample_occupancy(mesh, mesh_path, center_mesh, points_size, uniform_ratio):
     return pts, occ
 
 
-# ------------------------------------------------------------------------------------------------------------
-# level-0 surface without PyMCubes
-# ------------------------------------------------------------------------------------------------------------
-def mc_vertices(volume: torch.Tensor, level: float = 0.0) -> torch.Tensor:
-    """The vertex set marching cubes produces: one vertex per grid edge whose end points straddle `level`,
-    at the linearly interpolated crossing (grid coordinates, [V,3]).  Triangulation tables are not needed for
-    vertex counts or for the Chamfer metric of meshProcess.py:18-35."""
-    v = volume.float() - level
-    out = []
-    for axis in range(3):
-        a = v.narrow(axis, 0, v.shape[axis] - 1)
-        b = v.narrow(axis, 1, v.shape[axis] - 1)
-        cross = (a < 0) != (b < 0)
-        idx = cross.nonzero()
-        if idx.numel() == 0:
-            continue
-        va, vb = a[cross], b[cross]
-        t = va / (va - vb)
-        p = idx.float()
-        p[:, axis] += t
-        out.append(p)
-    return torch.cat(out, dim=0) if out else torch.zeros((0, 3), device=volume.device)
-
-
-def chamfer_distance(pa: torch.Tensor, pb: torch.Tensor, point_num=20000, seed: int = 0, chunk: int = 2048) -> float:
-    """meshProcess.py:18-35: mean squared nearest-neighbour distance a->b plus b->a on `point_num` samples per side
-    (the reference samples mesh surfaces with Open3D; here the samples are drawn from the surface vertex sets).
-    point_num=None uses every vertex (no sampling floor)."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
-
-    def pick(p):
-        if point_num is None or p.shape[0] <= point_num:
-            return p
-        return p[torch.randperm(p.shape[0], generator=g)[:point_num].to(p.device)]
-    a, b = pick(pa).float(), pick(pb).float()
-    if a.shape[0] == 0 or b.shape[0] == 0:
-        return float("nan")
-
-    def one_way(x, y):
-        mins = []
-        step = max(1, min(chunk, (1 << 28) // max(1, y.shape[0])))       # bound the distance block to ~1 GiB
-        for i in range(0, x.shape[0], step):
-            d = torch.cdist(x[i:i + step], y, compute_mode="donot_use_mm_for_euclid_dist")   # exact differences
-            mins.append(d.min(dim=1).values)
-        return float((torch.cat(mins) ** 2).mean())
-    return one_way(b, a) + one_way(a, b)
-
-
-_TET_TRI = torch.tensor([[-1, -1, -1, -1, -1, -1], [1, 0, 2, -1, -1, -1], [4, 0, 3, -1, -1, -1], [1, 4, 2, 1, 3, 4],
-                         [3, 1, 5, -1, -1, -1], [2, 3, 0, 2, 5, 3], [1, 4, 0, 1, 5, 4], [4, 2, 5, -1, -1, -1],
-                         [4, 5, 2, -1, -1, -1], [4, 1, 0, 4, 5, 1], [3, 2, 0, 3, 5, 2], [1, 3, 5, -1, -1, -1],
-                         [4, 1, 2, 4, 3, 1], [3, 0, 4, -1, -1, -1], [2, 0, 1, -1, -1, -1], [-1, -1, -1, -1, -1, -1]])
-_TET_NTRI = torch.tensor([0, 1, 1, 2, 1, 2, 2, 1, 1, 2, 2, 1, 2, 1, 1, 0])
-_TET_EDGES = torch.tensor([[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]])
-_CUBE_TETS = torch.tensor([[0, 1, 3, 7], [0, 3, 2, 7], [0, 2, 6, 7], [0, 6, 4, 7], [0, 4, 5, 7], [0, 5, 1, 7]])
-
-
-def marching_tetrahedra(volume: torch.Tensor, max_cells: int = 4_000_000):
-    """Level-0 triangle mesh over the cells that straddle the surface (6 tetrahedra per cell, 16-case table).
-    Returns (vertices [V,3] in grid coordinates, faces [F,3])."""
-    dev = volume.device
-    v = volume.float()
-    occ = v > 0
-    R = v.shape
-    c = torch.zeros((R[0] - 1, R[1] - 1, R[2] - 1), dtype=torch.int32, device=dev)
-    for dx in (0, 1):
-        for dy in (0, 1):
-            for dz in (0, 1):
-                c += occ[dx:R[0] - 1 + dx, dy:R[1] - 1 + dy, dz:R[2] - 1 + dz].int()
-    cells = ((c > 0) & (c < 8)).nonzero()
-    if cells.shape[0] == 0:
-        return torch.zeros((0, 3), device=dev), torch.zeros((0, 3), dtype=torch.long, device=dev)
-    if cells.shape[0] > max_cells:
-        raise RuntimeError(f"{cells.shape[0]} surface cells: volume is not a surface (noise?)")
-    corner = torch.tensor([[i & 1, (i >> 1) & 1, (i >> 2) & 1] for i in range(8)], device=dev)
-    cp = cells[:, None, :] + corner[None]                                   # [C,8,3] grid points
-    lin = (cp[..., 0] * R[1] + cp[..., 1]) * R[2] + cp[..., 2]              # [C,8] linear ids
-    tets = lin[:, _CUBE_TETS.to(dev)].reshape(-1, 4)                        # [6C,4]
-    flat = v.reshape(-1)
-    o = (flat[tets] > 0)
-    code = (o.long() * torch.tensor([1, 2, 4, 8], device=dev)).sum(-1)
-    keep = (code > 0) & (code < 15)
-    tets, code = tets[keep], code[keep]
-    e = tets[:, _TET_EDGES.to(dev)]                                         # [T,6,2]
-    e = torch.sort(e, dim=-1).values
-    tri = _TET_TRI.to(dev)[code]                                            # [T,6]
-    ntri = _TET_NTRI.to(dev)[code]
-    faces_e = []
-    for k in range(2):
-        m = ntri > k
-        sel = tri[m][:, 3 * k:3 * k + 3]
-        faces_e.append(torch.gather(e[m], 1, sel[..., None].expand(-1, -1, 2)))   # [F,3,2]
-    fe = torch.cat(faces_e, dim=0).reshape(-1, 2)
-    key = fe[:, 0] * flat.shape[0] + fe[:, 1]
-    uniq, inv = torch.unique(key, return_inverse=True)
-    a, b = uniq // flat.shape[0], uniq % flat.shape[0]
-    va, vb = flat[a], flat[b]
-    t = (va / (va - vb)).unsqueeze(-1)
-
-    def coords(l):
-        return torch.stack([l // (R[1] * R[2]), (l // R[2]) % R[1], l % R[2]], dim=-1).float()
-    verts = coords(a) * (1 - t) + coords(b) * t
-    return verts, inv.reshape(-1, 3)
-
-
 def export_obj(volume: torch.Tensor, path: str, scale_div: float = 255.0):
-    """visualize.py:71-73 (create_obj): marching cubes at 0, vertices / 255 * 2 - 1, Wavefront OBJ.
-    PyMCubes when importable (the reference's exact call); marching tetrahedra otherwise."""
+    """visualize.py:71-73 (create_obj): surface at 0, vertices / 255 * 2 - 1, Wavefront OBJ.
+    PyMCubes when importable (the reference's exact call); the device extraction otherwise."""
     try:
         import mcubes
         vertices, triangles = mcubes.marching_cubes(volume.detach().cpu().numpy(), 0)
@@ -203,16 +200,5 @@ def export_obj(volume: torch.Tensor, path: str, scale_div: float = 255.0):
         return
     except ImportError:
         pass
-    try:
-        verts, faces = marching_tetrahedra(volume)
-    except RuntimeError as e:
-        with open(path, "w") as f:
-            f.write(f"# {e}\n")
-        return
-    verts = (verts / scale_div * 2 - 1).cpu().numpy()
-    faces = faces.cpu().numpy() + 1
-    with open(path, "w") as f:
-        for v in verts:
-            f.write(f"v {v[0]:.6f} {v[1]:.6f} {v[2]:.6f}\n")
-        for t in faces:
-            f.write(f"f {t[0]} {t[1]} {t[2]}\n")
+    verts, tris = extract_surface(volume, 0.0)
+    _write_obj(path, verts / scale_div * 2 - 1, tris)

@@ -99,25 +99,3 @@ def test_gather_volumes_world_size_2_gloo(n_edits):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == [float(i) for i in range(n_edits)]
-
-
-def test_surface_extraction_on_analytic_sphere():
-    """mc_vertices / marching_tetrahedra / chamfer on a sphere SDF (CPU tensors): vertices lie on the sphere,
-    the mesh is closed (every edge shared by two faces) and Chamfer(sphere, same sphere) ~ 0."""
-    from ishapediting_amd.mesh import chamfer_distance, marching_tetrahedra, mc_vertices
-    res, r = 32, 9.3
-    ax = torch.arange(res, dtype=torch.float32) - (res - 1) / 2
-    x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
-    vol = r - torch.sqrt(x * x + y * y + z * z)              # > 0 inside
-    pv = mc_vertices(vol)
-    rad = torch.linalg.norm(pv - (res - 1) / 2, dim=1)
-    assert pv.shape[0] > 1000 and float((rad - r).abs().max()) < 0.05
-    verts, faces = marching_tetrahedra(vol)
-    rad = torch.linalg.norm(verts - (res - 1) / 2, dim=1)
-    assert float((rad - r).abs().max()) < 0.08
-    e = torch.cat([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]]).sort(dim=1).values
-    _, counts = torch.unique(e, dim=0, return_counts=True)
-    assert int(counts.min()) == 2 and int(counts.max()) == 2        # watertight
-    assert chamfer_distance(pv, pv.clone(), 10 ** 6) < 1e-6          # no subsampling: identical sets
-    shifted = pv + torch.tensor([0.5, 0.0, 0.0])
-    assert 0.05 < chamfer_distance(pv, shifted, 2000) < 0.6

@@ -167,3 +167,29 @@ def test_reconstruction_loop(gold):
     close(torch.stack(losses), g["losses"], rtol=1e-4, atol=1e-6)
     close(torch.stack(grads), g["grads"], rtol=2e-3, atol=1e-7)
     close(torch.stack(imgs), g["imgs"], rtol=1e-3, atol=1e-4)
+
+
+def test_surface_extraction_on_analytic_sphere():
+    """The surface checker (oracle/surface_cpu.py) itself, on a sphere SDF: vertices lie on the sphere,
+    the mesh is closed (every edge shared by two faces) and Chamfer(sphere, same sphere) ~ 0."""
+    from oracle.surface_cpu import chamfer_distance, marching_tetrahedra, mc_vertices, smooth_simple
+    res, r = 32, 9.3
+    ax = torch.arange(res, dtype=torch.float32) - (res - 1) / 2
+    x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    vol = r - torch.sqrt(x * x + y * y + z * z)              # > 0 inside
+    pv = mc_vertices(vol)
+    rad = torch.linalg.norm(pv - (res - 1) / 2, dim=1)
+    assert pv.shape[0] > 1000 and float((rad - r).abs().max()) < 0.05
+    verts, faces = marching_tetrahedra(vol)
+    rad = torch.linalg.norm(verts - (res - 1) / 2, dim=1)
+    assert float((rad - r).abs().max()) < 0.08
+    e = torch.cat([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]]).sort(dim=1).values
+    _, counts = torch.unique(e, dim=0, return_counts=True)
+    assert int(counts.min()) == 2 and int(counts.max()) == 2        # watertight
+    assert chamfer_distance(pv, pv.clone(), 10 ** 6) < 1e-6          # no subsampling: identical sets
+    shifted = pv + torch.tensor([0.5, 0.0, 0.0])
+    assert 0.05 < chamfer_distance(pv, shifted, 2000) < 0.6
+    assert verts.shape[0] - 3 * faces.shape[0] // 2 + faces.shape[0] == 2      # Euler characteristic of a sphere
+    sm = smooth_simple(verts, faces, 10)
+    rs = torch.linalg.norm(sm - (res - 1) / 2, dim=1)
+    assert 0.9 * r < float(rs.mean()) < r and float(rs.std()) < 0.1      # Laplacian smoothing shrinks the sphere slightly

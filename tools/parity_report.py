@@ -25,7 +25,8 @@ def main():
     a = ap.parse_args()
     from ishapediting_amd import synthetic
     from ishapediting_amd.drag_utils import DragStuff, get_args
-    from ishapediting_amd.mesh import chamfer_distance, mc_vertices
+    from ishapediting_amd.mesh import chamfer_distance
+    from oracle.surface_cpu import mc_vertices          # checker-side vertex sets for both volumes
     from ishapediting_amd.unet_spec import build_spec, full_config
     from oracle import ref_cpu as O
     dev = torch.device("cuda", 0)
@@ -67,7 +68,7 @@ def main():
     t_cpu = time.time() - t0
     # ---------------- report ----------------
     rel = lambda x, y: float((x - y).norm() / y.norm())
-    va, vb = mc_vertices(vol_gpu) / a.res * 2 - 1, mc_vertices(vol_cpu) / a.res * 2 - 1     # visualize.py:101 convention
+    va, vb = mc_vertices(vol_gpu.cpu()) / a.res * 2 - 1, mc_vertices(vol_cpu.cpu()) / a.res * 2 - 1     # visualize.py:101 convention
     rep = {
         "config": {"T": a.T, "guided_steps": a.W, "decode_res": a.res, "handles": 3, "scale": scale, "cof": cof,
                    "weights": "synthetic seed 1234 (421M params)", "feature_range": "+-0.05"},
@@ -79,8 +80,8 @@ def main():
         "sign_flips": int(((vol_gpu > 0) != (vol_cpu > 0)).sum()), "voxels": int(vol_cpu.numel()),
         "mc_vertices_device": int(va.shape[0]), "mc_vertices_oracle": int(vb.shape[0]),
         "chamfer_all_vertices": chamfer_distance(va.to(dev), vb.to(dev), None) if min(va.shape[0], vb.shape[0]) > 0 else None,
-        "chamfer_20k_samples": chamfer_distance(va, vb, 20000) if min(va.shape[0], vb.shape[0]) > 0 else None,
-        "chamfer_20k_sampling_floor": chamfer_distance(vb, vb.clone(), 20000, seed=1),
+        "chamfer_20k_samples": chamfer_distance(va.to(dev), vb.to(dev), 20000) if min(va.shape[0], vb.shape[0]) > 0 else None,
+        "chamfer_20k_sampling_floor": chamfer_distance(vb.to(dev), vb.clone().to(dev), 20000, seed=1),
         "oracle_drag_losses": losses, "device_drag_losses": [float(l) for l in ds.last_losses],
         "seconds_device": round(t_gpu, 2), "seconds_oracle_cpu": round(t_cpu, 1),
     }
