@@ -383,6 +383,18 @@ int igemm_pick_ksplit(int M, int N, int K, int nbatch) {
   return split;
 }
 
+bool igemm_skinny_applicable(const IgemmArgs& a);                      // igemm_skinny.hip (small maps, one launch)
+int igemm_skinny_launch(const IgemmArgs& a, int mt, hipStream_t s);
+
+// 1x1 GEMMs on the 8x8 maps: the one-launch skinny kernel beats the tiled one there (measured in situ: 7.8 vs 11.4 us
+// at 64 x 1024 x 1024); for 3x3 layers it re-reads the im2col fragments once per 16-channel tile and loses.
+static bool use_skinny(const IgemmArgs& a) {
+  static const int mode = [] { const char* e = getenv("ISHAP_SKINNY"); return e ? atoi(e) : 1; }();   // 0 off, 1 1x1 only, 2 all
+  if (!mode || !igemm_skinny_applicable(a)) return false;
+  if (mode == 1 && (a.conv3 || a.M > 64)) return false;      // in situ it wins at M = 64 (-3..5 us per launch) and loses at M = 256
+  return true;
+}
+
 int igemm_launch(const IgemmArgs& a, hipStream_t s) {
   ISHAP_REQUIRE(a.M % 64 == 0, "M must be a multiple of 64");
   ISHAP_REQUIRE(a.N % 4 == 0, "N must be a multiple of 4");
@@ -393,6 +405,19 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
                             a.gb_stats && a.gb_gamma && a.gb_beta && (!a.gb_film || a.gb_emb)),
                 "fused GroupNorm-backward sums: fp16 dense output, N % 32 == 0, no forward statistics");
   ISHAP_REQUIRE(a.ldx % 8 == 0 && a.ldw % 8 == 0, "row strides must keep 16-byte alignment");
+  if (use_skinny(a)) {
+    if (!g_prof_on) return igemm_skinny_launch(a, 0, s);
+    ProfRec r;
+    r.a = prof_event(); r.b = prof_event(); r.c = nullptr;
+    r.flops = 2.0 * a.M * a.N * a.K * a.flops_scale;
+    r.variant = a.conv3 ? 1 : 3;
+    r.M = a.M; r.N = a.N; r.K = a.K; r.conv3 = a.conv3; r.big = false; r.ksplit = 0;      // ksplit 0 marks the skinny kernel
+    g_igemm_prof_start = r.a; g_igemm_prof_stop = r.b;
+    const int rc = igemm_skinny_launch(a, 0, s);
+    g_igemm_prof_start = nullptr; g_igemm_prof_stop = nullptr;
+    g_prof.push_back(r);
+    return rc;
+  }
   const bool k64 = a.conv3 ? (a.Cin % 64 == 0) : (a.K % 64 == 0);
   const bool big = igemm_use_big(a.M, a.N, a.nbatch);
 #define IG_DISPATCH(BM, BN, WM_, WN_)                                                          \

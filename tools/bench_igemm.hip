@@ -6,6 +6,7 @@
 #include <vector>
 #include "../ishapediting_amd/csrc/igemm2.hip"
 #include "../ishapediting_amd/csrc/igemm3.hip"
+#include "../ishapediting_amd/csrc/igemm_skinny.hip"
 hipEvent_t g_igemm_prof_start = nullptr, g_igemm_prof_stop = nullptr;
 void ishap_set_error(const std::string& m) { fprintf(stderr, "ERR %s\n", m.c_str()); }
 
@@ -29,7 +30,25 @@ int main(int argc, char** argv) {
   long long* st = nullptr;
   if (stats) { hipMalloc(&st, (size_t)Cout * 2 * 8); hipMemset(st, 0, (size_t)Cout * 2 * 8); a.stat_out = st; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  auto run = [&]() { if (gen == 3 && igemm3_applicable(a, big)) igemm3_launch_main(a, big, 0); else igemm2_launch_main(a, big, 0); };
+  const int mt = ksplit;                          // gen 4 (skinny kernel): argument 5 is MT (pixels per workgroup / 16)
+  if (gen == 4) { a.ksplit = 1; }
+  auto run = [&]() {
+    if (gen == 4) igemm_skinny_launch(a, mt, 0);
+    else if (gen == 3 && igemm3_applicable(a, big)) igemm3_launch_main(a, big, 0);
+    else igemm2_launch_main(a, big, 0);
+  };
+  if (gen == 4) {                                 // check against the tiled kernel
+    half_t* O1; hipMalloc(&O1, (size_t)M * Cout * 2);
+    IgemmArgs b = a; b.out = O1; b.stat_out = nullptr;
+    igemm2_launch_main(b, 0, 0);
+    run();
+    std::vector<half_t> o((size_t)M * Cout), o1((size_t)M * Cout);
+    hipMemcpy(o.data(), O, o.size() * 2, hipMemcpyDeviceToHost);
+    hipMemcpy(o1.data(), O1, o1.size() * 2, hipMemcpyDeviceToHost);
+    double md = 0, mx = 0;
+    for (size_t i = 0; i < o.size(); ++i) { md = fmax(md, fabs((double)o[i] - (double)o1[i])); mx = fmax(mx, fabs((double)o1[i])); }
+    printf("skinny vs tiled: max |diff| %.4g of max |out| %.4g\n", md, mx);
+  }
   for (int i = 0; i < 5; ++i) run();
   hipDeviceSynchronize();
   const int it = 50;
