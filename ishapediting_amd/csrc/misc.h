@@ -9,9 +9,6 @@ int concat2(const half_t* a, const half_t* b, half_t* o, long long M, int Ca, in
             const long long* sa = nullptr, const long long* sb = nullptr, long long* so = nullptr, int N = 1);
 int slice_channels(const half_t* src, half_t* o, long long M, int Cs, int off, int Co, int accumulate, hipStream_t s);
 int add_f16(const half_t* a, const half_t* b, half_t* o, long long n, hipStream_t s);
-int head_transpose(const half_t* src, half_t* dst, int N, int T, int ld, int heads, int d, int dpad, int head_stride,
-                   int part_off, hipStream_t s);
-int softmax_rows(const float* S, half_t* P, float* lse, long long rows, int T, hipStream_t s);
 struct TsArg { float t[16]; };   // timesteps by value: no host->device copy on the step path
 int timestep_embedding(const TsArg& t, float* out, int N, int dim, hipStream_t s);
 int gemv_f32(const float* W, const float* b, const float* in, float* out, int rows, int K, int N, int silu_in, hipStream_t s);
@@ -19,7 +16,4 @@ int pack_conv_weight(const float* w, half_t* dst, int O, int I, int taps, int ro
 int pack_conv_weight_split(const float* w, half_t* dst, int O, int I, int taps, int rows_pad, hipStream_t s);
 int round_through_f16(const float* src, float* dst, long long n, hipStream_t s);
 // attention backward pieces + gradient export (attn_bwd.hip)
-int exp_sub_lse_cols(const float* ST, const float* lse, half_t* PT, long long batches, int T, hipStream_t s);
-int softmax_bwd_rows(const half_t* P, const float* dP, half_t* dS, float* D, long long rows, int T, float alpha, hipStream_t s);
-int softmax_bwd_cols(const half_t* PT, const float* dPT, const float* D, half_t* dST, long long batches, int T, float alpha, hipStream_t s);
 int nhwc_f16_to_nchw_f32_scaled(const half_t* src, float* dst, int N, int C, int HW, int ld, const float* mul_dev, hipStream_t s);

@@ -155,64 +155,6 @@ int add_f16(const half_t* a, const half_t* b, half_t* o, long long n, hipStream_
   return 0;
 }
 
-// --------------------------- attention glue ---------------------------
-// qkv [N][T][3C] (per head h: q = ch [h*3d, h*3d+d), k next d, v next d  -- "legacy" order, unet.py:347)
-// -> dst [N*heads][dpad][T]  (row = channel within head, contiguous over tokens), part = 0 q / 1 k / 2 v
-__global__ __launch_bounds__(256) void head_transpose_kernel(const half_t* __restrict__ src, half_t* __restrict__ dst,
-                                                             int T, int ld, int d, int dpad, int head_stride,
-                                                             int part_off, int heads) {
-  __shared__ half_t tile[32][34];
-  const int nh = blockIdx.z;                 // n*heads + h
-  const int n = nh / heads, h = nh % heads;
-  const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int j = ty; j < 32; j += 8) {
-    int t = t0 + j, c = c0 + tx;
-    tile[j][tx] = (t < T && c < d) ? src[((long long)n * T + t) * ld + h * head_stride + part_off + c] : (half_t)0;
-  }
-  __syncthreads();
-  for (int j = ty; j < 32; j += 8) {
-    int c = c0 + j, t = t0 + tx;
-    if (c < dpad && t < T) dst[((long long)nh * dpad + c) * T + t] = tile[tx][j];
-  }
-}
-int head_transpose(const half_t* src, half_t* dst, int N, int T, int ld, int heads, int d, int dpad, int head_stride,
-                   int part_off, hipStream_t s) {
-  dim3 g(ceil_div(T, 32), ceil_div(dpad, 32), N * heads);
-  hipLaunchKernelGGL(head_transpose_kernel, g, dim3(256), 0, s, src, dst, T, ld, d, dpad, head_stride, part_off, heads);
-  ISHAP_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-// row softmax in fp32 (unet.py:352): S [rows][T] fp32 -> P [rows][T] fp16, lse[rows] (natural log) for the backward
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, half_t* __restrict__ P,
-                                                           float* __restrict__ lse, int T) {
-  __shared__ float red[8];
-  const long long row = blockIdx.x;
-  const float* s = S + row * T;
-  const int tid = threadIdx.x;
-  float m = -INFINITY;
-  for (int i = tid; i < T; i += 256) m = fmaxf(m, s[i]);
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((tid & 63) == 0) red[tid >> 6] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
-  float sum = 0.f;
-  for (int i = tid; i < T; i += 256) sum += __expf(s[i] - m);
-  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-  if ((tid & 63) == 0) red[tid >> 6] = sum;
-  __syncthreads();
-  sum = red[0] + red[1] + red[2] + red[3];
-  const float inv = 1.f / sum;
-  for (int i = tid; i < T; i += 256) P[row * T + i] = (half_t)(__expf(s[i] - m) * inv);
-  if (tid == 0 && lse) lse[row] = m + __logf(sum);
-}
-int softmax_rows(const float* S, half_t* P, float* lse, long long rows, int T, hipStream_t s) {
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, S, P, lse, T);
-  ISHAP_CHECK_HIP(hipGetLastError());
-  return 0;
-}
 
 // --------------------------- timestep embedding + GEMV ---------------------------
 // nn.py:102-120: [cos(t*f) | sin(t*f)], f_j = exp(-ln(1e4) * j / half)
@@ -329,6 +271,32 @@ __global__ void round_f16_kernel(const float* __restrict__ src, float* __restric
 int round_through_f16(const float* src, float* dst, long long n, hipStream_t s) {
   int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(round_f16_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// NHWC fp16 (row stride ld) -> NCHW fp32 times *mul_dev (gradient leaving the backward pass, loss scale removed)
+__global__ __launch_bounds__(256) void nhwc_to_nchw_scaled_kernel(const half_t* __restrict__ src, float* __restrict__ dst,
+                                                                  int C, int HW, int ld, const float* __restrict__ mul_dev) {
+  __shared__ float tile[32][33];
+  const float mul = mul_dev ? *mul_dev : 1.f;
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    int p = p0 + j, c = c0 + tx;
+    tile[j][tx] = (c < C && p < HW) ? (float)src[((long long)n * HW + p) * ld + c] * mul : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int c = c0 + j, p = p0 + tx;
+    if (c < C && p < HW) dst[((long long)n * C + c) * HW + p] = tile[tx][j];
+  }
+}
+int nhwc_f16_to_nchw_f32_scaled(const half_t* src, float* dst, int N, int C, int HW, int ld, const float* mul_dev,
+                                hipStream_t s) {
+  dim3 g(ceil_div(HW, 32), ceil_div(C, 32), N);
+  hipLaunchKernelGGL(nhwc_to_nchw_scaled_kernel, g, dim3(256), 0, s, src, dst, C, HW, ld, mul_dev);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -125,10 +125,6 @@ struct ishap_unet {
   Arena arena;
   float* ws = nullptr;          size_t ws_floats = 0;       // split-K partials
   float* gn_partial = nullptr;  size_t gn_partial_floats = 0;
-  float* attn_S = nullptr;      size_t attn_S_floats = 0;
-  half_t* attn_P = nullptr;
-  half_t* attn_T = nullptr;     size_t attn_T_halfs = 0;    // transposed head operands (4 slots)
-  half_t* attn_dS = nullptr;                                // backward scratch (same size as P), 2 slots
   // last forward
   int last_N = 0, last_feat = -1;
   bool have_saved = false;
@@ -139,7 +135,6 @@ struct ishap_unet {
   size_t stat_cap = 0, stat_off = 0, stat_high = 0, stat_fwd_mark = 0;
   int bwd_since_fwd = 0;
   size_t fwd_mark = 0;          // arena offset after the forward (backward scratch goes above it)
-  float* gn_mstats = nullptr;   // backward GN scratch [max_batch][32][2]
   float* attn_D = nullptr;      // backward attention row sums
   size_t attn_D_floats = 0;
 };

@@ -511,15 +511,8 @@ int ishap_unet_create(const ishap_unet_config* cfg, int device, ishap_unet** out
   ISHAP_CHECK_HIP(hipMalloc((void**)&u->arena.base, u->arena.cap));
   if (u->ws_floats) ISHAP_CHECK_HIP(hipMalloc((void**)&u->ws, u->ws_floats * sizeof(float)));
   ISHAP_CHECK_HIP(hipMalloc((void**)&u->gn_partial, std::max<size_t>(u->gn_partial_floats, 64) * sizeof(float)));
-  if (u->attn_S_floats) {
-    ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_S, u->attn_S_floats * sizeof(float)));
-    ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_P, u->attn_S_floats * sizeof(half_t)));
-    ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_dS, 2 * u->attn_S_floats * sizeof(half_t)));
-    ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_T, 4 * u->attn_T_halfs * sizeof(half_t) + 65536));
-  }
   u->stat_cap = (u->stat_high + 1023) / 1024 * 1024;
   ISHAP_CHECK_HIP(hipMalloc((void**)&u->stat_base, std::max<size_t>(u->stat_cap, 1024) * sizeof(long long)));
-  ISHAP_CHECK_HIP(hipMalloc((void**)&u->gn_mstats, (size_t)cfg->max_batch * 64 * sizeof(float)));
   if (u->attn_D_floats) ISHAP_CHECK_HIP(hipMalloc((void**)&u->attn_D, u->attn_D_floats * sizeof(float)));
   u->have_saved = false;
   *out = u;
@@ -539,7 +532,7 @@ void ishap_unet_destroy(ishap_unet* u) {
   for (auto& a : u->attn) { frc(a.qkv); frc(a.proj); fr(a.n.gamma); fr(a.n.beta); }
   fr(u->te_w0); fr(u->te_b0); fr(u->te_w2); fr(u->te_b2); fr(u->emb_w); fr(u->emb_b);
   fr(u->d_temb); fr(u->d_e1); fr(u->d_emb); fr(u->d_film);
-  fr(u->arena.base); fr(u->ws); fr(u->gn_partial); fr(u->attn_S); fr(u->attn_P); fr(u->attn_T); fr(u->attn_dS); fr(u->gn_mstats); fr(u->attn_D); fr(u->stat_base);
+  fr(u->arena.base); fr(u->ws); fr(u->gn_partial); fr(u->attn_D); fr(u->stat_base);
   delete u;
 }
 
