@@ -36,7 +36,9 @@ static int dgrad_op(Exec& e, const ConvW& c, const Tensor& dy, Tensor& dx_out, i
                  IG_OUT_F16, 0, 0, nullptr, gb);
 }
 
-static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx) {
+// `split` > 0: the block input was a skip concatenation [h | skip]; its gradient is written as two dense tensors
+// (dx = first `split` channels, *dx2 = the rest) so no slicing pass is needed afterwards.
+static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int split = 0, Tensor* dx2 = nullptr) {
   ishap_unet* u = e.u;
   const ResSaved& sv = L.sv;
   const Tensor& x = sv.x;
@@ -69,7 +71,18 @@ static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx) {
     add = dxs.p;
   }
   dx = x;
-  dx.p = aalloc<half_t>(e, x.numel());
+  if (split > 0) {
+    dx.C = split;
+    *dx2 = x;
+    dx2->C = x.C - split;
+    dx2->sums = nullptr;
+    dx.p = aalloc<half_t>(e, dx.numel());
+    dx2->p = aalloc<half_t>(e, dx2->numel());
+    g1.dx2 = dx2->p; g1.csplit = split;
+  } else {
+    dx.p = aalloc<half_t>(e, x.numel());
+  }
+  dx.sums = nullptr;
   g1.g = da.p; g1.add = add; g1.dx = dx.p;
   ISHAP_TRY(gn_bwd_op(e, g1));
   return 0;
@@ -108,7 +121,7 @@ static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx) {
   return 0;
 }
 
-static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out) {
+static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out, int split = 0, Tensor* out2 = nullptr) {
   ishap_unet* u = e.u;
   for (int i = (int)b.layers.size() - 1; i >= 0; --i) {
     const LayerRef& l = b.layers[i];
@@ -116,7 +129,8 @@ static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out) {
     if (l.kind == 0) {
       ISHAP_TRY(dgrad_op(e, u->stem, g, dx, u->in_pad));
     } else if (l.kind == 1) {
-      ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx));
+      if (i == 0 && split > 0) ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, split, out2));
+      else ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx));
     } else {
       ISHAP_TRY(attn_backward(e, u->attn[l.idx], g, dx));
     }
@@ -169,16 +183,10 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
   std::vector<Tensor> skipgrad(n_in);
   for (int i = F; i >= 0; --i) {
     BlockL& b = u->out_blocks[i];
-    Tensor gcat;
-    ISHAP_TRY(block_backward(e, b, g, gcat));
     const int Cs = b.skip_ch, Ch = b.cin - Cs;
-    Tensor gh{nullptr, gcat.N, gcat.H, gcat.W, Ch}, gs{nullptr, gcat.N, gcat.H, gcat.W, Cs};
-    gh.p = aalloc<half_t>(e, gh.numel());
-    gs.p = aalloc<half_t>(e, gs.numel());
-    if (!dry) {
-      ISHAP_TRY(slice_channels(gcat.p, gh.p, gcat.rows(), b.cin, 0, Ch, 0, s));
-      ISHAP_TRY(slice_channels(gcat.p, gs.p, gcat.rows(), b.cin, Ch, Cs, 0, s));
-    }
+    ISHAP_REQUIRE(b.layers[0].kind == 1 && Ch % 8 == 0, "an output block starts with a ResBlock on the concatenation");
+    Tensor gh, gs;
+    ISHAP_TRY(block_backward(e, b, g, gh, Ch, &gs));       // the first ResBlock writes d/d[h | skip] as two tensors
     skipgrad[n_in - 1 - i] = gs;     // hs.pop() order (unet.py:663)
     g = gh;
   }

@@ -7,7 +7,6 @@ int nhwc_f16_to_nchw(const half_t* src, void* dst, int out_f32, int N, int C, in
 int nchw_to_nhwc_f16_scaled(const void* src, int src_f32, half_t* dst, int N, int C, int HW, int ld, float mul, hipStream_t s);
 int concat2(const half_t* a, const half_t* b, half_t* o, long long M, int Ca, int Cb, hipStream_t s,
             const long long* sa = nullptr, const long long* sb = nullptr, long long* so = nullptr, int N = 1);
-int slice_channels(const half_t* src, half_t* o, long long M, int Cs, int off, int Co, int accumulate, hipStream_t s);
 int add_f16(const half_t* a, const half_t* b, half_t* o, long long n, hipStream_t s);
 struct TsArg { float t[16]; };   // timesteps by value: no host->device copy on the step path
 int timestep_embedding(const TsArg& t, float* out, int N, int dim, hipStream_t s);

@@ -112,32 +112,6 @@ int concat2(const half_t* a, const half_t* b, half_t* o, long long M, int Ca, in
   return 0;
 }
 
-// out[m][0:Co) (+)= src[m][off : off+Co)
-__global__ void slice_kernel(const half_t* __restrict__ src, half_t* __restrict__ o, long long M, int Cs, int off, int Co,
-                             int accumulate) {
-  const int CV = Co >> 3;
-  const long long total = M * CV;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    long long m = i / CV;
-    int cv = (int)(i % CV);
-    half8 v = *reinterpret_cast<const half8*>(src + m * Cs + off + cv * 8);
-    half8* dst = reinterpret_cast<half8*>(o + m * Co + cv * 8);
-    if (accumulate) {
-      half8 w = *dst;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)w[k]);
-    }
-    *dst = v;
-  }
-}
-int slice_channels(const half_t* src, half_t* o, long long M, int Cs, int off, int Co, int accumulate, hipStream_t s) {
-  long long total = M * (Co / 8);
-  int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(slice_kernel, dim3(blocks), dim3(256), 0, s, src, o, M, Cs, off, Co, accumulate);
-  ISHAP_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
 // o = a + b (fp16, fp32 add)
 __global__ void add_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, half_t* __restrict__ o, long long nvec) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {

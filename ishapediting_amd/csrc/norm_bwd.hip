@@ -144,12 +144,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
       if (a.add) v += ad[i];
       o[i] = (half_t)v;
     }
-    *reinterpret_cast<half8*>(a.dx + pix * a.C + c0) = o;
+    if (a.csplit == 0) *reinterpret_cast<half8*>(a.dx + pix * a.C + c0) = o;
+    else if (c0 < a.csplit) *reinterpret_cast<half8*>(a.dx + pix * a.csplit + c0) = o;
+    else *reinterpret_cast<half8*>(a.dx2 + pix * (a.C - a.csplit) + (c0 - a.csplit)) = o;
   }
 }
 
 int gn_backward_launch(const GnBwdArgs& a, hipStream_t s) {
   ISHAP_REQUIRE(a.C % 32 == 0 && a.C / 8 <= 256, "GroupNorm channels");
+  ISHAP_REQUIRE(a.csplit == 0 || (a.dx2 && a.csplit % 8 == 0 && a.csplit < a.C), "split output");
   const int HW = a.H * a.W;
   const int rpb = gn_rows_per_block(HW), nblk = HW / rpb, CV = a.C / 8;
   const int rpi = 256 / CV > 0 ? 256 / CV : 1;
