@@ -26,6 +26,13 @@ struct GnApplyArgs {
   int emb_ld = 0;
   int N = 1, H = 0, W = 0, C = 0;
   int film = 0, act = 1, pool = 0, split = 0;
+  // the input is the channel concatenation [x | x2] of two dense tensors (a skip connection): channels < csplit come
+  // from x (row stride csplit, sums `sums`), the rest from x2 (row stride C - csplit, sums `sums2`); the raw
+  // concatenation is also written to xcopy [N][H*W][C] for the consumers that need it.  Plain variant only (no pool/split).
+  const half_t* x2 = nullptr;
+  const long long* sums2 = nullptr;
+  half_t* xcopy = nullptr;
+  int csplit = 0;
 };
 int gn_apply_launch(const GnApplyArgs& a, hipStream_t s);
 

@@ -126,8 +126,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
       const int part = idx & 7, g = (idx >> 3) & 31, n = idx >> 8;
       float s = 0.f, q = 0.f;
       for (int c = g * cpg + part; c < (g + 1) * cpg; c += 8) {
-        s += (float)a.sums[((long long)n * a.C + c) * 2] * (1.f / STAT_SCALE_SUM);
-        q += (float)a.sums[((long long)n * a.C + c) * 2 + 1] * (1.f / STAT_SCALE_SQ);
+        const long long* sp = a.sums + ((long long)n * a.C + c) * 2;
+        if (a.x2) sp = c < a.csplit ? a.sums + ((long long)n * a.csplit + c) * 2
+                                    : a.sums2 + ((long long)n * (a.C - a.csplit) + (c - a.csplit)) * 2;
+        s += (float)sp[0] * (1.f / STAT_SCALE_SUM);
+        q += (float)sp[1] * (1.f / STAT_SCALE_SQ);
       }
 #pragma unroll
       for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
@@ -205,7 +208,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
       *reinterpret_cast<half8*>(a.out + pix * a.C + c0) = ov;
       if (a.xpool) *reinterpret_cast<half8*>(a.xpool + pix * a.C + c0) = xv;
     } else {
-      half8 v = *reinterpret_cast<const half8*>(a.x + pix * a.C + c0);
+      half8 v;
+      if (a.x2) {                                   // two-source input (skip concatenation); also emit the raw copy
+        v = c0 < a.csplit ? *reinterpret_cast<const half8*>(a.x + pix * a.csplit + c0)
+                          : *reinterpret_cast<const half8*>(a.x2 + pix * (a.C - a.csplit) + (c0 - a.csplit));
+        *reinterpret_cast<half8*>(a.xcopy + pix * a.C + c0) = v;
+      } else {
+        v = *reinterpret_cast<const half8*>(a.x + pix * a.C + c0);
+      }
       one(v, o);
       if (SPLIT) {
         half8 hi, lo;
@@ -226,6 +236,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
 }
 
 int gn_apply_launch(const GnApplyArgs& a, hipStream_t s) {
+  ISHAP_REQUIRE(!a.x2 || (a.sums && a.sums2 && a.xcopy && !a.pool && !a.split && a.csplit % 8 == 0 && a.csplit > 0 && a.csplit < a.C),
+                "two-source GroupNorm: sums of both halves, a copy target, plain variant");
   const int HWo = a.pool ? (a.H / 2) * (a.W / 2) : a.H * a.W;
   long long total = (long long)a.N * HWo * (a.C / 8);
   int blocks = (int)((total + 255) / 256);

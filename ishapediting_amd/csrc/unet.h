@@ -11,6 +11,10 @@ struct Tensor {
   half_t* p = nullptr;
   int N = 0, H = 0, W = 0, C = 0;
   long long* sums = nullptr;   // [N][C][2] per-channel (sum, sum of squares), fixed point, gathered by the producer; or null
+  // a skip concatenation that has not been materialised yet: p is the buffer the first consumer (the ResBlock's GroupNorm
+  // pass) fills while it reads the two halves (cat_a: first cat_ca channels with sums cat_sa; cat_b: the rest, sums cat_sb)
+  const half_t* cat_a = nullptr; const half_t* cat_b = nullptr; const long long* cat_sa = nullptr; const long long* cat_sb = nullptr;
+  int cat_ca = 0;
   long long rows() const { return (long long)N * H * W; }
   long long numel() const { return rows() * C; }
 };

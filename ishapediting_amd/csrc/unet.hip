@@ -291,7 +291,9 @@ static int res_forward(Exec& e, ResL& L, const Tensor& x, Tensor& y) {
   ISHAP_REQUIRE(x.C == L.cin, "ResBlock input channels");
   float* st1 = aalloc<float>(e, (size_t)N * 64);
   float* st2 = aalloc<float>(e, (size_t)N * 64);
-  if (!x.sums) ISHAP_TRY(gn_stats_op(e, x, st1));
+  const bool lazy_cat = x.cat_a != nullptr;
+  ISHAP_REQUIRE(!lazy_cat || (!L.down && !L.up), "a skip concatenation feeds a plain ResBlock");
+  if (!x.sums && !lazy_cat) ISHAP_TRY(gn_stats_op(e, x, st1));
   Tensor a{nullptr, N, L.down ? Ho : H, L.down ? Wo : W, L.cin};
   a.p = aalloc<half_t>(e, a.numel());
   Tensor xs = x;
@@ -301,6 +303,10 @@ static int res_forward(Exec& e, ResL& L, const Tensor& x, Tensor& y) {
     g.x = x.p; g.out = a.p; g.xpool = L.down ? xs.p : nullptr;
     g.stats = st1; g.sums = x.sums; g.stats_out = x.sums ? st1 : nullptr; g.gamma = L.n1.gamma; g.beta = L.n1.beta;
     g.N = N; g.H = H; g.W = W; g.C = L.cin; g.act = 1; g.pool = L.down;
+    if (lazy_cat) {
+      g.x = x.cat_a; g.x2 = x.cat_b; g.sums = x.cat_sa; g.sums2 = x.cat_sb; g.csplit = x.cat_ca; g.xcopy = x.p;
+      g.stats_out = st1;
+    }
     ISHAP_TRY(gn_apply_launch(g, e.s));
   }
   Tensor h1{nullptr, N, Ho, Wo, L.cout};
@@ -439,8 +445,13 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     Tensor cat{nullptr, h.N, h.H, h.W, h.C + skip.C};
     ISHAP_REQUIRE(skip.H == h.H && cat.C == b.cin, "skip connection shape");
     cat.p = aalloc<half_t>(e, cat.numel());
-    cat.sums = (h.sums && skip.sums) ? salloc(e, (size_t)cat.N * cat.C * 2) : nullptr;
-    if (!dry) ISHAP_TRY(concat2(h.p, skip.p, cat.p, cat.rows(), h.C, skip.C, s, h.sums, skip.sums, cat.sums, cat.N));
+    if (h.sums && skip.sums && h.C % 8 == 0 && b.layers[0].kind == 1) {
+      // no copy pass: the ResBlock's first GroupNorm reads both halves and writes the concatenation as it goes
+      cat.cat_a = h.p; cat.cat_b = skip.p; cat.cat_sa = h.sums; cat.cat_sb = skip.sums; cat.cat_ca = h.C;
+    } else {
+      cat.sums = (h.sums && skip.sums) ? salloc(e, (size_t)cat.N * cat.C * 2) : nullptr;
+      if (!dry) ISHAP_TRY(concat2(h.p, skip.p, cat.p, cat.rows(), h.C, skip.C, s, h.sums, skip.sums, cat.sums, cat.N));
+    }
     b.cat = cat;
     Tensor y;
     ISHAP_TRY(block_forward(e, b, cat, y));
