@@ -38,7 +38,9 @@ static int dgrad_op(Exec& e, const ConvW& c, const Tensor& dy, Tensor& dx_out, i
 
 // `split` > 0: the block input was a skip concatenation [h | skip]; its gradient is written as two dense tensors
 // (dx = first `split` channels, *dx2 = the rest) so no slicing pass is needed afterwards.
-static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int split = 0, Tensor* dx2 = nullptr) {
+// `add2`: a gradient map of the block input's shape (the skip-connection gradient of an input block) added to the result.
+static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int split = 0, Tensor* dx2 = nullptr,
+                        const half_t* add2 = nullptr) {
   ishap_unet* u = e.u;
   const ResSaved& sv = L.sv;
   const Tensor& x = sv.x;
@@ -83,7 +85,7 @@ static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int spli
     dx.p = aalloc<half_t>(e, x.numel());
   }
   dx.sums = nullptr;
-  g1.g = da.p; g1.add = add; g1.dx = dx.p;
+  g1.g = da.p; g1.add = add; g1.dx = dx.p; g1.add2 = add2;
   ISHAP_TRY(gn_bwd_op(e, g1));
   return 0;
 }
@@ -121,7 +123,8 @@ static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx) {
   return 0;
 }
 
-static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out, int split = 0, Tensor* out2 = nullptr) {
+static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out, int split = 0, Tensor* out2 = nullptr,
+                          const half_t* add2 = nullptr, bool* add2_done = nullptr) {
   ishap_unet* u = e.u;
   for (int i = (int)b.layers.size() - 1; i >= 0; --i) {
     const LayerRef& l = b.layers[i];
@@ -130,6 +133,7 @@ static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out, int split =
       ISHAP_TRY(dgrad_op(e, u->stem, g, dx, u->in_pad));
     } else if (l.kind == 1) {
       if (i == 0 && split > 0) ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, split, out2));
+      else if (i == 0 && add2) { ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, 0, nullptr, add2)); *add2_done = true; }
       else ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx));
     } else {
       ISHAP_TRY(attn_backward(e, u->attn[l.idx], g, dx));
@@ -190,21 +194,27 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
     skipgrad[n_in - 1 - i] = gs;     // hs.pop() order (unet.py:663)
     g = gh;
   }
-  {
+  // The gradient entering input block i is (gradient from the block after it) + (its skip-connection gradient).  When the
+  // block after it ends its backward with a ResBlock (always, except the stem), that ResBlock's last kernel adds the skip
+  // gradient itself; `pending` is the addend still owed when that was not possible.
+  auto run = [&](BlockL& blk, const half_t* owed_next, const half_t*& pending) -> int {
+    bool done = false;
     Tensor o;
-    ISHAP_TRY(block_backward(e, u->mid, g, o));
+    ISHAP_TRY(block_backward(e, blk, g, o, 0, nullptr, owed_next, &done));
     g = o;
-  }
+    pending = (owed_next && !done) ? owed_next : nullptr;
+    return 0;
+  };
+  const half_t* pending = nullptr;
+  ISHAP_TRY(run(u->mid, n_in > 0 ? skipgrad[n_in - 1].p : nullptr, pending));
   for (int i = n_in - 1; i >= 0; --i) {
-    if (skipgrad[i].p) {
+    if (pending) {                       // fall-back: a separate add
       Tensor sum = g;
       sum.p = aalloc<half_t>(e, g.numel());
-      if (!dry) ISHAP_TRY(add_f16(g.p, skipgrad[i].p, sum.p, g.numel(), s));
+      if (!dry) ISHAP_TRY(add_f16(g.p, pending, sum.p, g.numel(), s));
       g = sum;
     }
-    Tensor o;
-    ISHAP_TRY(block_backward(e, u->in_blocks[i], g, o));
-    g = o;
+    ISHAP_TRY(run(u->in_blocks[i], i > 0 ? skipgrad[i - 1].p : nullptr, pending));
   }
   if (!dry)
     ISHAP_TRY(nhwc_f16_to_nchw_f32_scaled(g.p, dx, N, cfg.in_channels, cfg.image_size * cfg.image_size, u->in_pad,

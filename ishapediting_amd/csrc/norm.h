@@ -44,6 +44,7 @@ struct GnBwdArgs {
   const half_t* g = nullptr;      // upstream gradient: [N][H*W][C] (SAME), [N][H/2*W/2][C] (UNPOOL: each /4), [N][2H*2W][C] (SUM4)
   const half_t* x = nullptr;      // GN input [N][H*W][C]
   const half_t* add = nullptr;    // optional extra gradient added to dx, same indexing mode as g
+  const half_t* add2 = nullptr;   // optional second addend at the OUTPUT resolution, dense [N][H*W][C] (a skip-connection gradient)
   half_t* dx = nullptr;           // [N][H*W][C], or the first `csplit` channels when the output is split
   half_t* dx2 = nullptr;          // channels csplit..C-1 as their own dense tensor (the two halves of a skip concatenation)
   int csplit = 0;                 // 0: one dense output; else a multiple of 8

@@ -135,6 +135,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
     load_upstream(a.g, a.gmode, n, y, x, a.H, a.W, a.C, c0, up);
     const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.C + c0);
     if (a.add) load_upstream(a.add, a.gmode, n, y, x, a.H, a.W, a.C, c0, ad);
+    half8 a2 = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.add2) a2 = *reinterpret_cast<const half8*>(a.add2 + pix * a.C + c0);
     half8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
       gn_bwd_term(up[i], (float)xv[i], mu[i], rs[i], gam[i], bet[i], esc[i], esh[i], FILM, ACT, dyh, xh);
       float v = rs[i] * (dyh - m1[i] - xh * m2[i]);
       if (a.add) v += ad[i];
+      if (a.add2) v = (float)(half_t)v + (float)a2[i];      // same rounding as a separate fp16 add of the two gradient maps
       o[i] = (half_t)v;
     }
     if (a.csplit == 0) *reinterpret_cast<half8*>(a.dx + pix * a.C + c0) = o;
