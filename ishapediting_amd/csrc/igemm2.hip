@@ -16,8 +16,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 #define IG2_LOADERS 4          // loader waves per workgroup (4 measured faster than 8)
 #endif
 
-template <int BM, int BN, int NST, bool CONV3>
-__global__ __launch_bounds__(256 + 64 * IG2_LOADERS) void igemm2_kernel(IgemmArgs a) {
+// HALVES = 2: the workgroup is two such 8-wave teams, each with its own ring, working on the two halves of the K range
+// and meeting once in LDS at the end -- split-K by two without partial tiles in HBM or a reduce launch.  It gives a CU
+// that holds a single workgroup (grids of <= 256 tiles) the DMA/MFMA overlap two co-resident workgroups would have.
+template <int BM, int BN, int NST, bool CONV3, int HALVES = 1>
+__global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kernel(IgemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only builtins; the host pass only needs the launch stub
   constexpr int BK = 64;
   constexpr int CPR = 8;                 // 16-byte chunks per tile row
@@ -28,13 +31,15 @@ __global__ __launch_bounds__(256 + 64 * IG2_LOADERS) void igemm2_kernel(IgemmArg
   constexpr int TMW = BM / 2, TNW = BN / 2;
   constexpr int MT = TMW / 16, NT = TNW / 16;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  half_t* lds = reinterpret_cast<half_t*>(smem_raw);
 
   // 8 waves: 0-3 compute (2x2 MFMA sub-tiles), 4-7 only issue the global->LDS DMA.  A DMA instruction costs its wave
   // ~150 cycles of issue time; on dedicated loader waves that time overlaps the consumers' MFMAs instead of preceding them.
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = HALVES == 2 ? wave_all / (4 + IG2_LOADERS) : 0;
+  const int wave8 = wave_all - team * (4 + IG2_LOADERS);
+  half_t* lds = reinterpret_cast<half_t*>(smem_raw) + team * (NST * STAGE);
   const bool loader = wave8 >= 4;
   constexpr int LSPLIT = IG2_LOADERS / 4;               // loader waves sharing one consumer-wave's worth of DMA instructions
   const int wave = loader ? (wave8 - 4) / LSPLIT : wave8;
@@ -66,9 +71,16 @@ __global__ __launch_bounds__(256 + 64 * IG2_LOADERS) void igemm2_kernel(IgemmArg
   const half_t* Wt = a.Wt + (long long)batch * a.bsw;
   const int KS = a.K / BK;
   const int per = (KS + a.ksplit - 1) / a.ksplit;
-  const int ks0 = ks_id * per;
-  const int ks1 = min(KS, ks0 + per);
-  const int nk = ks1 - ks0;
+  int ks0 = ks_id * per;
+  int ks1 = min(KS, ks0 + per);
+  int nk_loop = ks1 - ks0;                       // barrier count: identical for every wave of the workgroup
+  if (HALVES == 2) {
+    const int half_n = (ks1 - ks0 + 1) / 2;      // team 0 takes the larger half
+    nk_loop = half_n;
+    ks0 += team * half_n;
+    ks1 = min(ks1, ks0 + half_n);
+  }
+  const int nk = max(0, ks1 - ks0);
   const int HW = a.H * a.W;
 
   // ---- loader state: instruction i of this wave covers tile rows (wave*XI + i)*8 .. +7.  K order is tap-outer,
@@ -163,8 +175,8 @@ __global__ __launch_bounds__(256 + 64 * IG2_LOADERS) void igemm2_kernel(IgemmArg
       if (s < nk) issue(s);
   }
 
-  for (int k = 0; k < nk; ++k) {
-    if (loader) {
+  for (int k = 0; k < nk_loop; ++k) {
+    if (loader && k < nk) {
       // stage k must have landed: stages up to min(nk, k+NST-1)-1 are issued, (XI+WI) instructions each
       if (k + NST - 1 <= nk) {
       #if defined(ABL_NOX)
@@ -184,6 +196,7 @@ __global__ __launch_bounds__(256 + 64 * IG2_LOADERS) void igemm2_kernel(IgemmArg
       if (k + NST - 1 < nk) issue((k + NST - 1) % NST);
       continue;
     }
+    if (k >= nk) continue;                       // the shorter half (odd step count) idles through the last barrier
     const half_t* bx = lds + (k % NST) * STAGE;
     const half_t* bw = bx + BM * BK;
 #pragma unroll
@@ -215,22 +228,42 @@ __global__ __launch_bounds__(256 + 64 * IG2_LOADERS) void igemm2_kernel(IgemmArg
     }
   }
 
-  igemm_epilogue<MT, NT, TMW, TNW, BN>(a, acc, m0, n0, wm, wn, lane, batch, ks_id, reinterpret_cast<float*>(smem_raw), !loader);
+  if (HALVES == 2) {
+    // team 1 hands its accumulators to team 0 through (its own, now idle) ring memory
+    f32x4* red = reinterpret_cast<f32x4*>(reinterpret_cast<half_t*>(smem_raw) + NST * STAGE);
+    __syncthreads();                             // every fragment read of the K loop is done
+    if (!loader && team == 1) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) red[((i * MT + j) * 4 + wave) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (!loader && team == 0) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] += red[((i * MT + j) * 4 + wave) * 64 + lane];
+    }
+  }
+  igemm_epilogue<MT, NT, TMW, TNW, BN>(a, acc, m0, n0, wm, wn, lane, batch, ks_id, reinterpret_cast<float*>(smem_raw),
+                                       !loader && team == 0);
 #endif
 }
 
-template <int BM, int BN, int NST, bool CONV3>
+template <int BM, int BN, int NST, bool CONV3, int HALVES = 1>
 static int launch2(const IgemmArgs& a, hipStream_t s) {
-  constexpr size_t smem = (size_t)NST * (BM + BN) * 64 * sizeof(half_t);
-  auto kern = igemm2_kernel<BM, BN, NST, CONV3>;
+  constexpr size_t smem = (size_t)HALVES * NST * (BM + BN) * 64 * sizeof(half_t);
+  static_assert(smem <= 163840, "LDS");
+  auto kern = igemm2_kernel<BM, BN, NST, CONV3, HALVES>;
   static bool attr_set = false;
   if (!attr_set) {
     ISHAP_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
-  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(256 + 64 * IG2_LOADERS), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a);
-  else hipLaunchKernelGGL(kern, grid, dim3(256 + 64 * IG2_LOADERS), smem, s, a);
+  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3((256 + 64 * IG2_LOADERS) * HALVES), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a);
+  else hipLaunchKernelGGL(kern, grid, dim3((256 + 64 * IG2_LOADERS) * HALVES), smem, s, a);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -241,5 +274,11 @@ int igemm2_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
 #ifndef IG2_SMALL_NST
 #define IG2_SMALL_NST 4
 #endif
+  // one workgroup per CU at most and a K slice long enough to split: the two-team variant
+  static const int halves = [] { const char* e = getenv("ISHAP_HALVES"); return e ? atoi(e) : 2; }();
+  const long long tiles = (long long)(a.M / 64) * ((a.N + 63) / 64) * a.nbatch * a.ksplit;
+  const int steps = (a.K / 64 + a.ksplit - 1) / a.ksplit;
+  if (halves == 2 && a.conv3 && tiles <= 256 && steps >= 16)      // measured: +4..16 % there, a loss on short slices and 1x1
+    return a.conv3 ? launch2<64, 64, 4, true, 2>(a, s) : launch2<64, 64, 4, false, 2>(a, s);
   return a.conv3 ? launch2<64, 64, IG2_SMALL_NST, true>(a, s) : launch2<64, 64, IG2_SMALL_NST, false>(a, s);
 }
