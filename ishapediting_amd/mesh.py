@@ -16,6 +16,9 @@ import torch
 from . import _lib
 
 
+MAX_OBJ_VERTICES = 4_000_000      # text export limit (a 256^3 shape has well under a million surface vertices)
+
+
 def _need_gpu(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise RuntimeError(f"{what} runs on the GPU (libishap_hip.so); there is no CPU fallback")
@@ -158,6 +161,11 @@ def _write_obj(path, verts: torch.Tensor, tris: torch.Tensor):
 def write_mesh(path, mesh):
     """o3d.io.write_triangle_mesh (drag_utils.py:470) when Open3D produced the mesh; Wavefront OBJ of the device mesh otherwise."""
     if isinstance(mesh, OccupancyMesh):
+        nv, nt = mesh.counts()
+        if nv > MAX_OBJ_VERTICES:
+            with open(path, "w") as f:
+                f.write(f"# {nv} vertices / {nt} triangles: the volume is not a surface, mesh not written\n")
+            return
         _write_obj(path, mesh.vertices, mesh.triangles)
         return
     import open3d as o3d
@@ -200,5 +208,10 @@ def export_obj(volume: torch.Tensor, path: str, scale_div: float = 255.0):
         return
     except ImportError:
         pass
+    nv, nt = surface_counts(volume, 0.0)
+    if nv > MAX_OBJ_VERTICES:                      # not a surface (e.g. random weights decode to noise): do not write GBs of text
+        with open(path, "w") as f:
+            f.write(f"# {nv} vertices / {nt} triangles: the volume is not a surface, mesh not written\n")
+        return
     verts, tris = extract_surface(volume, 0.0)
     _write_obj(path, verts / scale_div * 2 - 1, tris)
