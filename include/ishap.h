@@ -187,6 +187,19 @@ int ishap_mesh_smooth(float* verts, long long nverts, const int* tris, long long
  * reference's chamfer distance); nearest: device scratch float[max(na, nb)] */
 int ishap_chamfer(const float* a, long long na, const float* b, long long nb, float* nearest, float* out2, void* stream);
 
+/* ------------------------------------------------------------------ occupancy samples of an input mesh (8(f) rank 2)
+ * Replaces the Open3D calls of train_triplane's data preparation (drag_utils.py:411-440): mesh.sample_points_uniformly
+ * (area-weighted triangle choice -- the caller draws the triangle indices from `areas` and the uniforms) and
+ * RaycastingScene.compute_occupancy (here: parity of the crossings of the +x ray with the closed triangle mesh).
+ * verts: device float[3*nverts]; tris: device int[3*ntris]. */
+int ishap_mesh_tri_areas(const float* verts, const int* tris, long long ntris, float* areas, void* stream);
+/* pts[i] = uniform point of triangle tri_idx[i] from the uniforms uw[2i], uw[2i+1] */
+int ishap_mesh_points_on_tris(const float* verts, const int* tris, const int* tri_idx, const float* uw, long long n,
+                              float* pts, void* stream);
+/* occ[i] = 1 inside / 0 outside */
+int ishap_mesh_occupancy(const float* verts, const int* tris, long long ntris, const float* pts, long long npts,
+                         float* occ, void* stream);
+
 /* ------------------------------------------------------------------ measurement aid (bench.py roofline leg)
  * Brackets every implicit-GEMM launch with HIP events on its own stream between begin and end.
  * out[v*3+{0,1,2}] = {launches, total ms, algorithmic FLOPs}; v: 0 conv3x3 128^2 tile, 1 conv3x3 64^2 tile,

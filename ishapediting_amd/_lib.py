@@ -77,6 +77,9 @@ SYMBOLS = {
     "ishap_surface_emit": (C.c_int, [c_void_p, C.c_int, C.c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ishap_mesh_smooth": (C.c_int, [c_void_p, C.c_longlong, c_void_p, C.c_longlong, C.c_int, c_void_p, c_void_p]),
     "ishap_chamfer": (C.c_int, [c_void_p, C.c_longlong, c_void_p, C.c_longlong, c_void_p, c_void_p, c_void_p]),
+    "ishap_mesh_tri_areas": (C.c_int, [c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
+    "ishap_mesh_points_on_tris": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
+    "ishap_mesh_occupancy": (C.c_int, [c_void_p, c_void_p, C.c_longlong, c_void_p, C.c_longlong, c_void_p, c_void_p]),
     "ishap_profile_begin": (C.c_int, []),
     "ishap_profile_end": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "ishap_profile_shapes": (C.c_int, [C.c_char_p, C.c_int]),

@@ -294,6 +294,69 @@ __global__ __launch_bounds__(1024) void mean_kernel(const float* __restrict__ x,
   if (threadIdx.x == 0) out[0] = n > 0 ? (float)(red[0] / (double)n) : 0.f;
 }
 
+// ---- occupancy sampling of an input mesh (drag_utils.py:411-440: Open3D sample_points_uniformly + RaycastingScene
+//      .compute_occupancy in the reference) ----------------------------------------------------------------------------
+__global__ void tri_area_kernel(const float* __restrict__ v, const int* __restrict__ t, long long nt, float* __restrict__ area) {
+  const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nt) return;
+  const float* A = v + 3LL * t[3 * f]; const float* B = v + 3LL * t[3 * f + 1]; const float* C = v + 3LL * t[3 * f + 2];
+  const float ux = B[0] - A[0], uy = B[1] - A[1], uz = B[2] - A[2];
+  const float wx = C[0] - A[0], wy = C[1] - A[1], wz = C[2] - A[2];
+  const float cx = uy * wz - uz * wy, cy = uz * wx - ux * wz, cz = ux * wy - uy * wx;
+  area[f] = 0.5f * sqrtf(cx * cx + cy * cy + cz * cz);
+}
+// uniform point on triangle f = idx[i] from two uniforms (u, w): (1-sqrt(u)) A + sqrt(u)(1-w) B + sqrt(u) w C
+__global__ void tri_point_kernel(const float* __restrict__ v, const int* __restrict__ t, const int* __restrict__ idx,
+                                 const float* __restrict__ uw, long long n, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long f = idx[i];
+  const float* A = v + 3LL * t[3 * f]; const float* B = v + 3LL * t[3 * f + 1]; const float* C = v + 3LL * t[3 * f + 2];
+  const float su = sqrtf(uw[2 * i]), w = uw[2 * i + 1];
+  const float a = 1.f - su, b = su * (1.f - w), c = su * w;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) out[3 * i + k] = a * A[k] + b * B[k] + c * C[k];
+}
+// inside / outside by the parity of the crossings of the ray p + s*(1,0,0), s > 0.  Triangles are staged through LDS
+// (256 at a time); a thread owns one point.  A crossing needs the point's (y,z) strictly inside the triangle's (y,z)
+// projection, so rays through an edge or a vertex (measure zero for random samples) are not counted.
+__global__ __launch_bounds__(256) void occupancy_kernel(const float* __restrict__ v, const int* __restrict__ t, long long nt,
+                                                        const float* __restrict__ pts, long long np, float* __restrict__ occ) {
+  __shared__ float tri[256][9];
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (i < np) { px = pts[3 * i]; py = pts[3 * i + 1]; pz = pts[3 * i + 2]; }
+  unsigned crossings = 0;
+  for (long long f0 = 0; f0 < nt; f0 += 256) {
+    const int m = (int)min(256LL, nt - f0);
+    __syncthreads();
+    if ((int)threadIdx.x < m) {
+      const long long f = f0 + threadIdx.x;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* P = v + 3LL * t[3 * f + c];
+        tri[threadIdx.x][3 * c] = P[0]; tri[threadIdx.x][3 * c + 1] = P[1]; tri[threadIdx.x][3 * c + 2] = P[2];
+      }
+    }
+    __syncthreads();
+    for (int k = 0; k < m; ++k) {
+      // barycentric coordinates in the (y,z) plane relative to vertex A: differences of nearby numbers stay accurate
+      // however far the point is; a triangle seen edge-on (negligible projected area) cannot be crossed
+      const float uy = tri[k][4] - tri[k][1], uz = tri[k][5] - tri[k][2];
+      const float wy = tri[k][7] - tri[k][1], wz = tri[k][8] - tri[k][2];
+      const float qy = py - tri[k][1], qz = pz - tri[k][2];
+      const float D = uy * wz - uz * wy;
+      if (fabsf(D) <= 1e-6f * (fabsf(uy) + fabsf(uz)) * (fabsf(wy) + fabsf(wz))) continue;
+      const float sB = (qy * wz - qz * wy) / D, sC = (uy * qz - uz * qy) / D;
+      if (sB > 0.f && sC > 0.f && sB + sC < 1.f) {
+        const float xh = tri[k][0] + sB * (tri[k][3] - tri[k][0]) + sC * (tri[k][6] - tri[k][0]);
+        crossings += xh > px ? 1u : 0u;
+      }
+    }
+  }
+  if (i < np) occ[i] = (crossings & 1u) ? 1.f : 0.f;
+}
+
 int fill(SurfArgs& a, const float* volume, int res, float level, void* scratch, unsigned* counts) {
   ISHAP_REQUIRE(volume && scratch && res >= 2 && res <= 1024, "surface: volume, scratch and 2 <= res <= 1024");
   a.vol = volume; a.res = res; a.level = level; a.n = (long long)res * res * res;
@@ -360,6 +423,30 @@ extern "C" int ishap_chamfer(const float* a, long long na, const float* b, long 
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, nearest, na, out2);
   hipLaunchKernelGGL(nearest_sq_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, b, nb, a, na, nearest);
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, nearest, nb, out2 + 1);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ishap_mesh_tri_areas(const float* verts, const int* tris, long long ntris, float* areas, void* stream) {
+  ISHAP_REQUIRE(verts && tris && areas && ntris > 0, "mesh_tri_areas arguments");
+  hipLaunchKernelGGL(tri_area_kernel, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts, tris, ntris, areas);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ishap_mesh_points_on_tris(const float* verts, const int* tris, const int* tri_idx, const float* uw, long long n,
+                                         float* pts, void* stream) {
+  ISHAP_REQUIRE(verts && tris && tri_idx && uw && pts && n > 0, "mesh_points_on_tris arguments");
+  hipLaunchKernelGGL(tri_point_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts, tris, tri_idx, uw, n, pts);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ishap_mesh_occupancy(const float* verts, const int* tris, long long ntris, const float* pts, long long npts,
+                                    float* occ, void* stream) {
+  ISHAP_REQUIRE(verts && tris && pts && occ && ntris > 0 && npts > 0, "mesh_occupancy arguments");
+  hipLaunchKernelGGL(occupancy_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts, tris, ntris, pts,
+                     npts, occ);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

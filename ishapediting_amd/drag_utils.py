@@ -351,7 +351,7 @@ class DragStuff:
             return
         if points is None:
             points, occupancies = mesh_backend.sample_occupancy(mesh, mesh_path, center_mesh, self.args.points_size,
-                                                                self.args.points_uniform_ratio)
+                                                                self.args.points_uniform_ratio, device=self.device)
             if points is None:
                 return
         points = th.as_tensor(np.asarray(points), dtype=th.float32).to(self.device)

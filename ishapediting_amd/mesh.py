@@ -172,29 +172,109 @@ def write_mesh(path, mesh):
     o3d.io.write_triangle_mesh(path, mesh)
 
 
-def sample_occupancy(mesh, mesh_path, center_mesh, points_size, uniform_ratio):
-    """drag_utils.py:411-440 via Open3D (RaycastingScene); returns (None, None) when no mesh is given."""
+def read_obj(path: str):
+    """Minimal Wavefront OBJ reader (v / f records, polygons fan-triangulated): (vertices [V,3] float32, triangles [F,3] int32)."""
+    vs, fs = [], []
+    with open(path) as fh:
+        for line in fh:
+            p = line.split()
+            if not p:
+                continue
+            if p[0] == "v":
+                vs.append([float(p[1]), float(p[2]), float(p[3])])
+            elif p[0] == "f":
+                idx = [int(t.split("/")[0]) for t in p[1:]]
+                idx = [i - 1 if i > 0 else len(vs) + i for i in idx]
+                fs.extend([idx[0], idx[k], idx[k + 1]] for k in range(1, len(idx) - 1))
+    return np.asarray(vs, np.float32).reshape(-1, 3), np.asarray(fs, np.int32).reshape(-1, 3)
+
+
+def mesh_occupancy(verts: torch.Tensor, tris: torch.Tensor, points: torch.Tensor) -> torch.Tensor:
+    """RaycastingScene.compute_occupancy of the reference (drag_utils.py:437-440) on the device: 1 inside / 0 outside the
+    closed triangle mesh, by ray parity.  verts [V,3], tris [F,3], points [P,3] -> [P] float32."""
+    _need_gpu(verts, "mesh_occupancy")
+    dev = verts.device
+    v = verts.detach().to(torch.float32).contiguous()
+    t = tris.detach().to(device=dev, dtype=torch.int32).contiguous()
+    p = points.detach().to(device=dev, dtype=torch.float32).contiguous()
+    occ = torch.empty(p.shape[0], dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ishap_mesh_occupancy(v.data_ptr(), t.data_ptr(), t.shape[0], p.data_ptr(), p.shape[0], occ.data_ptr(),
+                                                   _lib.stream_ptr(dev)))
+    return occ
+
+
+def sample_surface_points(verts: torch.Tensor, tris: torch.Tensor, n: int, generator=None) -> torch.Tensor:
+    """mesh.sample_points_uniformly(n) (drag_utils.py:432): triangles drawn with probability proportional to their area,
+    a uniform point on each.  The random draws are torch's (plumbing); areas and points are computed by the library."""
+    _need_gpu(verts, "sample_surface_points")
+    dev = verts.device
+    v = verts.detach().to(torch.float32).contiguous()
+    t = tris.detach().to(device=dev, dtype=torch.int32).contiguous()
+    areas = torch.empty(t.shape[0], dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        _lib.check(L.ishap_mesh_tri_areas(v.data_ptr(), t.data_ptr(), t.shape[0], areas.data_ptr(), _lib.stream_ptr(dev)))
+        idx = torch.multinomial(areas.double().cpu(), n, replacement=True, generator=generator).to(device=dev, dtype=torch.int32)
+        uw = torch.rand((n, 2), generator=generator).to(dev).contiguous()
+        pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        _lib.check(L.ishap_mesh_points_on_tris(v.data_ptr(), t.data_ptr(), idx.data_ptr(), uw.data_ptr(), n, pts.data_ptr(),
+                                               _lib.stream_ptr(dev)))
+    return pts
+
+
+def sample_occupancy(mesh, mesh_path, center_mesh, points_size, uniform_ratio, device=None, generator=None):
+    """drag_utils.py:411-440: `points_size` samples (a `uniform_ratio` share uniform in [-1,1]^3, the rest on the surface
+    plus N(0, 0.01) noise) with their occupancy.  Open3D (RaycastingScene) when importable, exactly as the reference;
+    otherwise the mesh (an OBJ file, or a (vertices, triangles) pair) is sampled on the device.
+    Returns (None, None) when no mesh is given."""
     if mesh is None and mesh_path is None:
         return None, None
-    import open3d as o3d        # required for this route, exactly as in the reference
-    if mesh is None:
-        mesh = o3d.io.read_triangle_mesh(mesh_path)
-    if center_mesh:
-        max_bound, min_bound = mesh.get_max_bound(), mesh.get_min_bound()
-        axis_extent = max_bound - min_bound
-        if np.any(min_bound > 1) or np.any(min_bound < -1) or np.any(max_bound > 1) or np.any(max_bound < -1):
-            mesh.translate(-mesh.get_center())
-            if axis_extent.max() > 2:
-                mesh.scale(2. / (axis_extent.max() + 1e-2), center=np.array([0., 0, 0]))
+    try:
+        import open3d as o3d
+    except ImportError:
+        o3d = None
+    if o3d is not None and not isinstance(mesh, tuple):
+        if mesh is None:
+            mesh = o3d.io.read_triangle_mesh(mesh_path)
+        if center_mesh:
+            max_bound, min_bound = mesh.get_max_bound(), mesh.get_min_bound()
+            axis_extent = max_bound - min_bound
+            if np.any(min_bound > 1) or np.any(min_bound < -1) or np.any(max_bound > 1) or np.any(max_bound < -1):
+                mesh.translate(-mesh.get_center())
+                if axis_extent.max() > 2:
+                    mesh.scale(2. / (axis_extent.max() + 1e-2), center=np.array([0., 0, 0]))
+        n_uniform = int(points_size * uniform_ratio)
+        uniform = (np.random.rand(n_uniform, 3) * 2 - 1).astype(np.float32)
+        surf = np.asarray(mesh.sample_points_uniformly(points_size - n_uniform).points, dtype=np.float32)
+        surf += 0.01 * np.random.randn(surf.shape[0], 3)
+        pts = np.concatenate([uniform, surf], axis=0).astype(np.float32)
+        scene = o3d.t.geometry.RaycastingScene()
+        scene.add_triangles(o3d.t.geometry.TriangleMesh().from_legacy(mesh_legacy=mesh))
+        occ = scene.compute_occupancy(pts).numpy().reshape(-1, 1).astype(np.float32)
+        return pts, occ
+    # ---- device route ----
+    if isinstance(mesh, tuple):
+        v_np, t_np = np.asarray(mesh[0], np.float32), np.asarray(mesh[1], np.int32)
+    else:
+        v_np, t_np = read_obj(mesh_path)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    v = torch.from_numpy(v_np).to(dev)
+    t = torch.from_numpy(t_np).to(dev)
+    if center_mesh:                                              # drag_utils.py:420-428
+        mx, mn = v.max(dim=0).values, v.min(dim=0).values
+        if bool((mn > 1).any() or (mn < -1).any() or (mx > 1).any() or (mx < -1).any()):
+            v = v - v.mean(dim=0)                                # get_center() = mean of the vertices
+            ext = float((mx - mn).max())
+            if ext > 2:
+                v = v * (2. / (ext + 1e-2))
     n_uniform = int(points_size * uniform_ratio)
-    uniform = (np.random.rand(n_uniform, 3) * 2 - 1).astype(np.float32)
-    surf = np.asarray(mesh.sample_points_uniformly(points_size - n_uniform).points, dtype=np.float32)
-    surf += 0.01 * np.random.randn(surf.shape[0], 3)
-    pts = np.concatenate([uniform, surf], axis=0).astype(np.float32)
-    scene = o3d.t.geometry.RaycastingScene()
-    scene.add_triangles(o3d.t.geometry.TriangleMesh().from_legacy(mesh_legacy=mesh))
-    occ = scene.compute_occupancy(pts).numpy().reshape(-1, 1).astype(np.float32)
-    return pts, occ
+    uniform = (torch.rand((n_uniform, 3), generator=generator) * 2 - 1).to(dev)
+    surf = sample_surface_points(v, t, points_size - n_uniform, generator)
+    surf = surf + 0.01 * torch.randn(surf.shape, generator=generator).to(dev)
+    pts = torch.cat([uniform, surf], dim=0).contiguous()
+    occ = mesh_occupancy(v, t, pts)
+    return pts.cpu().numpy(), occ.reshape(-1, 1).cpu().numpy()
 
 
 def export_obj(volume: torch.Tensor, path: str, scale_div: float = 255.0):

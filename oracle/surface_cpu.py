@@ -129,3 +129,26 @@ def smooth_simple(verts: torch.Tensor, faces: torch.Tensor, iterations: int = 10
         acc = torch.zeros_like(v).index_add_(0, e[:, 0], v[e[:, 1]])
         v = (v + acc) / (1.0 + n).unsqueeze(1)
     return v.float()
+
+
+def mesh_occupancy(verts: torch.Tensor, faces: torch.Tensor, points: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
+    """Ray-parity occupancy (the device kernel's rule: crossings of p + s*(1,0,0), s > 0, counted when the point's (y,z)
+    is strictly inside the triangle's (y,z) projection; barycentric form about a triangle vertex, edge-on triangles skipped).  Stands in for Open3D's RaycastingScene.compute_occupancy
+    (drag_utils.py:437-440), which is absent here."""
+    v = verts.float()
+    A, B, C = v[faces[:, 0].long()], v[faces[:, 1].long()], v[faces[:, 2].long()]
+    out = torch.empty(points.shape[0])
+    for i in range(0, points.shape[0], chunk):
+        p = points[i:i + chunk].float()
+        uy, uz = (B[:, 1] - A[:, 1])[None], (B[:, 2] - A[:, 2])[None]
+        wy, wz = (C[:, 1] - A[:, 1])[None], (C[:, 2] - A[:, 2])[None]
+        qy, qz = p[:, None, 1] - A[None, :, 1], p[:, None, 2] - A[None, :, 2]
+        D = uy * wz - uz * wy
+        ok = D.abs() > 1e-6 * (uy.abs() + uz.abs()) * (wy.abs() + wz.abs())       # edge-on triangles cannot be crossed
+        Ds = torch.where(ok, D, torch.ones_like(D))
+        sB, sC = (qy * wz - qz * wy) / Ds, (uy * qz - uz * qy) / Ds
+        hit = ok & (sB > 0) & (sC > 0) & (sB + sC < 1)
+        xh = A[None, :, 0] + sB * (B[:, 0] - A[:, 0])[None] + sC * (C[:, 0] - A[:, 0])[None]
+        cross = hit & (xh > p[:, None, 0])
+        out[i:i + chunk] = (cross.sum(dim=1) % 2).float()
+    return out

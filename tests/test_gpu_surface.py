@@ -121,3 +121,33 @@ def test_occupancy_mesh_and_obj_export(tmp_path):
         assert sum(l.startswith("v ") for l in lines) == nv and sum(l.startswith("f ") for l in lines) == nt
     export_obj(vol, str(tmp_path / "e.obj"), scale_div=31.0)
     assert open(tmp_path / "e.obj").read().startswith("v ")
+
+
+def test_mesh_occupancy_and_surface_sampling(tmp_path):
+    """train_triplane's data preparation without Open3D: a closed mesh (the sphere surface extracted above, scaled to
+    [-1,1]) sampled on the device.  Occupancy vs the CPU statement (same rule; <= 0.05 % of the points may differ, those
+    whose ray grazes an edge within fp32 rounding) and vs the analytic sphere away from the surface; surface samples lie
+    on the mesh; the file route (OBJ) gives the same occupancy."""
+    from ishapediting_amd.mesh import extract_surface, mesh_occupancy, sample_occupancy, sample_surface_points, _write_obj
+    res, r = 48, 15.2
+    v, f = extract_surface(sphere(res, r).to(dev()))
+    v = v / (res - 1) * 2 - 1                                      # grid -> [-1, 1]
+    rad = r / (res - 1) * 2
+    g = torch.Generator().manual_seed(2)
+    pts = (torch.rand((20000, 3), generator=g) * 2 - 1).to(dev())
+    occ = mesh_occupancy(v, f, pts)
+    ref = S.mesh_occupancy(v.cpu(), f.cpu(), pts.cpu())
+    assert float((occ.cpu() != ref).float().mean()) <= 5e-4
+    d = torch.linalg.norm(pts, dim=1)
+    clear = (d - rad).abs() > 0.03                                 # the mesh is a polyhedral approximation of the sphere
+    assert torch.equal(occ[clear], (d[clear] < rad).float())
+    assert 0.05 < float(occ.mean()) < 0.5                         # sphere volume / cube volume = 0.135 here
+    sp = sample_surface_points(v, f, 5000, generator=g)
+    assert float((torch.linalg.norm(sp, dim=1) - rad).abs().max()) < 0.02
+    assert float(sp.mean(dim=0).abs().max()) < 0.03               # area-weighted: centred on the sphere
+    _write_obj(str(tmp_path / "s.obj"), v, f)
+    p2, o2 = sample_occupancy(None, str(tmp_path / "s.obj"), True, 4000, 0.5, device=dev(), generator=g)
+    assert p2.shape == (4000, 3) and o2.shape == (4000, 1) and set(np.unique(o2)) <= {0.0, 1.0}
+    d2 = np.linalg.norm(p2, axis=1)
+    far = np.abs(d2 - rad) > 0.03
+    np.testing.assert_array_equal(o2[far, 0], (d2[far] < rad).astype(np.float32))
