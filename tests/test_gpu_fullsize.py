@@ -160,3 +160,26 @@ def test_ddpm_step_with_zero_noise_returns_the_mean(ds):
     o0 = d.p_sample_guidance(ds.model, x, 0, feat_layer=-1, noise=big)
     o0z = d.p_sample_guidance(ds.model, x, 0, feat_layer=-1, noise=zero)
     assert torch.equal(o0["sample"], o0z["sample"])
+
+
+def test_train_triplane_from_a_mesh_file(ds, tmp_path):
+    """The public real-shape route at full size (drag_utils.py:401-471) without Open3D: an OBJ file is sampled on the
+    device (200 000 points by default), the guided reconstruction runs the full-depth UNet backward every step, and
+    the result is inverted back into guidance state -- everything `training()` needs afterwards."""
+    import copy
+    from ishapediting_amd.mesh import extract_surface, _write_obj
+    ax = torch.arange(64, dtype=torch.float32, device=ds.device) - 31.5
+    sph = 20.0 - torch.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2)
+    v, f = extract_surface(sph)
+    _write_obj(str(tmp_path / "shape.obj"), v / 63 * 2 - 1, f)
+    saved = (ds.w, ds.w0, list(ds.feature_guidance), ds.mesh, ds.mesh0)
+    try:
+        ds.train_triplane(mesh_path=str(tmp_path / "shape.obj"), path=str(tmp_path))
+        tri = np.load(tmp_path / "tri_feat.npy")
+        assert tri.shape == (1, 96, 128, 128) and np.isfinite(tri).all()
+        assert (tmp_path / "mesh_recon.obj").exists()
+        assert len(ds.feature_guidance) == W_TIME and tuple(ds.w.shape) == (1, 96, 128, 128)
+        assert len(ds.variance) == W_TIME and len(ds.variance_noise) == W_TIME
+        assert bool(torch.isfinite(ds.w).all())
+    finally:
+        ds.w, ds.w0, ds.feature_guidance, ds.mesh, ds.mesh0 = saved
