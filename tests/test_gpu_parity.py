@@ -273,3 +273,32 @@ def test_small_map_gemm_path_vs_oracle():
     r_gx, _ = rel_err(gx, ref_gx.numpy())
     print(f"64-channel config: out {r_out:.2e} tap {r_tap:.2e} grad {r_gx:.2e}")
     assert r_out < 1e-2 and r_tap < 1e-2 and r_gx < 2e-2
+
+
+def test_batched_forward_and_backward_on_the_64_channel_configuration():
+    """Batch 2 through the LDS-DMA kernels, the fused skip concatenation, the epilogue statistics and the split gradient
+    outputs (all indexed per image) against the two samples run one by one: relative L2 <= 5e-3 (kernel choice
+    differs with the row count; no image may leak into the other -- a leak would be O(1))."""
+    from ishapediting_amd.unet import UNetModel
+    from ishapediting_amd.unet_spec import UNetConfig, build_spec
+    cfg = UNetConfig(image_size=16, in_channels=6, model_channels=64, out_channels=12, num_res_blocks=1,
+                     attention_resolutions="8", channel_mult=(1, 2), num_head_channels=64)
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 78))
+    m2, m1 = UNetModel(cfg, dev(), max_batch=2), UNetModel(cfg, dev())
+    m2.load_state_dict(sd)
+    m1.load_state_dict(sd)
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 6, 16, 16, generator=g).to(dev())
+    ts = [123.0, 876.0]
+    k = len(build_spec(cfg).output_blocks) - 2
+    ch, sz = m1.tap_shape(k)
+    cot = (torch.randn(2, sz * sz, ch, generator=g) * 0.1).half().to(dev())
+    out2, _ = m2(x, ts, feat_layer=k, keep_for_backward=True)
+    gx2 = m2.backward_input(cot)
+    for b in range(2):
+        o1, _ = m1(x[b:b + 1], ts[b:b + 1], feat_layer=k, keep_for_backward=True)
+        g1 = m1.backward_input(cot[b:b + 1].contiguous())
+        r_o, _ = rel_err(out2[b:b + 1], o1.cpu().numpy())
+        r_g, _ = rel_err(gx2[b:b + 1], g1.cpu().numpy())
+        print(f"batch element {b}: out {r_o:.2e} grad {r_g:.2e}")
+        assert r_o < 5e-3 and r_g < 1e-2
