@@ -171,11 +171,21 @@ def main():
         # HBM-side bytes per launch of that kernel from the committed PMC passes (profiles/pmc_traffic.json, produced by
         # tools/pmc_only.sh + tools/pmc_summary.py: counters cannot be collected from inside this process)
         traffic = None
-        rocprof_name = ["void igemm2_kernel<128, 128, 4, true>", "void igemm2_kernel<64, 64, 4, true>",
-                        "void igemm2_kernel<128, 128, 4, false>", "void igemm2_kernel<64, 64, 4, false>"][v]
+        # rocprof symbols behind each live-profiled variant (the 64x64 conv has a one-team and a two-team instantiation)
+        rocprof_names = [["void igemm2_kernel<128, 128, 4, true, 1>"],
+                         ["void igemm2_kernel<64, 64, 4, true, 1>", "void igemm2_kernel<64, 64, 4, true, 2>"],
+                         ["void igemm2_kernel<128, 128, 4, false, 1>"],
+                         ["void igemm2_kernel<64, 64, 4, false, 1>"]][v]
+        rocprof_name = " + ".join(rocprof_names)
         try:
-            k = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"][rocprof_name]
-            traffic = k["FETCH_SIZE"]["bytes_per_launch"] + k["WRITE_SIZE"]["bytes_per_launch"]
+            ks = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+            num = den = 0.0
+            for nme in rocprof_names:
+                if nme in ks:
+                    n = ks[nme]["FETCH_SIZE"]["dispatches"]
+                    num += n * (ks[nme]["FETCH_SIZE"]["bytes_per_launch"] + ks[nme]["WRITE_SIZE"]["bytes_per_launch"])
+                    den += n
+            traffic = int(num / den) if den else None
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
