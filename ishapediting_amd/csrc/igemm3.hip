@@ -21,7 +21,7 @@ constexpr int starts_ahead(int ph, int dist) {
 }
 
 template <int BM, int BN, int NSTW, int NSTX>
-__global__ __launch_bounds__(256) void igemm3_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(512) void igemm3_kernel(IgemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BK = 64;
   constexpr int WI = BN / 8 / 4;                   // weight DMA instructions per wave per K-step
@@ -35,8 +35,11 @@ __global__ __launch_bounds__(256) void igemm3_kernel(IgemmArgs a) {
   half_t* sW = reinterpret_cast<half_t*>(smem_raw);      // [NSTW][BN*BK]
   half_t* sX = sW + NSTW * WSLOT;                        // [NSTX][XROWS*BK]
 
+  // 8 waves: 0-3 compute, 4-7 only issue the DMA (same producer/consumer split as igemm2.hip)
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave8 >= 4;
+  const int wave = wave8 & 3;
   const int wm = wave >> 1, wn = wave & 1;
   int tile_m, tile_n, tile_z;
   {
@@ -116,23 +119,30 @@ __global__ __launch_bounds__(256) void igemm3_kernel(IgemmArgs a) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  if (loader) {
 #pragma unroll
-  for (int s = 0; s < DIST; ++s)
-    if (s < ns) issue(s);
+    for (int s = 0; s < DIST; ++s)
+      if (s < ns) issue(s);
+  }
 
   for (int s = 0; s < ns; ++s) {
     // step s needs W(s) and X(group(s)); issued after them: issue(s+1), issue(s+2) = WI (+XI at a group start) each
     const int ph = s - (s / 3) * 3;
-    if (s + DIST <= ns) {
-      if (ph == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * WI + starts_ahead(0, DIST) * XI) : "memory");
-      else if (ph == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * WI + starts_ahead(1, DIST) * XI) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * WI + starts_ahead(2, DIST) * XI) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (loader) {
+      if (s + DIST <= ns) {
+        if (ph == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * WI + starts_ahead(0, DIST) * XI) : "memory");
+        else if (ph == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * WI + starts_ahead(1, DIST) * XI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * WI + starts_ahead(2, DIST) * XI) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (s + DIST < ns) issue(s + DIST);
+    if (loader) {
+      if (s + DIST < ns) issue(s + DIST);
+      continue;
+    }
     const half_t* bw = sW + (s % NSTW) * WSLOT;
     const half_t* bx = sX + ((s / 3) % NSTX) * XSLOT;
     const int dx = ph - 1;
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(256) void igemm3_kernel(IgemmArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
   }
-  igemm_epilogue<MT, NT, TMW, TNW, BN>(a, acc, m0, n0, wm, wn, lane, 0, ks_id, reinterpret_cast<float*>(smem_raw));
+  igemm_epilogue<MT, NT, TMW, TNW, BN>(a, acc, m0, n0, wm, wn, lane, 0, ks_id, reinterpret_cast<float*>(smem_raw), !loader);
 #endif
 }
 
@@ -173,8 +183,8 @@ static int launch3(const IgemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.ksplit);
-  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(256), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a);
-  else hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(512), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a);
+  else hipLaunchKernelGGL(kern, grid, dim3(512), smem, s, a);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
