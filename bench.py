@@ -156,47 +156,37 @@ def main():
         L.ishap_profile_begin()
         one_edit(ds, src, tgt)
         torch.cuda.synchronize()
-        out = (C.c_double * 12)()
-        L.ishap_profile_end(out, 4)
+        NV = 7
+        out = (C.c_double * (NV * 3))()
+        L.ishap_profile_end(out, NV)
         if a.shape_profile:
             buf = C.create_string_buffer(1 << 16)
             L.ishap_profile_shapes(buf, len(buf))
             with open(a.shape_profile, "w") as f:
                 f.write("M,N,K,conv3,tile,ksplit,launches,main_ms,reduce_ms,gflop\n" + buf.value.decode())
-        names = ["igemm_kernel<128,128,*,conv3x3>", "igemm_kernel<64,64,*,conv3x3>", "igemm_kernel<128,128,*,gemm>",
-                 "igemm_kernel<64,64,*,gemm>"]
-        v = max(range(4), key=lambda i: out[i * 3 + 1])
+        # one entry per kernel symbol (the name rocprofv3 reports)
+        names = ["void igemm2_kernel<128, 128, 4, true, 1>", "void igemm2_kernel<64, 64, 4, true, 1>",
+                 "void igemm2_kernel<128, 128, 4, false, 1>", "void igemm2_kernel<64, 64, 4, false, 1>",
+                 "void igemm2_kernel<64, 64, 4, true, 2>", "igemm_skinny_kernel<*, false>", "void igemm_kernel<128, 128, 32, 2, 2, true>"]
+        v = max(range(NV), key=lambda i: out[i * 3 + 1])
         launches, ms, flops = out[v * 3], out[v * 3 + 1], out[v * 3 + 2]
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM-side bytes per launch of that kernel from the committed PMC passes (profiles/pmc_traffic.json, produced by
         # tools/pmc_only.sh + tools/pmc_summary.py: counters cannot be collected from inside this process)
         traffic = None
-        # rocprof symbols behind each live-profiled variant (the 64x64 conv has a one-team and a two-team instantiation)
-        rocprof_names = [["void igemm2_kernel<128, 128, 4, true, 1>"],
-                         ["void igemm2_kernel<64, 64, 4, true, 1>", "void igemm2_kernel<64, 64, 4, true, 2>"],
-                         ["void igemm2_kernel<128, 128, 4, false, 1>"],
-                         ["void igemm2_kernel<64, 64, 4, false, 1>"]][v]
-        rocprof_name = " + ".join(rocprof_names)
         try:
-            ks = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
-            num = den = 0.0
-            for nme in rocprof_names:
-                if nme in ks:
-                    n = ks[nme]["FETCH_SIZE"]["dispatches"]
-                    num += n * (ks[nme]["FETCH_SIZE"]["bytes_per_launch"] + ks[nme]["WRITE_SIZE"]["bytes_per_launch"])
-                    den += n
-            traffic = int(num / den) if den else None
+            k = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"][names[v]]
+            traffic = k["FETCH_SIZE"]["bytes_per_launch"] + k["WRITE_SIZE"]["bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": traffic, "kernel": names[v],
-                    "rocprof_kernel": rocprof_name,
                     "launches_per_edit": int(launches), "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
                     "flops_per_launch_avg": flops / max(launches, 1),
                     "share_of_edit_time": round(ms * 1e-3 / sec_per_shape / max(world, 1), 3) if world == 1 else None,
                     "all_variants": {names[i]: {"launches": int(out[i * 3]), "ms": round(out[i * 3 + 1], 3),
                                                 "tflops": round(out[i * 3 + 2] / max(out[i * 3 + 1], 1e-9) / 1e9, 1)}
-                                     for i in range(4)}}
+                                     for i in range(NV)}}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(1234)

@@ -272,7 +272,8 @@ extern "C" int ishap_profile_begin(void) {
   return 0;
 }
 // out[v*3 + {0,1,2}] = {launches, total milliseconds, algorithmic FLOPs} for variant v:
-//   0 conv3x3 128x128 tile, 1 conv3x3 64x64 tile, 2 GEMM 128x128 tile, 3 GEMM 64x64 tile
+//   0 conv3x3 128x128 tile, 1 conv3x3 64x64 tile, 2 GEMM 128x128 tile, 3 GEMM 64x64 tile, 4 conv3x3 64x64 two-team,
+//   5 small-map kernel, 6 register-staged (BK = 32) kernel
 extern "C" int ishap_profile_end(double* out, int nvar) {
   g_prof_on = false;
   for (int i = 0; i < nvar * 3; ++i) out[i] = 0.0;
@@ -314,6 +315,7 @@ extern "C" int ishap_profile_shapes(char* buf, int cap) {
 }
 
 int igemm2_launch_main(const IgemmArgs& a, bool big, hipStream_t s);   // igemm2.hip (LDS-DMA ring, BK = 64)
+bool igemm2_two_teams(const IgemmArgs& a, bool big);
 bool igemm3_applicable(const IgemmArgs& a, bool big);                  // igemm3.hip (3x3 with activation reuse across dx)
 int igemm3_launch_main(const IgemmArgs& a, bool big, hipStream_t s);
 
@@ -340,7 +342,10 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
     ProfRec r;
     r.a = prof_event(); r.b = prof_event(); r.c = nullptr;
     r.flops = 2.0 * a.M * a.N * a.K * a.nbatch * a.flops_scale;
-    r.variant = (CONV3 ? 0 : 2) + (BM == 128 ? 0 : 1);
+    // one variant per kernel symbol: 0/1 conv 128/64 tile, 2/3 GEMM 128/64 tile, 4 two-team 64-tile conv,
+    // 5 small-map kernel (set in igemm_launch), 6 register-staged BK=32 kernel (stem conv)
+    r.variant = BK == 64 ? ((CONV3 ? 0 : 2) + (BM == 128 ? 0 : 1)) : 6;
+    if (BK == 64 && igemm2_two_teams(a, BM == 128)) r.variant = 4;
     r.M = a.M * a.nbatch; r.N = a.N; r.K = a.K; r.conv3 = CONV3; r.big = BM == 128; r.ksplit = a.ksplit;
     g_igemm_prof_start = r.a; g_igemm_prof_stop = r.b;      // attached to the dispatch: kernel begin / end timestamps
     const int rc = fire();
@@ -410,7 +415,7 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
     ProfRec r;
     r.a = prof_event(); r.b = prof_event(); r.c = nullptr;
     r.flops = 2.0 * a.M * a.N * a.K * a.flops_scale;
-    r.variant = a.conv3 ? 1 : 3;
+    r.variant = 5;
     r.M = a.M; r.N = a.N; r.K = a.K; r.conv3 = a.conv3; r.big = false; r.ksplit = 0;      // ksplit 0 marks the skinny kernel
     g_igemm_prof_start = r.a; g_igemm_prof_stop = r.b;
     const int rc = igemm_skinny_launch(a, 0, s);

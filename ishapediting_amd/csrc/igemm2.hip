@@ -268,17 +268,22 @@ static int launch2(const IgemmArgs& a, hipStream_t s) {
   return 0;
 }
 
+// one workgroup per CU at most and a K slice long enough to split: the two-team variant of the 64x64 conv kernel
+// (measured: +4..16 % there, a loss on short slices and 1x1)
+bool igemm2_two_teams(const IgemmArgs& a, bool big) {
+  static const int halves = [] { const char* e = getenv("ISHAP_HALVES"); return e ? atoi(e) : 2; }();
+  if (big || halves != 2 || !a.conv3) return false;
+  const long long tiles = (long long)(a.M / 64) * ((a.N + 63) / 64) * a.nbatch * a.ksplit;
+  const int steps = (a.K / 64 + a.ksplit - 1) / a.ksplit;
+  return tiles <= 256 && steps >= 16;
+}
+
 // main kernel only (the caller adds the split-K reduce); big = 128x128 tile, else 64x64
 int igemm2_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
   if (big) return a.conv3 ? launch2<128, 128, 4, true>(a, s) : launch2<128, 128, 4, false>(a, s);
 #ifndef IG2_SMALL_NST
 #define IG2_SMALL_NST 4
 #endif
-  // one workgroup per CU at most and a K slice long enough to split: the two-team variant
-  static const int halves = [] { const char* e = getenv("ISHAP_HALVES"); return e ? atoi(e) : 2; }();
-  const long long tiles = (long long)(a.M / 64) * ((a.N + 63) / 64) * a.nbatch * a.ksplit;
-  const int steps = (a.K / 64 + a.ksplit - 1) / a.ksplit;
-  if (halves == 2 && a.conv3 && tiles <= 256 && steps >= 16)      // measured: +4..16 % there, a loss on short slices and 1x1
-    return a.conv3 ? launch2<64, 64, 4, true, 2>(a, s) : launch2<64, 64, 4, false, 2>(a, s);
+  if (igemm2_two_teams(a, big)) return launch2<64, 64, 4, true, 2>(a, s);
   return a.conv3 ? launch2<64, 64, IG2_SMALL_NST, true>(a, s) : launch2<64, 64, IG2_SMALL_NST, false>(a, s);
 }
