@@ -370,7 +370,7 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 }
 
 // Tile and split-K policy.  256 CUs: prefer the 128x128 tile when it alone yields >= ~200 workgroups, otherwise the
-// 64x64 tile; split K only when even that leaves most of the chip idle (the small-map, weight-streaming layers),
+// 64x64 tile; split K while the grid stays below ~224 workgroups (the small-map, weight-streaming layers),
 // keeping >= 6 K-steps of 64 per slice so the fp32 partial traffic stays below the weight traffic.
 static bool igemm_use_big(int M, int N, int nbatch) {
   if (M % 128 != 0 || N < 128) return false;
@@ -384,7 +384,9 @@ int igemm_pick_ksplit(int M, int N, int K, int nbatch) {
   int ks = K / 64;
   if (ks < 48) return 1;        // measured (tools/sweep_igemm.sh): below ~48 K-steps the extra reduce launch (~5.5 us) costs more than the split saves
   int split = 1;
-  while (blocks * split < 160 && ks / (split * 2) >= 6 && split < 32) split *= 2;
+  static const int fill = [] { const char* e = getenv("ISHAP_SPLIT_FILL"); return e ? atoi(e) : 224; }();   // in-situ sweep (tools/sweep_split_policy.sh): plateau 208..256, 1 % better than 160
+  static const int minsteps = [] { const char* e = getenv("ISHAP_SPLIT_MINSTEPS"); return e ? atoi(e) : 6; }();
+  while (blocks * split < fill && ks / (split * 2) >= minsteps && split < 32) split *= 2;
   return split;
 }
 
