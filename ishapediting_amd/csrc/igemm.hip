@@ -375,14 +375,16 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 static bool igemm_use_big(int M, int N, int nbatch) {
   if (M % 128 != 0 || N < 128) return false;
   long long blocks = (long long)(M / 128) * ceil_div(N, 128) * nbatch;
-  return blocks >= 192;
+  static const int big_min = [] { const char* e = getenv("ISHAP_BIG_MIN"); return e ? atoi(e) : 192; }();
+  return blocks >= big_min;
 }
 int igemm_pick_ksplit(int M, int N, int K, int nbatch) {
   const bool big = igemm_use_big(M, N, nbatch);
   const int bm = big ? 128 : 64, bn = big ? 128 : 64;
   long long blocks = (long long)(M / bm) * ceil_div(N, bn) * nbatch;
   int ks = K / 64;
-  if (ks < 48) return 1;        // measured (tools/sweep_igemm.sh): below ~48 K-steps the extra reduce launch (~5.5 us) costs more than the split saves
+  static const int nosplit = [] { const char* e = getenv("ISHAP_NOSPLIT_STEPS"); return e ? atoi(e) : 36; }();   // in situ: 36 beats 24 / 48 by ~0.5 %
+  if (ks < nosplit) return 1;        // below ~36 K-steps the extra reduce launch (~5.5 us) costs more than the split saves (harness sweep: ~48; in situ: 36)
   int split = 1;
   static const int fill = [] { const char* e = getenv("ISHAP_SPLIT_FILL"); return e ? atoi(e) : 224; }();   // in-situ sweep (tools/sweep_split_policy.sh): plateau 208..256, 1 % better than 160
   static const int minsteps = [] { const char* e = getenv("ISHAP_SPLIT_MINSTEPS"); return e ? atoi(e) : 6; }();

@@ -275,7 +275,9 @@ bool igemm2_two_teams(const IgemmArgs& a, bool big) {
   if (big || halves != 2 || !a.conv3) return false;
   const long long tiles = (long long)(a.M / 64) * ((a.N + 63) / 64) * a.nbatch * a.ksplit;
   const int steps = (a.K / 64 + a.ksplit - 1) / a.ksplit;
-  return tiles <= 256 && steps >= 16;
+  static const int max_tiles = [] { const char* e = getenv("ISHAP_TEAM_TILES"); return e ? atoi(e) : 256; }();
+  static const int min_steps = [] { const char* e = getenv("ISHAP_TEAM_STEPS"); return e ? atoi(e) : 16; }();
+  return tiles <= max_tiles && steps >= min_steps;
 }
 
 // main kernel only (the caller adds the split-K reduce); big = 128x128 tile, else 64x64
