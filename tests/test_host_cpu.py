@@ -99,3 +99,17 @@ def test_gather_volumes_world_size_2_gloo(n_edits):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == [float(i) for i in range(n_edits)]
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback: without libishap_hip.so the binding raises, and so does constructing a model on the CPU."""
+    from ishapediting_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libishap_hip.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+    monkeypatch.undo()
+    from ishapediting_amd.unet import UNetModel
+    from ishapediting_amd.unet_spec import tiny_config
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        UNetModel(tiny_config(1), torch.device("cpu"))
