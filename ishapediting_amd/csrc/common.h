@@ -71,10 +71,16 @@ struct IgemmArgs {
   const half_t* Wt = nullptr;  // [Npad][K] (K contiguous), rows >= N are zero
   void* out = nullptr;
   const float* bias = nullptr;   // [N] or null
+  const float* bias2 = nullptr;  // second bias added like the first (a 1x1 skip convolution folded into this launch)
   const half_t* res = nullptr;   // residual [M][ldr] or null (may alias out)
   float* ws = nullptr;           // split-K workspace [ksplit][nbatch][M][N] fp32
   int M = 0, N = 0, K = 0;
   int conv3 = 0;                 // 0: plain rows, 1: 3x3 gather
+  // 3x3 launches may carry a second activation source: after the 9*Cin gathered columns, K2 more columns are read
+  // from X2 (plain rows, stride ldx2) against weight columns [9*Cin, 9*Cin + K2) -- y = conv3x3(X) + conv1x1(X2) in
+  // one K loop (ResBlock: out_layers conv + skip_connection, unet.py:255-256).  K = 9*Cin + K2.
+  const half_t* X2 = nullptr;
+  int ldx2 = 0, K2 = 0;
   int Cin = 0;                   // channels per tap (conv3) -- K = 9*Cin
   int ldx = 0, ldw = 0, ldo = 0, ldr = 0;
   long long bsx = 0, bsw = 0, bso = 0;   // per-batch strides (elements)

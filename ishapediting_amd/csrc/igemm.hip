@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(IgemmArgs a) {
     for (; z < a.ksplit; ++z) v += *reinterpret_cast<const f32x4*>(wp + z * zs);
     v *= a.alpha;
     if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+    if (a.bias2) v += *reinterpret_cast<const f32x4*>(a.bias2 + n);
     int n_img = 0, py = 0, px = 0;
     if (a.res_ups || a.out_mode == IG_OUT_NCHW_F32) {
       n_img = m / HW;
@@ -408,7 +409,9 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
   ISHAP_REQUIRE(a.M % 64 == 0, "M must be a multiple of 64");
   ISHAP_REQUIRE(a.N % 4 == 0, "N must be a multiple of 4");
   ISHAP_REQUIRE(a.K % 32 == 0, "K must be a multiple of 32");
-  ISHAP_REQUIRE(!a.conv3 || (a.Cin % 32 == 0 && a.K == 9 * a.Cin), "conv3: K = 9*Cin, Cin % 32 == 0");
+  ISHAP_REQUIRE(!a.conv3 || (a.Cin % 32 == 0 && a.K == 9 * a.Cin + a.K2), "conv3: K = 9*Cin (+ K2), Cin % 32 == 0");
+  ISHAP_REQUIRE(a.K2 == 0 || (a.conv3 && a.X2 && a.K2 % 64 == 0 && a.Cin % 64 == 0 && a.ldx2 % 8 == 0 && a.nbatch == 1),
+                "folded 1x1 source: 3x3 launch, 64-wide K-steps");
   ISHAP_REQUIRE(a.ksplit == 1 || a.ws != nullptr, "split-K needs a workspace");
   ISHAP_REQUIRE(!a.gb_x || (!a.stat_out && a.out_mode == IG_OUT_F16 && a.ldo == a.N && a.N % 32 == 0 && a.nbatch == 1 && a.gb_csums &&
                             a.gb_stats && a.gb_gamma && a.gb_beta && (!a.gb_film || a.gb_emb)),

@@ -121,6 +121,17 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
   int next_ks = ks0;
 
   auto retap = [&]() {
+    if (next_ks >= 9 * steps_per_tap) {          // second source: the folded 1x1 convolution (plain rows of X2)
+      const int c0 = (next_ks - 9 * steps_per_tap) * BK;
+      tap_left = KS - next_ks;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const long long m = (long long)xn[i] * HW + xy[i] * a.W + xx[i];
+        xp[i] = a.X2 + m * a.ldx2 + c0 + xsc[i];
+        xstep[i] = BK;
+      }
+      return;
+    }
     const int tap = next_ks / steps_per_tap;
     const int c0 = (next_ks - tap * steps_per_tap) * BK;
     tap_left = steps_per_tap - (next_ks - tap * steps_per_tap);

@@ -192,7 +192,7 @@ static int launch3(const IgemmArgs& a, hipStream_t s) {
 // true when the shape fits this kernel: 3x3, no on-the-fly upsampling, Cin % 64 == 0, tile = whole image rows
 bool igemm3_applicable(const IgemmArgs& a, bool big) {
   const int BM = big ? 128 : 64;
-  if (!a.conv3 || a.ups || a.nbatch != 1 || a.Cin % 64 != 0) return false;
+  if (!a.conv3 || a.ups || a.nbatch != 1 || a.Cin % 64 != 0 || a.K2 != 0) return false;
   if (a.W < 16 || a.W % 16 != 0 || BM % a.W != 0 || (a.H * a.W) % BM != 0) return false;
   const int R = BM / a.W;
   return R * (a.W + 2) <= (big ? 160 : 96);

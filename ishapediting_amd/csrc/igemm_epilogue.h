@@ -41,6 +41,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
       }
       v *= a.alpha;
       if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+      if (a.bias2) v += *reinterpret_cast<const f32x4*>(a.bias2 + n);
       if (a.res) {
         long long rrow = a.res_ups ? ((long long)n_img * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1)) : m;
         half4 r = *reinterpret_cast<const half4*>(a.res + rrow * a.ldr + n);

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void igemm_skinny_kernel(IgemmArgs a
   if (ok) {
     v *= a.alpha;
     if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+    if (a.bias2) v += *reinterpret_cast<const f32x4*>(a.bias2 + n);
     if (a.res) {
       const long long rrow = a.res_ups ? ((long long)n_img * (HW >> 2) + (oy >> 1) * (a.W >> 1) + (ox >> 1)) : m;
       const half4 r = *reinterpret_cast<const half4*>(a.res + rrow * a.ldr + n);

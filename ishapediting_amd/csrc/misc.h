@@ -11,7 +11,9 @@ int add_f16(const half_t* a, const half_t* b, half_t* o, long long n, hipStream_
 struct TsArg { float t[16]; };   // timesteps by value: no host->device copy on the step path
 int timestep_embedding(const TsArg& t, float* out, int N, int dim, hipStream_t s);
 int gemv_f32(const float* W, const float* b, const float* in, float* out, int rows, int K, int N, int silu_in, hipStream_t s);
-int pack_conv_weight(const float* w, half_t* dst, int O, int I, int taps, int rows_pad, int cpad, int transpose_flip, hipStream_t s);
+// dst_ld / col_off: destination row stride (0 = taps*cpad) and first column -- lets two weights share one K-concatenated matrix
+int pack_conv_weight(const float* w, half_t* dst, int O, int I, int taps, int rows_pad, int cpad, int transpose_flip, hipStream_t s,
+                     int dst_ld = 0, int col_off = 0);
 int pack_conv_weight_split(const float* w, half_t* dst, int O, int I, int taps, int rows_pad, hipStream_t s);
 int round_through_f16(const float* src, float* dst, long long n, hipStream_t s);
 // attention backward pieces + gradient export (attn_bwd.hip)

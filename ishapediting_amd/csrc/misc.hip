@@ -185,7 +185,7 @@ int gemv_f32(const float* W, const float* b, const float* in, float* out, int ro
 // OIHW (fp32) -> Wt[Npad][taps*Cpad] fp16, k = tap*Cpad + c.  transpose_flip: build the input-gradient
 // operand instead: rows = input channel, k = tap'*Opad + o with tap' = 8 - tap (spatially flipped).
 __global__ void pack_conv_kernel(const float* __restrict__ w, half_t* __restrict__ dst, int O, int I, int taps,
-                                 int rows_pad, int cpad, int transpose_flip, int round_f16) {
+                                 int rows_pad, int cpad, int transpose_flip, int dst_ld, int col_off) {
   const long long total = (long long)rows_pad * taps * cpad;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     int c = (int)(i % cpad);
@@ -197,15 +197,15 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, half_t* __restrict
     } else {
       if (r < I && c < O) v = w[((long long)c * I + r) * taps + (taps - 1 - tap)];
     }
-    (void)round_f16;
-    dst[i] = (half_t)v;
+    dst[(long long)r * dst_ld + col_off + tap * cpad + c] = (half_t)v;
   }
 }
 int pack_conv_weight(const float* w, half_t* dst, int O, int I, int taps, int rows_pad, int cpad, int transpose_flip,
-                     hipStream_t s) {
+                     hipStream_t s, int dst_ld, int col_off) {
   long long total = (long long)rows_pad * taps * cpad;
   int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
-  hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, s, w, dst, O, I, taps, rows_pad, cpad, transpose_flip, 1);
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, s, w, dst, O, I, taps, rows_pad, cpad, transpose_flip,
+                     dst_ld ? dst_ld : taps * cpad, col_off);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -43,6 +43,10 @@ struct ConvW {
   int cout_pad = 0;
   float* bias = nullptr;
   bool split = false;    // fp32 head: [hi|hi|lo] packing, kpad = 3*cin
+  // K-concatenated forward operand shared with another conv of the same ResBlock ([c2 3x3 | skip 1x1]): this weight is
+  // also packed into cat at column cat_off (row stride cat_ld)
+  half_t* cat = nullptr;
+  int cat_ld = 0, cat_off = 0;
 };
 struct NormW {
   float* gamma = nullptr;
@@ -154,7 +158,8 @@ static inline T* aalloc(Exec& e, size_t count) { return (T*)e.u->arena.alloc(cou
 // X [N,H,W,ldx] (*) Wt -> out; taps 9 (3x3, pad 1) or 1; picks split-K and uses the context workspace
 int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps, int cout,
             const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups, int res_ups,
-            long long* stat_out = nullptr, const struct GnBwdArgs* gb = nullptr);
+            long long* stat_out = nullptr, const struct GnBwdArgs* gb = nullptr, const half_t* X2 = nullptr, int ldx2 = 0,
+            int K2 = 0, const float* bias2 = nullptr, int ldw = 0);
 long long* salloc(Exec& e, size_t count);   // from the stats arena
 int gn_stats_op(Exec& e, const Tensor& x, float* stats);
 

@@ -190,6 +190,15 @@ int unet_build(ishap_unet* u) {
     ISHAP_TRY(reg_conv(r.c2));
     if (r.has_skip) {
       ISHAP_TRY(conv_alloc(r.skip));
+      if (!r.down && !r.up && r.c2.kpad % 64 == 0 && r.skip.kpad % 64 == 0) {
+        // forward operand [c2 (9 taps) | skip (1x1)] concatenated along K: both convolutions in one launch
+        const int ld = 9 * r.c2.kpad + r.skip.kpad;
+        const size_t n = (size_t)round_up(r.cout, 128) * ld;
+        ISHAP_CHECK_HIP(hipMalloc((void**)&r.c2.cat, n * sizeof(half_t)));
+        ISHAP_CHECK_HIP(hipMemset(r.c2.cat, 0, n * sizeof(half_t)));
+        r.c2.cat_ld = ld; r.c2.cat_off = 0;
+        r.skip.cat = r.c2.cat; r.skip.cat_ld = ld; r.skip.cat_off = 9 * r.c2.kpad;
+      }
       reg(r.skip.path + ".weight", {r.cout, r.cin, 1, 1}, 0, &r.skip, nullptr, 0);
       reg(r.skip.path + ".bias", {r.cout}, 1, &r.skip, nullptr, 0);
     }
@@ -223,6 +232,7 @@ static int load_param(ishap_unet* u, ParamSlot& p, const float* data, hipStream_
       ISHAP_TRY(pack_conv_weight_split(data, c.w, c.cout, c.cin, c.taps, round_up(c.cout, 128), s));
     } else {
       ISHAP_TRY(pack_conv_weight(data, c.w, c.cout, c.cin, c.taps, round_up(c.cout, 128), c.kpad, 0, s));
+      if (c.cat) ISHAP_TRY(pack_conv_weight(data, c.cat, c.cout, c.cin, c.taps, round_up(c.cout, 128), c.kpad, 0, s, c.cat_ld, c.cat_off));
     }
     ISHAP_TRY(pack_conv_weight(data, c.wT, c.cout, c.cin, c.taps, round_up(round_up(c.cin, 32), 128), c.cout_pad, 1, s));
   } else if (p.kind == 1) {
@@ -249,7 +259,8 @@ long long* salloc(Exec& e, size_t count) {
 
 int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps,
                    int cout, const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups,
-                   int res_ups, long long* stat_out, const GnBwdArgs* gb) {
+                   int res_ups, long long* stat_out, const GnBwdArgs* gb, const half_t* X2, int ldx2, int K2,
+                   const float* bias2, int ldw) {
   IgemmArgs a;
   a.stat_out = stat_out;
   if (gb) {       // this launch produces the gradient arriving at act(film(GN(x))): accumulate the GN-backward sums in its epilogue
@@ -257,9 +268,10 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
     a.gb_emb_ld = gb->emb_ld; a.gb_film = gb->film; a.gb_act = gb->act; a.gb_csums = gb->csums;
   }
   a.X = X; a.Wt = Wt; a.out = out; a.bias = bias; a.res = res;
-  a.M = N * H * W; a.N = cout; a.K = taps * kpad;
+  a.M = N * H * W; a.N = cout; a.K = taps * kpad + K2;
+  a.X2 = X2; a.ldx2 = ldx2; a.K2 = K2; a.bias2 = bias2;
   a.conv3 = taps == 9; a.Cin = kpad;
-  a.ldx = ldx; a.ldw = taps * kpad; a.ldo = ldo; a.ldr = ldr;
+  a.ldx = ldx; a.ldw = ldw ? ldw : taps * kpad; a.ldo = ldo; a.ldr = ldr;
   a.H = H; a.W = W; a.ups = ups; a.res_ups = res_ups;
   a.out_mode = out_mode;
   a.flops_scale = (Wt == e.u->head.w) ? 1.f / 3.f : 1.f;
@@ -326,7 +338,11 @@ static int res_forward(Exec& e, ResL& L, const Tensor& x, Tensor& y) {
   y = h1;
   y.p = aalloc<half_t>(e, h1.numel());
   y.sums = salloc(e, (size_t)N * L.cout * 2);
-  if (L.has_skip) {
+  if (L.has_skip && L.c2.cat) {
+    // y = conv2(c) + skip(x) as ONE launch: the 1x1 skip convolution is L.cin more K columns read from x
+    ISHAP_TRY(conv_op(e, c.p, N, Ho, Wo, L.cout, L.c2.cat, L.c2.kpad, 9, L.cout, L.c2.bias, nullptr, 0, y.p, L.cout,
+                      IG_OUT_F16, 0, 0, y.sums, nullptr, xs.p, L.cin, L.skip.kpad, L.skip.bias, L.c2.cat_ld));
+  } else if (L.has_skip) {
     ISHAP_TRY(conv_op(e, xs.p, N, Ho, Wo, L.cin, L.skip.w, L.skip.kpad, 1, L.cout, L.skip.bias, nullptr, 0, y.p, L.cout,
                       IG_OUT_F16, 0, 0));
     ISHAP_TRY(conv_op(e, c.p, N, Ho, Wo, L.cout, L.c2.w, L.c2.kpad, 9, L.cout, L.c2.bias, y.p, L.cout, y.p, L.cout,
@@ -533,7 +549,7 @@ int ishap_unet_create(const ishap_unet_config* cfg, int device, ishap_unet** out
 void ishap_unet_destroy(ishap_unet* u) {
   if (!u) return;
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  auto frc = [&](ConvW& c) { fr(c.w); fr(c.wT); fr(c.bias); };
+  auto frc = [&](ConvW& c) { fr(c.w); fr(c.wT); fr(c.bias); if (c.cat && c.cat_off == 0) fr(c.cat); };
   frc(u->stem); frc(u->head);
   fr(u->head_norm.gamma); fr(u->head_norm.beta);
   for (auto& r : u->res) {
