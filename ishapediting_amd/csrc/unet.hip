@@ -26,7 +26,8 @@ int unet_build(ishap_unet* u) {
   const ishap_unet_config& cfg = u->cfg;
   const int mc = cfg.model_channels;
   u->ted = mc * 4;
-  u->in_pad = round_up(cfg.in_channels, 32);
+  // stem input channels padded with zeros: to 64-wide K-steps when that is cheap (96 -> 128: the LDS-DMA kernel), else to 32
+  u->in_pad = cfg.in_channels >= 64 ? round_up(cfg.in_channels, 64) : round_up(cfg.in_channels, 32);
   auto has_att = [&](int ds) {
     for (int i = 0; i < cfg.n_att; ++i) if (cfg.attention_ds[i] == ds) return true;
     return false;
@@ -62,6 +63,7 @@ int unet_build(ishap_unet* u) {
   int ch = cfg.channel_mult[0] * mc;
   int res = cfg.image_size;
   init_conv(u->stem, "input_blocks.0.0", cfg.in_channels, ch, 9);
+  u->stem.kpad = u->in_pad;
   {
     BlockL b;
     b.name = "input_blocks.0";
