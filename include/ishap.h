@@ -68,6 +68,16 @@ const void* ishap_unet_tap_ptr(const ishap_unet* u);
 /* copy it into a caller buffer of N*S_tap^2*C_tap halfs (the guidance cache of drag_utils.py:275-276, kept
  * on the device in the tap's own layout instead of resized fp32 copies on the host) */
 int ishap_unet_copy_tap(const ishap_unet* u, void* dst, void* stream);
+/* The output of any TimestepEmbedSequential of the last forward(keep_for_backward=1): group 0 = input_blocks[index]
+ * (the `hs` list, gd/unet.py:658-660), 1 = middle_block (:661), 2 = output_blocks[index] (:662-666).  Writes the
+ * block's channel count and side to *channels / *size; when dst is non-NULL also copies the activation as fp16
+ * [N][channels][size][size] (the reference's layout).  Parity tests use it to localise a mismatch to one block. */
+int ishap_unet_block_output(const ishap_unet* u, int group, int index, int* channels, int* size, void* dst_nchw_f16,
+                            void* stream);
+/* Device bytes the context holds besides the packed weights: activation arena + split-K partials + GroupNorm scratch
+ * (SURVEY 8b's ishap_workspace_bytes; the context allocates them itself at create time, sized by dry runs of
+ * forward + backward at every batch size 1..max_batch). */
+long long ishap_unet_workspace_bytes(const ishap_unet* u);
 
 /* d(sum(tap * cot)) / dx through output block feat_layer ... input block 0: what loss.backward()
  * computes for img.grad at drag_utils.py:383, without the weight gradients the reference discards.

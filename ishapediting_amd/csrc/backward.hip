@@ -14,7 +14,7 @@
 #include "norm.h"
 
 static int gn_bwd_op(Exec& e, GnBwdArgs g) {
-  if (!g.sums_ready) g.csums = salloc(e, (size_t)g.N * g.C * 2);     // zeroed with the rest of the stats arena at the start of the forward
+  if (!g.sums_ready) ISHAP_SALLOC(g.csums, e, (size_t)g.N * g.C * 2);     // zeroed with the rest of the stats arena at the start of the forward
   if (e.dry) return 0;
   ISHAP_REQUIRE(g.csums != nullptr, "stats arena exhausted");
   return gn_backward_launch(g, e.s);
@@ -25,9 +25,9 @@ static int gn_bwd_op(Exec& e, GnBwdArgs g) {
 // backward sums are then accumulated in this launch's epilogue (gb->csums allocated here, gb->sums_ready set).
 static int dgrad_op(Exec& e, const ConvW& c, const Tensor& dy, Tensor& dx_out, int n_out, GnBwdArgs* gb = nullptr) {
   dx_out = Tensor{nullptr, dy.N, dy.H, dy.W, n_out};
-  dx_out.p = aalloc<half_t>(e, dx_out.numel());
+  ISHAP_ALLOC(dx_out.p, e, dx_out.numel());
   if (gb) {
-    gb->csums = salloc(e, (size_t)gb->N * gb->C * 2);
+    ISHAP_SALLOC(gb->csums, e, (size_t)gb->N * gb->C * 2);
     gb->sums_ready = 1;
     ISHAP_REQUIRE(e.dry || gb->csums != nullptr, "stats arena exhausted");
     ISHAP_REQUIRE(gb->C == n_out && gb->gmode == GB_SAME, "fused GroupNorm-backward sums need the gradient at the GN resolution");
@@ -55,7 +55,7 @@ static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int spli
     g.emb = u->d_film + L.emb_off; g.emb_ld = u->film_rows;
     g.N = h1.N; g.H = h1.H; g.W = h1.W; g.C = L.cout; g.film = 1; g.act = 1; g.gmode = GB_SAME;
     ISHAP_TRY(dgrad_op(e, L.c2, dy, dc, L.cout, &g));
-    dh1.p = aalloc<half_t>(e, h1.numel());
+    ISHAP_ALLOC(dh1.p, e, h1.numel());
     g.g = dc.p; g.dx = dh1.p;
     ISHAP_TRY(gn_bwd_op(e, g));
   }
@@ -78,11 +78,11 @@ static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int spli
     *dx2 = x;
     dx2->C = x.C - split;
     dx2->sums = nullptr;
-    dx.p = aalloc<half_t>(e, dx.numel());
-    dx2->p = aalloc<half_t>(e, dx2->numel());
+    ISHAP_ALLOC(dx.p, e, dx.numel());
+    ISHAP_ALLOC(dx2->p, e, dx2->numel());
     g1.dx2 = dx2->p; g1.csplit = split;
   } else {
-    dx.p = aalloc<half_t>(e, x.numel());
+    ISHAP_ALLOC(dx.p, e, x.numel());
   }
   dx.sums = nullptr;
   g1.g = da.p; g1.add = add; g1.dx = dx.p; g1.add2 = add2;
@@ -99,7 +99,7 @@ static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx) {
   Tensor dA;
   ISHAP_TRY(dgrad_op(e, L.proj, dy, dA, C));
   Tensor dqkv{nullptr, N, x.H, x.W, 3 * C};
-  dqkv.p = aalloc<half_t>(e, dqkv.numel());
+  ISHAP_ALLOC(dqkv.p, e, dqkv.numel());
   const size_t d_need = (size_t)N * heads * T;
   if (e.dry) {
     if (d_need > u->attn_D_floats) u->attn_D_floats = d_need;
@@ -116,7 +116,7 @@ static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx) {
     g.x = x.p; g.stats = sv.stats; g.gamma = L.n.gamma; g.beta = L.n.beta;
     g.N = N; g.H = x.H; g.W = x.W; g.C = C; g.film = 0; g.act = 0; g.gmode = GB_SAME;
     ISHAP_TRY(dgrad_op(e, L.qkv, dqkv, dn, C, &g));
-    dx.p = aalloc<half_t>(e, x.numel());
+    ISHAP_ALLOC(dx.p, e, x.numel());
     g.g = dn.p; g.add = dy.p; g.dx = dx.p;
     ISHAP_TRY(gn_bwd_op(e, g));
   }
@@ -147,15 +147,15 @@ static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out, int split =
 int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out, int cot_out_f16, const float* scale2,
                        float* dx, hipStream_t s, bool dry) {
   Exec e{u, s, dry};
+  u->arena.off = u->fwd_mark;
+  u->stat_off = u->stat_fwd_mark;
   if (!dry) {
     ISHAP_REQUIRE(u->have_saved, "backward needs a preceding forward with keep_for_backward=1");
-    u->arena.off = u->fwd_mark;
-    u->stat_off = u->stat_fwd_mark;
     if (u->bwd_since_fwd++ > 0 && u->stat_cap > u->stat_fwd_mark)   // a second backward on the same forward: fresh zeros
       ISHAP_CHECK_HIP(hipMemsetAsync(u->stat_base + u->stat_fwd_mark, 0, (u->stat_cap - u->stat_fwd_mark) * sizeof(long long), s));
   }
   const ishap_unet_config& cfg = u->cfg;
-  const int N = dry ? cfg.max_batch : u->last_N;
+  const int N = u->last_N;            // dry runs follow a dry forward of the same batch size
   const int n_in = (int)u->in_blocks.size(), n_out = (int)u->out_blocks.size();
   int F;
   Tensor g;
@@ -164,7 +164,7 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
     F = n_out - 1;
     const int S = cfg.image_size, opad = u->head.cout_pad;
     Tensor dout{nullptr, N, S, S, opad};
-    dout.p = aalloc<half_t>(e, dout.numel());
+    ISHAP_ALLOC(dout.p, e, dout.numel());
     if (!dry) ISHAP_TRY(nchw_to_nhwc_f16_scaled(cot_out, cot_out_f16 ? 0 : 1, dout.p, N, cfg.out_channels, S * S, opad, 1.f, s));
     Tensor dact;
     GnBwdArgs a;
@@ -174,7 +174,7 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
     g = u->h_final;
     if (dry) g = Tensor{nullptr, N, S, S, u->final_ch};
     Tensor gh = g;
-    gh.p = aalloc<half_t>(e, g.numel());
+    ISHAP_ALLOC(gh.p, e, g.numel());
     a.g = dact.p; a.dx = gh.p;
     ISHAP_TRY(gn_bwd_op(e, a));
     g = gh;
@@ -210,7 +210,7 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
   for (int i = n_in - 1; i >= 0; --i) {
     if (pending) {                       // fall-back: a separate add
       Tensor sum = g;
-      sum.p = aalloc<half_t>(e, g.numel());
+      ISHAP_ALLOC(sum.p, e, g.numel());
       if (!dry) ISHAP_TRY(add_f16(g.p, pending, sum.p, g.numel(), s));
       g = sum;
     }

@@ -431,7 +431,13 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
     return rc;
   }
   const bool k64 = a.conv3 ? (a.Cin % 64 == 0) : (a.K % 64 == 0);
-  const bool big = igemm_use_big(a.M, a.N, a.nbatch);
+  bool big = igemm_use_big(a.M, a.N, a.nbatch);
+  if (a.stat_out || a.gb_x) {
+    // the statistics epilogues file a whole tile under image m0 / HW: a tile must not straddle two images
+    const int hw = a.H * a.W;
+    ISHAP_REQUIRE(hw > 0 && hw % 64 == 0, "fused GroupNorm sums need H*W to be a multiple of the 64-row tile");
+    if (hw % 128 != 0) big = false;
+  }
 #define IG_DISPATCH(BM, BN, WM_, WN_)                                                          \
   do {                                                                                         \
     if (a.conv3) {                                                                             \

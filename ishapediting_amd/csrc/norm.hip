@@ -124,21 +124,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
     const float cnt = (float)(a.H * a.W) * (float)cpg;
     for (int idx = threadIdx.x; idx < a.N * 32 * 8; idx += 256) {
       const int part = idx & 7, g = (idx >> 3) & 31, n = idx >> 8;
-      float s = 0.f, q = 0.f;
+      // exact integer adds of the fixed-point channel sums, then mean / variance in double: the one-pass
+      // E[x^2] - E[x]^2 cancels badly in fp32 once |mean| >> std (gn_finalize_kernel does the same arithmetic)
+      long long si = 0, qi = 0;
       for (int c = g * cpg + part; c < (g + 1) * cpg; c += 8) {
         const long long* sp = a.sums + ((long long)n * a.C + c) * 2;
         if (a.x2) sp = c < a.csplit ? a.sums + ((long long)n * a.csplit + c) * 2
                                     : a.sums2 + ((long long)n * (a.C - a.csplit) + (c - a.csplit)) * 2;
-        s += (float)sp[0] * (1.f / STAT_SCALE_SUM);
-        q += (float)sp[1] * (1.f / STAT_SCALE_SQ);
+        si += sp[0];
+        qi += sp[1];
       }
 #pragma unroll
-      for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+      for (int o = 1; o < 8; o <<= 1) { si += __shfl_xor(si, o); qi += __shfl_xor(qi, o); }
       if (part == 0) {
-        const float mean = s / cnt;
-        float var = q / cnt - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        const float rstd = rsqrtf(var + 1e-5f);
+        const double md = (double)si * (1.0 / (double)STAT_SCALE_SUM) / (double)cnt;
+        double vd = (double)qi * (1.0 / (double)STAT_SCALE_SQ) / (double)cnt - md * md;
+        vd = vd < 0.0 ? 0.0 : vd;
+        const float mean = (float)md;
+        const float rstd = (float)(1.0 / sqrt(vd + 1e-5));
         sh_stats[(n * 32 + g) * 2] = mean;
         sh_stats[(n * 32 + g) * 2 + 1] = rstd;
         if (a.stats_out && blockIdx.x == 0) {

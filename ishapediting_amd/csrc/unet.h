@@ -153,8 +153,20 @@ struct Exec {
   bool dry;
   bool keep = false;   // the forward keeps what a following backward re-reads
 };
+// Arena allocation that FAILS THE CALL when the arena sized by the create-time dry runs is exceeded (a null pointer
+// must never reach a kernel): ISHAP_ALLOC(ptr, e, count) inside any function returning an int status.
 template <typename T>
-static inline T* aalloc(Exec& e, size_t count) { return (T*)e.u->arena.alloc(count * sizeof(T)); }
+static inline int aalloc_checked(Exec& e, size_t count, T** out) {
+  *out = (T*)e.u->arena.alloc(count * sizeof(T));
+  ISHAP_REQUIRE(*out != nullptr, "activation arena exhausted (shape beyond what ishap_unet_create sized for)");
+  return 0;
+}
+#define ISHAP_ALLOC(ptr, e, count) ISHAP_TRY(aalloc_checked((e), (size_t)(count), &(ptr)))
+#define ISHAP_SALLOC(ptr, e, count)                                                                   \
+  do {                                                                                                \
+    (ptr) = salloc((e), (size_t)(count));                                                             \
+    ISHAP_REQUIRE((ptr) != nullptr, "GroupNorm statistics arena exhausted");                          \
+  } while (0)
 // X [N,H,W,ldx] (*) Wt -> out; taps 9 (3x3, pad 1) or 1; picks split-K and uses the context workspace
 int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps, int cout,
             const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups, int res_ups,

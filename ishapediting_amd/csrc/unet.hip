@@ -304,15 +304,15 @@ static int res_forward(Exec& e, ResL& L, const Tensor& x, Tensor& y) {
   const int N = x.N, H = x.H, W = x.W;
   const int Ho = L.down ? H / 2 : (L.up ? H * 2 : H), Wo = L.down ? W / 2 : (L.up ? W * 2 : W);
   ISHAP_REQUIRE(x.C == L.cin, "ResBlock input channels");
-  float* st1 = aalloc<float>(e, (size_t)N * 64);
-  float* st2 = aalloc<float>(e, (size_t)N * 64);
+  float* st1 = nullptr; ISHAP_ALLOC(st1, e, (size_t)N * 64);
+  float* st2 = nullptr; ISHAP_ALLOC(st2, e, (size_t)N * 64);
   const bool lazy_cat = x.cat_a != nullptr;
   ISHAP_REQUIRE(!lazy_cat || (!L.down && !L.up), "a skip concatenation feeds a plain ResBlock");
   if (!x.sums && !lazy_cat) ISHAP_TRY(gn_stats_op(e, x, st1));
   Tensor a{nullptr, N, L.down ? Ho : H, L.down ? Wo : W, L.cin};
-  a.p = aalloc<half_t>(e, a.numel());
+  ISHAP_ALLOC(a.p, e, a.numel());
   Tensor xs = x;
-  if (L.down) { xs = a; xs.p = aalloc<half_t>(e, a.numel()); }
+  if (L.down) { xs = a; ISHAP_ALLOC(xs.p, e, a.numel()); }
   if (!e.dry) {
     GnApplyArgs g;
     g.x = x.p; g.out = a.p; g.xpool = L.down ? xs.p : nullptr;
@@ -325,12 +325,12 @@ static int res_forward(Exec& e, ResL& L, const Tensor& x, Tensor& y) {
     ISHAP_TRY(gn_apply_launch(g, e.s));
   }
   Tensor h1{nullptr, N, Ho, Wo, L.cout};
-  h1.p = aalloc<half_t>(e, h1.numel());
-  h1.sums = salloc(e, (size_t)N * L.cout * 2);
+  ISHAP_ALLOC(h1.p, e, h1.numel());
+  ISHAP_SALLOC(h1.sums, e, (size_t)N * L.cout * 2);
   ISHAP_TRY(conv_op(e, a.p, N, Ho, Wo, L.cin, L.c1.w, L.c1.kpad, 9, L.cout, L.c1.bias, nullptr, 0, h1.p, L.cout, IG_OUT_F16,
                     L.up, 0, h1.sums));
   Tensor c = h1;
-  c.p = aalloc<half_t>(e, h1.numel());
+  ISHAP_ALLOC(c.p, e, h1.numel());
   if (!e.dry) {
     GnApplyArgs g;
     g.x = h1.p; g.out = c.p; g.stats = st2; g.sums = h1.sums; g.stats_out = st2; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
@@ -339,8 +339,8 @@ static int res_forward(Exec& e, ResL& L, const Tensor& x, Tensor& y) {
     ISHAP_TRY(gn_apply_launch(g, e.s));
   }
   y = h1;
-  y.p = aalloc<half_t>(e, h1.numel());
-  y.sums = salloc(e, (size_t)N * L.cout * 2);
+  ISHAP_ALLOC(y.p, e, h1.numel());
+  ISHAP_SALLOC(y.sums, e, (size_t)N * L.cout * 2);
   if (L.has_skip && L.c2.cat) {
     // y = conv2(c) + skip(x) as ONE launch: the 1x1 skip convolution is L.cin more K columns read from x
     ISHAP_TRY(conv_op(e, c.p, N, Ho, Wo, L.cout, L.c2.cat, L.c2.kpad, 9, L.cout, L.c2.bias, nullptr, 0, y.p, L.cout,
@@ -363,11 +363,11 @@ static int attn_forward(Exec& e, AttnL& L, const Tensor& x, Tensor& y) {
   const int N = x.N, T = x.H * x.W, C = L.C, heads = L.heads, d = C / heads;
   ISHAP_REQUIRE(x.C == C, "attention channels");
   ISHAP_REQUIRE(d % 32 == 0, "head width must be a multiple of 32");
-  float* st = aalloc<float>(e, (size_t)N * 64);
-  float* lse = aalloc<float>(e, (size_t)N * heads * T);
+  float* st = nullptr; ISHAP_ALLOC(st, e, (size_t)N * 64);
+  float* lse = nullptr; ISHAP_ALLOC(lse, e, (size_t)N * heads * T);
   if (!x.sums) ISHAP_TRY(gn_stats_op(e, x, st));
   Tensor nrm = x;
-  nrm.p = aalloc<half_t>(e, x.numel());
+  ISHAP_ALLOC(nrm.p, e, x.numel());
   if (!e.dry) {
     GnApplyArgs g;
     g.x = x.p; g.out = nrm.p; g.stats = st; g.sums = x.sums; g.stats_out = x.sums ? st : nullptr; g.gamma = L.n.gamma; g.beta = L.n.beta;
@@ -375,11 +375,11 @@ static int attn_forward(Exec& e, AttnL& L, const Tensor& x, Tensor& y) {
     ISHAP_TRY(gn_apply_launch(g, e.s));
   }
   Tensor qkv{nullptr, N, x.H, x.W, 3 * C};
-  qkv.p = aalloc<half_t>(e, qkv.numel());
+  ISHAP_ALLOC(qkv.p, e, qkv.numel());
   ISHAP_TRY(conv_op(e, nrm.p, N, x.H, x.W, C, L.qkv.w, L.qkv.kpad, 1, 3 * C, L.qkv.bias, nullptr, 0, qkv.p, 3 * C,
                     IG_OUT_F16, 0, 0));
   Tensor a = x;
-  a.p = aalloc<half_t>(e, x.numel());
+  ISHAP_ALLOC(a.p, e, x.numel());
   if (!e.dry) {
     // fused flash-style attention: w = softmax((q*s)^T (k*s)), a = w v   (unet.py:347-353)
     AttnArgs g;
@@ -388,8 +388,8 @@ static int attn_forward(Exec& e, AttnL& L, const Tensor& x, Tensor& y) {
     ISHAP_TRY(attn_forward_launch(g, e.s));
   }
   y = x;
-  y.p = aalloc<half_t>(e, x.numel());
-  y.sums = salloc(e, (size_t)N * C * 2);
+  ISHAP_ALLOC(y.p, e, x.numel());
+  ISHAP_SALLOC(y.sums, e, (size_t)N * C * 2);
   ISHAP_TRY(conv_op(e, a.p, N, x.H, x.W, C, L.proj.w, L.proj.kpad, 1, C, L.proj.bias, x.p, C, y.p, C, IG_OUT_F16, 0, 0,
                     y.sums));
   L.sv.x = x; L.sv.qkv = qkv; L.sv.a = a; L.sv.stats = st; L.sv.lse = lse; L.sv.P = nullptr;
@@ -402,8 +402,8 @@ static int block_forward(Exec& e, BlockL& b, Tensor h, Tensor& out) {
     Tensor y;
     if (l.kind == 0) {
       y = Tensor{nullptr, h.N, h.H, h.W, u->stem.cout};
-      y.p = aalloc<half_t>(e, y.numel());
-      y.sums = salloc(e, (size_t)h.N * u->stem.cout * 2);
+      ISHAP_ALLOC(y.p, e, y.numel());
+      ISHAP_SALLOC(y.sums, e, (size_t)h.N * u->stem.cout * 2);
       ISHAP_TRY(conv_op(e, h.p, h.N, h.H, h.W, h.C, u->stem.w, u->stem.kpad, 9, u->stem.cout, u->stem.bias, nullptr, 0, y.p,
                         u->stem.cout, IG_OUT_F16, 0, 0, y.sums));
     } else if (l.kind == 1) {
@@ -441,7 +441,7 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
   }
   // ---- x: NCHW fp32 -> NHWC fp16 (h = x.type(self.dtype), unet.py:657) ----
   Tensor h{nullptr, N, S, S, u->in_pad};
-  h.p = aalloc<half_t>(e, h.numel());
+  ISHAP_ALLOC(h.p, e, h.numel());
   if (!dry) ISHAP_TRY(nchw_f32_to_nhwc_f16(x, h.p, N, cfg.in_channels, HW, u->in_pad, s));
   u->x0 = h;
   std::vector<Tensor> hs;
@@ -463,7 +463,7 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     hs.pop_back();
     Tensor cat{nullptr, h.N, h.H, h.W, h.C + skip.C};
     ISHAP_REQUIRE(skip.H == h.H && cat.C == b.cin, "skip connection shape");
-    cat.p = aalloc<half_t>(e, cat.numel());
+    ISHAP_ALLOC(cat.p, e, cat.numel());
     if (h.sums && skip.sums && h.C % 8 == 0 && b.layers[0].kind == 1) {
       // no copy pass: the ResBlock's first GroupNorm reads both halves and writes the concatenation as it goes
       cat.cat_a = h.p; cat.cat_b = skip.p; cat.cat_sa = h.sums; cat.cat_sb = skip.sums; cat.cat_ca = h.C;
@@ -480,9 +480,9 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
   u->h_final = h;
   // ---- head in fp32 (unet.py:667-669): GroupNorm, SiLU, 3x3 conv with fp32 weights.  The fp32 products are
   //      formed on the fp16 MFMA from hi/lo splits of both operands (3 partial products, fp32 accumulate). ----
-  u->head_stats = aalloc<float>(e, (size_t)N * 64);
+  ISHAP_ALLOC(u->head_stats, e, (size_t)N * 64);
   if (!h.sums) ISHAP_TRY(gn_stats_op(e, h, u->head_stats));
-  half_t* hsplit = aalloc<half_t>(e, (size_t)h.numel() * 3);
+  half_t* hsplit = nullptr; ISHAP_ALLOC(hsplit, e, (size_t)h.numel() * 3);
   if (!dry) {
     GnApplyArgs g;
     g.x = h.p; g.out = hsplit; g.stats = u->head_stats; g.sums = h.sums; g.stats_out = h.sums ? u->head_stats : nullptr;
@@ -496,7 +496,7 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     ISHAP_TRY(nhwc_f16_to_nchw(u->tap.p, inter_feat, 0, N, u->tap.C, u->tap.H * u->tap.W, u->tap.C, s));
   u->last_N = N;
   u->last_feat = feat_layer;
-  u->have_saved = keep != 0;
+  u->have_saved = keep != 0 && !dry;
   u->fwd_mark = u->arena.off;
   u->stat_fwd_mark = u->stat_off;
   u->bwd_since_fwd = 0;
@@ -526,14 +526,13 @@ int ishap_unet_create(const ishap_unet_config* cfg, int device, ishap_unet** out
   u->device = device;
   int r = unet_build(u);
   if (r) { delete u; return r; }
-  // size the arena / workspaces with a dry run of forward + backward at max batch
+  // size the arena / workspaces with dry runs of forward + backward at EVERY batch size a call may use: the split-K
+  // policy depends on M = N*H*W, so a smaller batch can need a larger fp32 partial workspace than max_batch does
   u->arena.dry = true;
   std::vector<float> ts(cfg->max_batch, 0.f);
-  r = unet_forward_impl(u, nullptr, ts.data(), cfg->max_batch, (int)u->out_blocks.size() - 1, nullptr, nullptr, 1, 0, true);
-  size_t fwd_high = u->arena.high;
-  if (!r) {
-    u->arena.off = fwd_high;     // backward allocates on top of the kept forward state
-    r = unet_backward_impl(u, nullptr, (const void*)0x1000, 0, nullptr, nullptr, 0, true);
+  for (int nb = 1; nb <= cfg->max_batch && !r; ++nb) {
+    r = unet_forward_impl(u, nullptr, ts.data(), nb, (int)u->out_blocks.size() - 1, nullptr, nullptr, 1, 0, true);
+    if (!r) r = unet_backward_impl(u, nullptr, (const void*)0x1000, 0, nullptr, nullptr, 0, true);   // on top of the kept forward state
   }
   if (r) { delete u; return r; }
   u->arena.dry = false;
@@ -610,6 +609,27 @@ int ishap_unet_tap_shape(const ishap_unet* u, int feat_layer, int* channels, int
 }
 
 const void* ishap_unet_tap_ptr(const ishap_unet* u) { return u ? u->tap.p : nullptr; }
+
+long long ishap_unet_workspace_bytes(const ishap_unet* u) {
+  if (!u) return 0;
+  return (long long)(u->arena.cap + u->ws_floats * sizeof(float) + u->gn_partial_floats * sizeof(float) +
+                     u->stat_cap * sizeof(long long) + u->attn_D_floats * sizeof(float));
+}
+
+int ishap_unet_block_output(const ishap_unet* u, int group, int index, int* channels, int* size, void* dst_nchw_f16,
+                            void* stream) {
+  ISHAP_REQUIRE(u && group >= 0 && group <= 2, "group: 0 input_blocks, 1 middle_block, 2 output_blocks");
+  const BlockL* b = nullptr;
+  if (group == 0) { ISHAP_REQUIRE(index >= 0 && index < (int)u->in_blocks.size(), "input block index"); b = &u->in_blocks[index]; }
+  else if (group == 1) b = &u->mid;
+  else { ISHAP_REQUIRE(index >= 0 && index < (int)u->out_blocks.size(), "output block index"); b = &u->out_blocks[index]; }
+  if (channels) *channels = b->cout;
+  if (size) *size = b->res_out;
+  if (!dst_nchw_f16) return 0;
+  ISHAP_REQUIRE(u->have_saved && b->out.p, "block outputs stay resident only after a forward with keep_for_backward=1");
+  ISHAP_CHECK_HIP(hipSetDevice(u->device));
+  return nhwc_f16_to_nchw(b->out.p, dst_nchw_f16, 0, b->out.N, b->out.C, b->out.H * b->out.W, b->out.C, (hipStream_t)stream);
+}
 
 int ishap_unet_copy_tap(const ishap_unet* u, void* dst, void* stream) {
   ISHAP_REQUIRE(u && dst && u->tap.p, "no resident tap (run a forward with feat_layer >= 0 first)");

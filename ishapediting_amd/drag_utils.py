@@ -345,6 +345,8 @@ class DragStuff:
         sampling (:418-440) when given; the mesh-file route needs Open3D like the reference."""
         if tri_feat_path is not None:
             img = th.tensor(np.load(tri_feat_path), device=self.device)
+            if img.dim() == 3:        # a CHW file (generate.py's triplanes/{i}.npy layout): the model wants a batch axis
+                img = img.unsqueeze(0)
             self.mesh = self.get_mesh(img)
             self.mesh0 = copy.deepcopy(self.mesh)
             self.latent_inversion(tri_feat=img)

@@ -54,10 +54,14 @@ def decode_to_obj(triplane_chw: np.ndarray, decoder: MultiTriplane, res: int, ou
     return vol
 
 
-def main(argv=None):
+def main(argv=None, overrides=None):
+    """generate.py:14-98.  `overrides`: attribute values replacing the hard-wired model hyper-parameters of the
+    namespace (:63-70) -- used by tests that run the CLI on a small model."""
     args = build_parser().parse_args(argv)
     os.makedirs(args.save_dir, exist_ok=True)
     ddpm_args = ddpm_namespace(args)
+    for k, v in (overrides or {}).items():
+        setattr(ddpm_args, k, v)
     sd = bounds = dec_sd = None
     if args.synthetic:
         from . import synthetic

@@ -156,6 +156,20 @@ class UNetModel:
             _lib.check(self._L.ishap_unet_copy_tap(self._h, t.data_ptr(), _lib.stream_ptr(self.device)))
         return t
 
+    def block_output(self, group: int, index: int = 0, N: int = 1) -> torch.Tensor:
+        """Output of input_blocks[index] (group 0), middle_block (1) or output_blocks[index] (2) of the last
+        forward(keep_for_backward=True), as fp16 NCHW like the reference's activations."""
+        ch, sz = C.c_int(), C.c_int()
+        _lib.check(self._L.ishap_unet_block_output(self._h, group, index, C.byref(ch), C.byref(sz), None, None))
+        t = torch.empty((N, ch.value, sz.value, sz.value), dtype=torch.float16, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ishap_unet_block_output(self._h, group, index, C.byref(ch), C.byref(sz), t.data_ptr(),
+                                                       _lib.stream_ptr(self.device)))
+        return t
+
+    def workspace_bytes(self) -> int:
+        return int(self._L.ishap_unet_workspace_bytes(self._h))
+
     def backward_input(self, cot_nhwc_f16: torch.Tensor, scale2: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Gradient w.r.t. x of sum(tap * cot) for the last forward(keep_for_backward=True)."""
         dx = torch.empty(self._last_shape, dtype=torch.float32, device=self.device)

@@ -428,12 +428,14 @@ def drag_loop(diff: DiffusionOracle, unet: UNetOracle, w, cache, setup: DragSetu
     return img, losses
 
 
-def reconstruct_loop(diff: DiffusionOracle, unet: UNetOracle, net, img, rng, mid, coords, gts, noises, scale=600.0):
+def reconstruct_loop(diff: DiffusionOracle, unet: UNetOracle, net, img, rng, mid, coords, gts, noises, scale=600.0,
+                     steps=None):
     """drag_utils.py:445-463 (train_triplane's guided loop) for given point batches: per step decode pred_xstart on the
-    batch, loss = -BCEWithLogits, img <- sample + variance * scale * d loss / d img."""
+    batch, loss = -BCEWithLogits, img <- sample + variance * scale * d loss / d img.  `steps` (loop indices, default the
+    whole schedule T-1..0) lets shortened runs start mid-schedule; coords/gts/noises are indexed by position k."""
     T = diff.tb.num_timesteps
     imgs, losses, grads = [], [], []
-    for k, i in enumerate(range(T - 1, -1, -1)):
+    for k, i in enumerate(steps if steps is not None else range(T - 1, -1, -1)):
         img = img.detach().requires_grad_(True)
         o = diff.p_sample_guidance(unet, img, i, noise=noises[k])
         S = img.shape[-1]

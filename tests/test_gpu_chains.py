@@ -1,0 +1,321 @@
+"""Round-2 parity tests through the C ABI: the inversion entry (golden G8), the generate path (golden G12), per-block
+localisation (golden G4b), the checkpoint-tree / file-format route, context robustness (batch sizes below max_batch,
+over-size batch, worker thread + side stream).  Needs an MI355X: -m gpu.  Nothing here reads /root/reference."""
+import os
+import threading
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from ishapediting_amd import synthetic
+from ishapediting_amd.unet_spec import UNetConfig, build_spec, tiny_config
+from tests.helpers import redraw_generate_noise, small96_args, small96_config
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda", 0)
+
+
+def rel(a, b):
+    a = a.detach().float().cpu()
+    b = torch.as_tensor(b).float()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def tiny_args(Tn, w_time, feat_layer):
+    return Namespace(clip_denoised=True, num_samples=1, batch_size=1, use_ddim=False, num_steps=Tn, image_size=16,
+                     num_channels=32, num_res_blocks=1, num_heads=4, num_heads_upsample=-1, num_head_channels=32,
+                     attention_resolutions="8", channel_mult="1,2", dropout=0.1, class_cond=False, shape_resolution=32,
+                     use_checkpoint=False, use_scale_shift_norm=True, resblock_updown=True, use_fp16=True,
+                     use_new_attention_order=False, in_out_channels=6, learn_sigma=True, diffusion_steps=1000,
+                     noise_schedule="linear", timestep_respacing=str(Tn), w_time=w_time, feat_layer=feat_layer,
+                     loss_type="l2", use_kl=False, predict_xstart=False, rescale_timesteps=False,
+                     rescale_learned_sigmas=False, explicit_normalization=False)
+
+
+# ------------------------------------------------------------------------------------------ a9: ddpm_inversion vs G8
+def test_latent_inversion_vs_reference_run(gold):
+    """DragStuff.latent_inversion (drag_utils.py:552-566 -> gaussian_diffusion.py:512-532) on the tiny model against the
+    reference's own ddpm_inversion run (golden G8, fp32 CPU, noise drawn under torch.manual_seed and stored).
+    Tolerances (fp16 torso vs fp32, 3 chained steps, as for the G9 loops): latent (pure forward noising) 1e-5 abs;
+    variance 1e-2 rel; variance_noise / sample / taps 2e-2 relative L2."""
+    from ishapediting_amd.drag_utils import DragStuff, resize_feat_align
+    g = gold("g8_g9_tiny_loops")
+    Tn, w_time, feat_layer, r1, B = g["meta"].tolist()
+    ds = DragStuff(dev(), args=tiny_args(Tn, w_time, feat_layer))
+    ds.model.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(tiny_config(1), 101)))
+    captured = []
+    ds.get_mesh = lambda tri_feat=None, img=None, t=0: captured.append(tri_feat)
+    fwd = [n.to(dev()) for n in T(g["inv_fwd_noise"])]
+    ds.latent_inversion(T(g["inv_x0"]).to(dev()), fwd_noise=fwd)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(ds.w.cpu().numpy(), g["inv_latent"], rtol=0, atol=1e-5)
+    assert torch.equal(ds.w, ds.w0)
+    assert len(ds.variance) == len(ds.variance_noise) == len(ds.feature_guidance) == w_time
+    r_var = rel(torch.stack(ds.variance), g["inv_variance"])
+    r_vn = rel(torch.stack(ds.variance_noise), g["inv_variance_noise"])
+    r_s = rel(captured[-1], g["inv_sample"])
+    print(f"inversion: variance {r_var:.2e}, variance_noise {r_vn:.2e}, sample {r_s:.2e}")
+    assert r_var < 1e-2 and r_vn < 2e-2 and r_s < 2e-2
+    # the round-trip identity the construction guarantees (:530-531): img = mean + (x_i - mean) = x_i, so sample ~ x_0
+    assert rel(captured[-1], g["inv_x0"]) < 1e-5
+    ch, sz = ds.model.tap_shape(feat_layer)
+    for k, tap in enumerate(ds.feature_guidance):      # reverse-loop order i = w_time-1 .. 0, like the reference's list
+        nchw = tap.reshape(sz, sz, ch).permute(2, 0, 1).unsqueeze(0).float()
+        assert rel(nchw, g["inv_inter_feat"][k]) < 2e-2, k
+        assert resize_feat_align(nchw).shape[0] == 3
+
+
+# ------------------------------------------------------------------------------------------ a18: generate path vs G12
+@pytest.mark.parametrize("B", [1, 3])
+def test_noise2shape_vs_reference_p_sample_loop(gold, B):
+    """image_sample.noise2shape (image_sample.py:138-201) against the reference's own p_sample_loop + unnormalize + NHWC
+    permute (golden G12; the reference drew th.randn(*shape) and randn_like per step, the test redraws that stream).
+    Tolerance: relative L2 <= 2e-2 on the final un-normalised triplanes (fp16 torso vs fp32 over 5 chained p_sample steps,
+    the first of which amplifies by sqrt(1/alpha_bar) ~ 157 before the clip), per image <= 3e-2."""
+    from ishapediting_amd import image_sample
+    g = gold("g12_generate")
+    Tn = int(g["T"])
+    init, steps = redraw_generate_noise(g, B)
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(small96_config(), 303))
+    args = small96_args(Tn, batch=B)
+    stepd = steps.to(dev())
+    arr = image_sample.noise2shape(args, state_dict=sd, bounds=(g["lower_bound"], g["upper_bound"]),
+                                   noise=init.to(dev()), step_noise=lambda i: stepd[Tn - 1 - i])
+    assert arr.shape == (B, 16, 16, 96) and arr.dtype == np.float32
+    want = g[f"b{B}_arr"]
+    r = rel(T(arr), want)
+    per = [rel(T(arr[b]), want[b]) for b in range(B)]
+    print(f"noise2shape batch {B}: rel {r:.2e}, per image {['%.2e' % p for p in per]}")
+    assert r < 2e-2 and max(per) < 3e-2
+
+
+# ------------------------------------------------------------------------------------------ per-block localisation
+@pytest.mark.parametrize("nrb", [1, 2])
+def test_every_block_output_vs_reference_hooks(gold, nrb):
+    """Each TimestepEmbedSequential's output of the tiny UNet against forward hooks on the reference model (golden G4b):
+    plain / down / up ResBlocks, attention, skip concatenation are each pinned on their own, so compensating errors inside
+    one block cannot hide behind the whole-network taps.  Tolerance 1e-2 relative L2 (fp16 torso vs fp32)."""
+    from ishapediting_amd.unet import UNetModel
+    g4, gb = gold("g4_tiny_unet"), gold("g4b_block_outputs")
+    cfg = tiny_config(nrb)
+    spec = build_spec(cfg)
+    m = UNetModel(cfg, dev())
+    m.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 100 + nrb)))
+    with pytest.raises(RuntimeError):
+        m.block_output(1)                      # nothing resident before a forward
+    m(T(g4[f"nrb{nrb}_x"]).to(dev()), T(g4[f"nrb{nrb}_ts"]), feat_layer=0, keep_for_backward=True, want_inter_feat=False)
+    worst = 0.0
+    for i in range(len(spec.input_blocks)):
+        worst = max(worst, rel(m.block_output(0, i), gb[f"nrb{nrb}_in{i}"]))
+        assert rel(m.block_output(0, i), gb[f"nrb{nrb}_in{i}"]) < 1e-2, ("in", i)
+    assert rel(m.block_output(1), gb[f"nrb{nrb}_mid"]) < 1e-2
+    for i in range(len(spec.output_blocks)):
+        worst = max(worst, rel(m.block_output(2, i), gb[f"nrb{nrb}_out{i}"]))
+        assert rel(m.block_output(2, i), gb[f"nrb{nrb}_out{i}"]) < 1e-2, ("out", i)
+    print(f"nrb={nrb}: worst block rel err {worst:.2e}")
+    assert m.workspace_bytes() > 0
+
+
+# ------------------------------------------------------------------------------------------ context robustness
+def _cfg64():
+    return UNetConfig(image_size=16, in_channels=6, model_channels=64, out_channels=12, num_res_blocks=1,
+                      attention_resolutions="8", channel_mult=(1, 2), num_head_channels=64)
+
+
+def test_smaller_batches_on_a_context_built_for_more():
+    """A context created for max_batch = 3 must serve N = 1 and N = 2 as well (the split-K policy depends on N*H*W, so the
+    fp32 partial workspace is sized over every batch size at create time): forward + backward against contexts built for
+    exactly that N.  Same kernels on both sides for equal N -> bitwise equal."""
+    from ishapediting_amd.unet import UNetModel
+    cfg = _cfg64()
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 79))
+    big = UNetModel(cfg, dev(), max_batch=3)
+    big.load_state_dict(sd)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(3, 6, 16, 16, generator=g).to(dev())
+    ts = [11.0, 480.0, 902.0]
+    k = len(build_spec(cfg).output_blocks) - 2
+    ch, sz = big.tap_shape(k)
+    cot = (torch.randn(3, sz * sz, ch, generator=g) * 0.1).half().to(dev())
+    for n in (1, 2, 3):
+        own = UNetModel(cfg, dev(), max_batch=n)
+        own.load_state_dict(sd)
+        o_big, _ = big(x[:n], ts[:n], feat_layer=k, keep_for_backward=True)
+        g_big = big.backward_input(cot[:n].contiguous())
+        o_own, _ = own(x[:n], ts[:n], feat_layer=k, keep_for_backward=True)
+        g_own = own.backward_input(cot[:n].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(o_big, o_own), n
+        assert torch.equal(g_big, g_own), n
+
+
+def test_full_size_context_for_batch_2_serves_batch_1():
+    """The ADVICE case at the real sizes: at max_batch = 2 the 421M model's N = 1 launches need a larger split-K
+    workspace (dgrad M = 4096, N = 768, K = 2304 splits by 2) than any N = 2 launch."""
+    from ishapediting_amd.unet import UNetModel
+    from ishapediting_amd.unet_spec import full_config
+    cfg = full_config()
+    m = UNetModel(cfg, dev(), max_batch=2)
+    m.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 1234)))
+    x = torch.from_numpy(synthetic.latent(4)).to(dev())
+    ch, sz = m.tap_shape(8)
+    cot = (torch.randn(sz * sz, ch, generator=torch.Generator().manual_seed(2)) * 0.05).half().to(dev())
+    out, _ = m(x, [500.0], feat_layer=8, keep_for_backward=True, want_inter_feat=False)
+    gx = m.backward_input(cot)
+    out2, _ = m(torch.cat([x, x]), [500.0, 500.0], feat_layer=8, keep_for_backward=True, want_inter_feat=False)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(gx).all()) and float(gx.abs().max()) > 0
+    assert rel(out2[:1], out.cpu()) < 5e-3 and rel(out2[1:], out.cpu()) < 5e-3
+
+
+def test_batch_beyond_max_batch_is_rejected_with_a_message():
+    from ishapediting_amd.unet import UNetModel
+    cfg = tiny_config(1)
+    m = UNetModel(cfg, dev(), max_batch=1)
+    m.load_state_dict(synthetic.unet_state_dict(cfg, 1))
+    with pytest.raises(RuntimeError, match="batch size outside"):
+        m(torch.zeros(2, 6, 16, 16, device=dev()), [0, 0])
+    out = m(torch.zeros(1, 6, 16, 16, device=dev()), [0])         # the context is still usable afterwards
+    assert bool(torch.isfinite(out).all())
+
+
+def test_training_from_a_worker_thread_on_a_side_stream(gold):
+    """Every heavy call of the GUI arrives on a non-main Python thread (main.py:266,283,447,480).  The same edit run on
+    the main thread / default stream and on a worker thread under a non-default torch stream must agree bitwise."""
+    from ishapediting_amd.drag_utils import DragStuff
+    g = gold("g8_g9_tiny_loops")
+    Tn, w_time, feat_layer, r1, B = g["meta"].tolist()
+    ds = DragStuff(dev(), args=tiny_args(Tn, w_time, feat_layer))
+    ds.model.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(tiny_config(1), 101)))
+    finals = []
+    ds.get_mesh = lambda tri_feat=None, img=None, t=0: finals.append(img if img is not None else tri_feat)
+    ns = T(g["loop_noise_sampling"]).to(dev())
+    dn = T(g["drag_noise"]).to(dev())
+
+    def edit():
+        ds.clear_params()
+        ds.step_noise = lambda i: ns[Tn - 1 - i]
+        ds.update_latent_params(img=g["loop_latent0"])
+        ds.set_offset1(r1)
+        ds.voxel_size = 2.0 / 32
+        ds.step_noise = lambda i: dn[w_time - 1 - i]
+        prog = list(ds.training(g["drag_sources"], g["drag_targets"], scale=50.0, cof=0.4))
+        torch.cuda.synchronize()
+        return prog
+
+    prog_main = edit()
+    ref = finals[-1].clone()
+    result = {}
+
+    def worker():
+        try:
+            s = torch.cuda.Stream(device=dev())
+            with torch.cuda.stream(s):
+                result["prog"] = edit()
+                s.synchronize()
+        except BaseException as e:          # surfaced below: a failure on the thread must fail the test
+            result["err"] = e
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join(timeout=300)
+    assert not t.is_alive() and "err" not in result, result.get("err")
+    assert result["prog"] == prog_main
+    assert torch.equal(finals[-1], ref)
+    assert rel(finals[-1], g["drag_final"]) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------ f3: checkpoint tree + files
+def test_checkpoint_tree_generate_cli_and_tri_feat_round_trip(tmp_path, monkeypatch):
+    """the directory walk of update_model_params (drag_utils.py:211-249: models/<cat>/{ddpm*/ema*, *.pt,
+    statistics/<dir>/{lower,upper}_bound.npy}, strict state_dict), the generate CLI's files (generate.py:80-95:
+    <save_dir>/triplanes/{i}.npy CHW, objects/{i}.obj) and the tri_feat.npy re-use route of main.py:446-448."""
+    from ishapediting_amd import generate, image_sample
+    from ishapediting_amd.drag_utils import DragStuff
+    from ishapediting_amd.mesh import read_obj
+    cfg = small96_config()
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 202))
+    dec_sd = synthetic.decoder_state_dict()
+    rs = np.random.RandomState(3)
+    lower = -(0.02 + 0.03 * rs.rand(96)).astype(np.float32)
+    upper = (0.02 + 0.03 * rs.rand(96)).astype(np.float32)
+    root = tmp_path / "models" / "chairs"
+    (root / "ddpm_chairs_ckpts").mkdir(parents=True)
+    (root / "statistics" / "chairs_triplanes_stats").mkdir(parents=True)
+    torch.save(sd, root / "ddpm_chairs_ckpts" / "ema_0.9999_200000.pt")
+    torch.save({"junk": torch.zeros(1)}, root / "ddpm_chairs_ckpts" / "model200000.pt")    # not "ema*": must be ignored
+    torch.save(dec_sd, root / "chair_decoder.pt")
+    np.save(root / "statistics" / "chairs_triplanes_stats" / "lower_bound.npy", lower)
+    np.save(root / "statistics" / "chairs_triplanes_stats" / "upper_bound.npy", upper)
+    monkeypatch.chdir(tmp_path)
+    Tn = 4
+    ds = DragStuff(dev(), args=small96_args(Tn, w_time=2, feat_layer=1))
+    ds.update_model_params("./models/chairs")
+    assert ds.args.model_path.endswith("ema_0.9999_200000.pt") and ds.args.decoder_ckpt.endswith("chair_decoder.pt")
+    assert ds.args.stats_dir.endswith("chairs_triplanes_stats")
+    assert ds.args.save_dir == os.path.join("samples", "chairs_samples") and os.path.isdir(ds.args.save_dir)
+    np.testing.assert_allclose(ds.range.reshape(-1).cpu().numpy(), (upper - lower) / 2, rtol=1e-6)
+    np.testing.assert_allclose(ds.middle.reshape(-1).cpu().numpy(), (upper + lower) / 2, rtol=1e-6, atol=1e-9)
+    # strict=True (drag_utils.py:229-230): a checkpoint with a foreign key must not load
+    bad = dict(sd)
+    bad["input_blocks.99.0.weight"] = torch.zeros(1)
+    torch.save(bad, root / "ddpm_chairs_ckpts" / "ema_0.9999_200000.pt")
+    with pytest.raises(RuntimeError, match="unexpected"):
+        DragStuff(dev(), args=small96_args(Tn, w_time=2, feat_layer=1)).update_model_params("./models/chairs")
+    torch.save(sd, root / "ddpm_chairs_ckpts" / "ema_0.9999_200000.pt")
+
+    # ---- generate CLI on the same tree ----
+    over = dict(num_channels=32, num_res_blocks=1, num_head_channels=32, attention_resolutions="8", channel_mult="1,2")
+    argv = ["--resolution", "16", "--ddpm_ckpt", str(root / "ddpm_chairs_ckpts" / "ema_0.9999_200000.pt"),
+            "--decoder_ckpt", str(root / "chair_decoder.pt"), "--stats_dir", str(root / "statistics" / "chairs_triplanes_stats"),
+            "--save_dir", "samples/chairs_samples", "--num_samples", "2", "--batch_size", "2", "--num_steps", str(Tn),
+            "--shape_resolution", "32"]
+    torch.manual_seed(7)
+    generate.main(argv, overrides=over)
+    tri = [np.load(f"samples/chairs_samples/triplanes/{i}.npy") for i in range(2)]
+    assert all(t.shape == (96, 16, 16) and t.dtype == np.float32 and np.isfinite(t).all() for t in tri)   # CHW
+    # the same seed through noise2shape directly: the files are its NHWC result transposed (generate.py:80)
+    args2 = generate.ddpm_namespace(generate.build_parser().parse_args(argv))
+    for k, v in over.items():
+        setattr(args2, k, v)
+    torch.manual_seed(7)
+    arr = image_sample.noise2shape(args2)
+    np.testing.assert_array_equal(np.transpose(arr, [0, 3, 1, 2])[0], tri[0])
+    # un-normalised values lie inside the bounds (x0 is clipped to [-1, 1] at t = 0, then x*range + middle)
+    assert (tri[0] <= upper[:, None, None] + 1e-6).all() and (tri[0] >= lower[:, None, None] - 1e-6).all()
+    for i in range(2):
+        v, f = read_obj(f"samples/chairs_samples/objects/{i}.obj")
+        assert v.shape[1] == 3 and f.shape[1] == 3 and f.max() < v.shape[0]
+        if v.shape[0]:
+            assert float(np.abs(v).max()) <= 1.0 + 1e-3          # create_obj's vertex rescale: / 255 * 2 - 1 territory
+
+    # ---- tri_feat.npy: written by train_triplane, re-used through tri_feat_path (main.py:446-448) ----
+    g = torch.Generator().manual_seed(5)
+    pts = torch.rand(4096, 3, generator=g) * 2 - 1
+    occ = (pts.norm(dim=1) < 0.6).float()
+    noise = torch.randn(Tn, 1, 96, 16, 16, generator=g).to(dev())
+    ds.step_noise = lambda i: noise[i]
+    ds.train_triplane(points=pts, occupancies=occ, path=str(tmp_path))
+    saved = np.load(tmp_path / "tri_feat.npy")
+    assert saved.shape == (1, 96, 16, 16) and os.path.exists(tmp_path / "mesh_recon.obj")
+    w_first, taps_first = ds.w.clone(), [t.clone() for t in ds.feature_guidance]
+    fwd = [torch.randn(1, 96, 16, 16, generator=g).to(dev()) for _ in range(2)]
+    ds2 = DragStuff(dev(), args=small96_args(Tn, w_time=2, feat_layer=1))
+    ds2.update_model_params("./models/chairs")
+    inv_orig = ds2.latent_inversion
+    ds2.latent_inversion = lambda tri_feat: inv_orig(tri_feat, fwd_noise=fwd)
+    ds2.train_triplane(tri_feat_path=str(tmp_path / "tri_feat.npy"))
+    assert tuple(ds2.w.shape) == (1, 96, 16, 16) and len(ds2.feature_guidance) == 2 and ds2.mesh is not None
+    # the inverted chain reproduces the stored triplane: sample == x_0 by construction
+    assert rel(ds2.tri_feat, saved) < 1e-5
+    # a CHW file (generate.py's layout) is accepted on the same route
+    np.save(tmp_path / "chw.npy", saved[0])
+    ds2.train_triplane(tri_feat_path=str(tmp_path / "chw.npy"))
+    assert tuple(ds2.w.shape) == (1, 96, 16, 16)
+    assert w_first.shape == ds2.w.shape and len(taps_first) == 2

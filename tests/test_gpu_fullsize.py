@@ -276,3 +276,128 @@ def test_shortened_c3_edit_against_the_oracle():
         assert abs(a - float(b)) <= 2e-2 * abs(float(b)) + 1e-7
     # the guidance must matter for this to be a test of the gradient path
     assert rel(lat_dev, d.w0.cpu()) > 1e-2
+
+
+def test_shortened_c4_chain_against_the_oracle():
+    """BASELINE configs[3] (real shape: triplane reconstruction -> DDPM inversion -> drag edit -> decode), shortened so the
+    CPU oracle finishes in seconds, at full size (421M UNet, 64^2 x 512 tap): 2 reconstruction steps (full UNet forward,
+    decoder BCE on 4096 occupancy samples of an analytic sphere, full-depth input-gradient backward, guided update;
+    drag_utils.py:445-463), inversion over w_time = 2 (gaussian_diffusion.py:512-532), 2 guided drag iterations
+    (drag_utils.py:336-398), 64^3 decode.  Every stage is compared with the fp32 oracle run on the device's own
+    stage input (so each tolerance measures one stage) and the chain end to end.
+    Tolerances: losses 2 % relative; latents 5e-3 relative L2 per stage (reconstruction 1e-2: fp16 gradient maps with a
+    loss scale against fp32 autograd); end-to-end logit RMS error <= 2 % of RMS."""
+    import os
+    from oracle import ref_cpu as O
+    from ishapediting_amd.drag_utils import DragStuff, get_args
+    from ishapediting_amd.unet_spec import build_spec, full_config
+    dev = torch.device("cuda", 0)
+    T, W, res = 6, 2, 64
+    cfg = full_config()
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 1234))
+    dec_sd = synthetic.decoder_state_dict(4321)
+    lo, hi = -0.05 * np.ones(96, np.float32), 0.05 * np.ones(96, np.float32)
+    rng = torch.from_numpy((hi - lo) / 2).reshape(1, 96, 1, 1)
+    mid = torch.from_numpy((hi + lo) / 2).reshape(1, 96, 1, 1)
+    gen = torch.Generator().manual_seed(77)
+    img0 = torch.randn(1, 96, 128, 128, generator=gen) * 0.6           # a mid-schedule latent (steps 1 and 0 of T = 6)
+    coords = torch.rand(2, 4096, 3, generator=gen) * 2 - 1
+    gts = (coords.norm(dim=-1, keepdim=True) < 0.6).float()
+    n_rec = torch.randn(2, 1, 96, 128, 128, generator=gen)
+    n_fwd = [torch.randn(1, 96, 128, 128, generator=gen) for _ in range(W)]
+    n_drag = [torch.randn(1, 96, 128, 128, generator=gen) for _ in range(W)]
+    src, tgt = synthetic.handles(3)
+    d = DragStuff(dev, args=get_args(["--w_time", str(W), "--num_steps", str(T), "--shape_resolution", str(res)]))
+    d.load_weights(sd, dec_sd, lo, hi)
+    # ---- device ----
+    rec_steps = [1, 0]
+    d.step_noise = lambda i: n_rec[rec_steps.index(i)].to(dev)
+    cd, gd = coords.to(dev), gts.to(dev)
+    rec_dev = d.reconstruct(None, None, scale=600, img=img0, batch_fn=lambda i: (cd[rec_steps.index(i)], gd[rec_steps.index(i)].reshape(-1)),
+                            steps=rec_steps)
+    loss_rec_dev = [float(l) for l in d.last_losses]
+    d.clear_params()
+    d.latent_inversion(rec_dev, fwd_noise=[n.to(dev) for n in n_fwd])
+    w_dev = d.w.clone()
+    vn_dev = torch.stack(d.variance_noise).cpu()
+    d.step_noise = lambda i: n_drag[W - 1 - i].to(dev)
+    for _ in d.training(src, tgt, scale=1200.0, cof=0.4):
+        pass
+    torch.cuda.synchronize()
+    final_dev, vol_dev = d.tri_feat.cpu(), d.volume.cpu()
+    loss_drag_dev = [float(l) for l in d.last_losses]
+    # ---- oracle, stage by stage from the device's stage inputs ----
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    net = O.UNetOracle(build_spec(cfg), sd, fp16=False)
+    diff = O.DiffusionOracle(O.Tables(str(T)))
+    imgs, losses, _ = O.reconstruct_loop(diff, net, dec_sd, img0, rng, mid, coords, gts, n_rec, scale=600.0, steps=rec_steps)
+    r_rec = rel(rec_dev.cpu(), imgs[-1])
+    rec_in = rec_dev.cpu()
+    with torch.no_grad():
+        inv = diff.ddpm_inversion(net, rec_in, W, n_fwd, feat_layer=8)
+    r_w = rel(w_dev.cpu(), inv["latent"])
+    r_vn = rel(vn_dev, torch.stack(inv["variance_noise"]))
+    cache = [O.resize_feat_align(f) for f in inv["inter_feat"]]
+    setup = O.DragSetup(src, tgt, 12, 2.0 / res, cache[0].shape[-1])
+    final_ref, loss_drag_ref = O.drag_loop(diff, net, w_dev.cpu(), cache, setup, W, 8, 1200.0, 0.4,
+                                           {W - 1 - k: n_drag[k] for k in range(W)})
+    with torch.no_grad():
+        vol_ref = O.decode_volume(dec_sd, final_ref, rng, mid, res)
+    r_fin = rel(final_dev, final_ref.detach())
+    r_vol = float((vol_dev - vol_ref).pow(2).mean().sqrt()) / float(vol_ref.pow(2).mean().sqrt())
+    print(f"short C4: recon latent {r_rec:.2e} (losses {loss_rec_dev} vs {[float(l) for l in losses]}), inversion latent {r_w:.2e}, "
+          f"variance_noise {r_vn:.2e}, drag final {r_fin:.2e} (losses {loss_drag_dev} vs {loss_drag_ref}), logit RMS err / RMS {r_vol:.2e}")
+    for a, b in zip(loss_rec_dev, losses):
+        assert abs(a - float(b)) <= 2e-2 * abs(float(b))
+    for a, b in zip(loss_drag_dev, loss_drag_ref):
+        assert abs(a - float(b)) <= 2e-2 * abs(float(b)) + 1e-7
+    assert r_rec <= 1e-2 and r_w <= 1e-5 and r_vn <= 2e-2 and r_fin <= 5e-3 and r_vol <= 2e-2
+    # the guidance terms must be resolved by these tolerances
+    assert rel(rec_dev.cpu(), img0) > 5 * r_rec and rel(final_dev, w_dev.cpu()) > 1e-2
+
+
+def test_shortened_c2_generate_against_the_oracle():
+    """BASELINE configs[1] (generate.py: DDPM sample -> un-normalise -> dense decode), shortened: the full 421M model,
+    batch 2, T = 6 p_sample steps (exp(0.5 logvar) form, gaussian_diffusion.py:400-444) with injected noise, then the
+    64^3 decode of both samples -- noise2shape + decode_to_obj on the device vs the fp32 oracle.
+    Tolerances: un-normalised triplanes 5e-3 relative L2 per sample; logit RMS error <= 1 % of RMS; sign flips <= 0.5 %."""
+    import os
+    from oracle import ref_cpu as O
+    from ishapediting_amd import generate, image_sample
+    from ishapediting_amd.triplane_decoder import MultiTriplane
+    from ishapediting_amd.unet_spec import build_spec, full_config
+    dev = torch.device("cuda", 0)
+    T, B, res = 6, 2, 64
+    cfg = full_config()
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 1234))
+    dec_sd = synthetic.decoder_state_dict(4321)
+    lo, hi = -0.05 * np.ones(96, np.float32), 0.05 * np.ones(96, np.float32)
+    gen = torch.Generator().manual_seed(55)
+    init = torch.randn(B, 96, 128, 128, generator=gen)
+    steps = [torch.randn(B, 96, 128, 128, generator=gen) for _ in range(T)]
+    args = generate.ddpm_namespace(generate.build_parser().parse_args(
+        ["--num_samples", str(B), "--batch_size", str(B), "--num_steps", str(T), "--shape_resolution", str(res)]))
+    arr = image_sample.noise2shape(args, state_dict=sd, bounds=(lo, hi), noise=init.to(dev),
+                                   step_noise=lambda i: steps[T - 1 - i].to(dev))
+    assert arr.shape == (B, 128, 128, 96)
+    tri = np.transpose(arr, [0, 3, 1, 2])
+    dec = MultiTriplane(1, device=dev)
+    dec.net.load_state_dict(dec_sd)
+    vols = [generate.decode_to_obj(tri[b], dec, res, os.devnull).cpu() for b in range(B)]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    net = O.UNetOracle(build_spec(cfg), sd, fp16=False)
+    diff = O.DiffusionOracle(O.Tables(str(T)))
+    img = init
+    with torch.no_grad():
+        for k, i in enumerate(range(T - 1, -1, -1)):
+            img = diff.p_sample(net, img, i, steps[k])["sample"]
+        rng = torch.from_numpy((hi - lo) / 2).reshape(1, 96, 1, 1)
+        mid = torch.from_numpy((hi + lo) / 2).reshape(1, 96, 1, 1)
+        un = img * rng + mid
+        for b in range(B):
+            r = rel(torch.from_numpy(tri[b]), un[b])
+            vol_ref = O.decode_volume(dec_sd, un[b:b + 1], 1.0, 0.0, res)
+            r_vol = float((vols[b] - vol_ref).pow(2).mean().sqrt()) / float(vol_ref.pow(2).mean().sqrt())
+            flips = int(((vols[b] > 0) != (vol_ref > 0)).sum())
+            print(f"short C2 sample {b}: triplane rel {r:.2e}, logit RMS err / RMS {r_vol:.2e}, sign flips {flips} / {vol_ref.numel()}")
+            assert r <= 5e-3 and r_vol <= 1e-2 and flips <= 0.005 * vol_ref.numel()

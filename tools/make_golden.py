@@ -48,6 +48,7 @@ class _Comm:
 _mpi.COMM_WORLD = _Comm()
 sys.modules["mpi4py"].MPI = _mpi
 sys.modules["mpi4py.MPI"] = _mpi
+_WHICH = sys.argv[1:] or None      # fixture names given on the command line (the reference's argparse must not see them)
 sys.argv = ["x"]
 
 import torch  # noqa: E402
@@ -403,6 +404,123 @@ def g11_reconstruct():
     save("g11_reconstruct", **out)
 
 
+
+def _seed_module(mod, seed):
+    """Seeded non-zero values for every parameter of a reference module (zero_module tensors included)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in mod.state_dict().items():
+        if v.dim() == 1 and ("in_layers.0" in k or "out_layers.0" in k or "norm" in k):
+            t = (1.0 if k.endswith("weight") else 0.0) + 0.1 * torch.randn(v.shape, generator=g)
+        elif k.endswith("bias"):
+            t = 0.05 * torch.randn(v.shape, generator=g)
+        else:
+            t = torch.randn(v.shape, generator=g) / float(np.sqrt(np.prod(v.shape[1:])))
+        sd[k] = t
+    mod.load_state_dict(sd)
+    mod.eval()
+    return sd
+
+
+def g3b_block_primitives():
+    """the reference's own ResBlock (plain / channel change / up / down, FiLM) and AttentionBlock
+    (legacy qkv order) classes, standalone, with seeded weights; GroupNorm32 + SiLU alone.  Inputs carry a per-group
+    mean offset so a one-pass variance would show."""
+    from neural_field_diffusion.guided_diffusion.nn import normalization
+    g = torch.Generator().manual_seed(23)
+    out = {}
+    emb = torch.randn(2, 64, generator=g)
+    out["emb"] = emb
+    cases = {"plain": dict(channels=32, out_channels=32), "chan": dict(channels=64, out_channels=32),
+             "up": dict(channels=32, out_channels=32, up=True), "down": dict(channels=32, out_channels=32, down=True)}
+    for name, kw in cases.items():
+        blk = ref_unet.ResBlock(kw["channels"], 64, 0.1, out_channels=kw["out_channels"], use_scale_shift_norm=True,
+                                dims=2, use_checkpoint=False, up=kw.get("up", False), down=kw.get("down", False))
+        sd = _seed_module(blk, 300 + len(out))
+        x = torch.randn(2, kw["channels"], 8, 8, generator=g) + 3.0 * torch.randn(2, kw["channels"], 1, 1, generator=g)
+        with torch.no_grad():
+            y = blk(x, emb)
+        out[f"res_{name}_x"] = x
+        out[f"res_{name}_y"] = y
+        for k, v in sd.items():
+            out[f"res_{name}_sd.{k}"] = v
+    att = ref_unet.AttentionBlock(64, num_heads=4, num_head_channels=32, use_checkpoint=False, use_new_attention_order=False)
+    sd = _seed_module(att, 401)
+    x = torch.randn(2, 64, 4, 4, generator=g)
+    with torch.no_grad():
+        y = att._forward(x)
+    out["attn_x"], out["attn_y"] = x, y
+    for k, v in sd.items():
+        out[f"attn_sd.{k}"] = v
+    gn = normalization(64)
+    sd = _seed_module(gn, 402)
+    x = (torch.randn(2, 64, 8, 8, generator=g) * 0.1 + 100.0 * torch.randn(2, 64, 1, 1, generator=g).sign()).half()
+    with torch.no_grad():
+        y = torch.nn.functional.silu(gn(x.float()))
+    out["gn_x"], out["gn_y"], out["gn_w"], out["gn_b"] = x.float(), y, sd["weight"], sd["bias"]
+    save("g3b_block_primitives", **out)
+
+
+def g4b_block_outputs():
+    """Every block's output (input_blocks[i], middle_block, output_blocks[i]) of the tiny UNet runs of G4 (fp32 reference),
+    so a device mismatch is localised to one block."""
+    out = {}
+    for nrb in (1, 2):
+        cfg = tiny_config(nrb)
+        model, _ = load_ref_unet(cfg, 100 + nrb, "10")
+        g = torch.Generator().manual_seed(31 + nrb)
+        x = torch.randn(1, 6, 16, 16, generator=g)
+        ts = torch.tensor([437])
+        rec = {}
+        hooks = []
+        for i, b in enumerate(model.input_blocks):
+            hooks.append(b.register_forward_hook(lambda m, a, o, i=i: rec.__setitem__(f"in{i}", o.detach().clone())))
+        hooks.append(model.middle_block.register_forward_hook(lambda m, a, o: rec.__setitem__("mid", o.detach().clone())))
+        for i, b in enumerate(model.output_blocks):
+            hooks.append(b.register_forward_hook(lambda m, a, o, i=i: rec.__setitem__(f"out{i}", o.detach().clone())))
+        with torch.no_grad():
+            model(x, ts)
+        for h in hooks:
+            h.remove()
+        for k, v in rec.items():
+            out[f"nrb{nrb}_{k}"] = v.half()        # fp16 storage: the device tensors are fp16 and the tolerance is 1e-2
+    save("g4b_block_outputs", **out)
+
+
+def g12_generate():
+    """The generate path (image_sample.py:173-192): the reference's p_sample_loop with its own RNG draws (noise=None:
+    th.randn(*shape) then randn_like per step, gaussian_diffusion.py:629,437), its unnormalize (normalization.py:6-15)
+    and the NHWC permute, for batch 1 and 3 on small96_config."""
+    import tempfile
+    from neural_field_diffusion.guided_diffusion.normalization import unnormalize
+    cfg = small96_config()
+    T = 5
+    model, diff = load_ref_unet(cfg, 303, str(T))
+    g = torch.Generator().manual_seed(81)
+    lower = -(torch.rand(96, generator=g) + 0.5).numpy().astype(np.float32)
+    upper = (torch.rand(96, generator=g) + 0.5).numpy().astype(np.float32)
+    out = {"T": T, "lower_bound": lower, "upper_bound": upper}
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "lower_bound.npy"), lower)
+        np.save(os.path.join(d, "upper_bound.npy"), upper)
+        for B in (1, 3):
+            shape = (B, 96, 16, 16)
+            torch.manual_seed(500 + B)
+            sample = diff.p_sample_loop(model, shape, clip_denoised=True, model_kwargs={})
+            torch.manual_seed(500 + B)
+            init = torch.randn(*shape)
+            steps = torch.stack([torch.randn(*shape) for _ in range(T)])     # consumed in loop order i = T-1 .. 0
+            arr = unnormalize(sample, stats_dir=d).permute(0, 2, 3, 1).contiguous()
+            # the noise itself is not stored (incompressible megabytes): tests redraw it from the same seed on the CPU
+            # generator and check these float64 checksums before using it
+            out[f"b{B}_seed"] = 500 + B
+            out[f"b{B}_noise_check"] = np.array([float(init.double().sum()), float(steps.double().pow(2).sum()),
+                                                  float(steps[-1, -1, -1, -1, -1])], dtype=np.float64)
+            out[f"b{B}_sample"] = sample
+            out[f"b{B}_arr"] = arr
+    save("g12_generate", **out)
+
+
 def g10_full_keys():
     """Key table + parameter count of the full-size model (structure only, no tensors stored)."""
     cfg = full_config()
@@ -419,8 +537,9 @@ def g10_full_keys():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] if len(sys.argv) > 1 else None
-    todo = [g1_schedules, g2_steps, g3_primitives, g4_tiny_unet, g6_decoder, g7_drag, g8_g9_tiny_loops, g10_full_keys, g11_reconstruct]
+    which = _WHICH
+    todo = [g1_schedules, g2_steps, g3_primitives, g3b_block_primitives, g4_tiny_unet, g4b_block_outputs, g6_decoder, g7_drag,
+            g8_g9_tiny_loops, g10_full_keys, g11_reconstruct, g12_generate]
     if which:
         todo = [f for f in todo if f.__name__ in which]
     with torch.no_grad():
