@@ -184,9 +184,14 @@ def test_reconstruction_loop_vs_reference_run(gold):
         r = rel(img, g["imgs"][k])
         step_effect = rel(T(g["imgs"][k]), prev if k else g["img0"])
         print(f"step {k} (t={i}): loss {loss:.6f} vs {float(g['losses'][k]):.6f}; latent rel err {r:.3e}")
+        assert abs(loss - float(g["losses"][k])) <= 1e-3 * abs(float(g["losses"][k]))
         if k >= 1:
-            assert abs(loss - float(g["losses"][k])) <= 1e-3 * abs(float(g["losses"][k]))
             assert r < 2e-2, (k, r)
+        else:
+            # step 0 runs at t = 999: pred_xstart = clamp(157.1*x - 157.1*eps), so the fp16 torso's ~1e-3 relative error of
+            # eps is amplified 157x before the clip (only the elements that stay inside [-1, 1] carry it on); measured 0.11
+            assert r < 0.25, (k, r)
+            assert r < 0.5 * step_effect, "step 0: the update itself must stay resolved"
         prev = T(g["imgs"][k])
     # the guidance term itself (scale 600 vs 0) must be resolved by that tolerance
     i = 1

