@@ -53,42 +53,121 @@ def one_edit(ds, src, tgt):
     return ds.volume
 
 
-def cpu_baseline(seed):
-    """The oracle (torch-CPU restatement of the reference path, fp32) on this host's cores, bounded sample:
-    one guided step (forward + drag loss + autograd backward to the latent) and one 64^3 decode, extrapolated
-    linearly to 40 guided steps + a 256^3 decode (x64 points)."""
+def _cpu_info():
+    model, logical = "unknown", os.cpu_count() or 1
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = logical
+    # a container's CPU share (cgroup quota) is what the threads really get: more threads than that only thrash
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            usable = min(usable, max(1, int(float(q[0]) / float(q[1]))))
+    except (OSError, ValueError, IndexError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                usable = min(usable, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    cap = int(os.environ.get("ISHAP_BENCH_CPU_THREADS", "0"))
+    if cap > 0:
+        usable = min(usable, cap)
+    return model, logical, usable
+
+
+def cpu_baseline(seed, reps=3):
+    """The oracle (torch-CPU restatement of the reference path, fp32) on every core this process may use, bounded
+    sample: `reps` guided steps (forward + drag loss + autograd backward to the latent), `reps` unguided
+    steps and `reps` 64^3 decodes, each kind averaged, then extrapolated linearly to C3 = 40 guided steps + a 256^3
+    decode (x64 points)."""
     from oracle import ref_cpu as O
     from ishapediting_amd import synthetic
     from ishapediting_amd.unet_spec import build_spec, full_config
-    cores = min(16, os.cpu_count() or 1)
+    model, logical, cores = _cpu_info()
     torch.set_num_threads(cores)
+    print(f"[bench] cpu baseline: {cores} threads on {model} ({logical} logical CPUs)", file=sys.stderr, flush=True)
     cfg = full_config()
     sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, seed))
     net = O.UNetOracle(build_spec(cfg), sd, fp16=False)
     diff = O.DiffusionOracle(O.Tables(str(NUM_STEPS)))
     img = torch.from_numpy(synthetic.latent(0))
     src, tgt = synthetic.handles(HANDLES)
-    t0 = time.time()
-    with torch.no_grad():
+    with torch.no_grad():                                          # untimed warm-up (thread pool, allocator) + the guidance feature
         o = diff.p_sample_guidance(net, img, GUIDED_STEPS - 1, noise=torch.zeros_like(img), feat_layer=8)
-    t_fwd = time.time() - t0
     orig = O.resize_feat_align(o["inter_feat"])
     setup = O.DragSetup(src, tgt, 12, 2.0 / RES, orig.shape[-1])
-    t0 = time.time()
-    x = img.clone().requires_grad_(True)
-    o = diff.p_sample_guidance(net, x, GUIDED_STEPS - 1, noise=torch.zeros_like(img), feat_layer=8)
-    loss = O.drag_loss(O.resize_feat_align(o["inter_feat"]), orig + 0.01, setup, 0.4)
-    torch.autograd.grad(loss, x)
-    t_guided = time.time() - t0
+    print("[bench] cpu baseline: warm-up forward done", file=sys.stderr, flush=True)
+    t_fwd, t_guided, t_dec = [], [], []
+    for r in range(reps):
+        t0 = time.time()
+        with torch.no_grad():
+            diff.p_sample_guidance(net, img, GUIDED_STEPS - 1 - r, noise=torch.zeros_like(img), feat_layer=8)
+        t_fwd.append(time.time() - t0)
+    for r in range(reps):
+        t0 = time.time()
+        x = img.clone().requires_grad_(True)
+        o = diff.p_sample_guidance(net, x, GUIDED_STEPS - 1 - r, noise=torch.zeros_like(img), feat_layer=8)
+        loss = O.drag_loss(O.resize_feat_align(o["inter_feat"]), orig + 0.01, setup, 0.4)
+        torch.autograd.grad(loss, x)
+        t_guided.append(time.time() - t0)
+        print(f"[bench] cpu baseline: guided step {r}: {t_guided[-1]:.2f}s", file=sys.stderr, flush=True)
     dec = synthetic.decoder_state_dict(4321)
-    t0 = time.time()
-    with torch.no_grad():
-        O.decode_volume(dec, img, 1.0, 0.0, 64)
-    t_dec64 = time.time() - t0
-    est = GUIDED_STEPS * t_guided + 64 * t_dec64
+    for r in range(reps):
+        t0 = time.time()
+        with torch.no_grad():
+            O.decode_volume(dec, img, 1.0, 0.0, 64)
+        t_dec.append(time.time() - t0)
+    mg, mf, md = (sum(v) / len(v) for v in (t_guided, t_fwd, t_dec))
+    est = GUIDED_STEPS * mg + 64 * md
     return {"value": round(est, 2), "unit": "s/shape", "cores": cores, "kind": "port",
-            "sample": f"1 guided step ({t_guided:.2f}s; fwd-only {t_fwd:.2f}s) + 64^3 decode ({t_dec64:.2f}s) on {cores} "
-                      f"threads, fp32 torch-CPU oracle; extrapolated x{GUIDED_STEPS} steps + x64 decode points"}
+            "cpu_model": model, "logical_cpus": logical,
+            "sample": f"{reps} guided steps (mean {mg:.2f}s), {reps} unguided steps (mean {mf:.2f}s), {reps} 64^3 decodes "
+                      f"(mean {md:.2f}s) on {cores} threads of {model} ({logical} logical CPUs), fp32 torch-CPU oracle; "
+                      f"extrapolated to {GUIDED_STEPS} guided steps + 64x the decode points (256^3)",
+            "unguided_step_s": round(mf, 3), "guided_step_s": round(mg, 3), "decode64_s": round(md, 3)}
+
+
+def spawn_workers(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (each its own
+    interpreter; this parent never touches the GPU), relay rank 0's JSON line, exit with the worst status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    have = torch.cuda.device_count()                           # counting devices does not initialise the GPU in this parent
+    if a.gpus > have:
+        sys.exit(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) are visible")
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:                                                # a rank that dies must not leave the others waiting in a collective
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = max(rc, abs(code))
+                for q in live:
+                    q.terminate()
+    sys.exit(rc)
 
 
 def main():
@@ -102,6 +181,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and "RANK" not in os.environ:
+        spawn_workers(a)                                       # does not return
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     import torch.distributed as dist
     torch.cuda.set_device(local)
@@ -125,13 +206,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    gather_buf = [torch.empty((RES, RES, RES), dtype=torch.float32, device=device) for _ in range(world)] \
+    from ishapediting_amd.parallel import gather_volumes
+    recv = [torch.empty((RES, RES, RES), dtype=torch.float32, device=device) for _ in range(world)] \
         if (world > 1 and rank == 0) else None
 
     def step():
         vol = one_edit(ds, src, tgt)
-        if world > 1:
-            dist.gather(vol, gather_buf, dst=0)
+        if world > 1:     # the path's only collective: every rank's occupancy volume to rank 0 (RCCL gather, 67 MB per rank)
+            gather_volumes([vol], world, dst=0, full_shape=(RES, RES, RES), recv=recv)
         return vol
 
     for _ in range(a.warmup):
@@ -159,11 +241,29 @@ def main():
         NV = 7
         out = (C.c_double * (NV * 3))()
         L.ishap_profile_end(out, NV)
+        buf = C.create_string_buffer(1 << 17)
+        L.ishap_profile_shapes(buf, len(buf))
+        shape_csv = buf.value.decode()
         if a.shape_profile:
-            buf = C.create_string_buffer(1 << 16)
-            L.ishap_profile_shapes(buf, len(buf))
             with open(a.shape_profile, "w") as f:
-                f.write("M,N,K,conv3,tile,ksplit,launches,main_ms,reduce_ms,gflop\n" + buf.value.decode())
+                f.write("M,N,K,conv3,tile,ksplit,launches,main_ms,reduce_ms,gflop\n" + shape_csv)
+        # second record: the HBM-bound class -- every conv / GEMM on the 8x8 and 16x16 maps (M <= 256 rows at
+        # batch 1) streams its weights once; algorithmic bytes = fp16 weights + input map + output map per launch
+        sm_bytes = sm_ms = sm_launch = 0.0
+        for row in shape_csv.strip().splitlines():
+            M_, N_, K_, c3, _tile, _ks, n_, main_ms, red_ms, _gf = (float(v) for v in row.split(","))
+            if M_ <= 256:
+                cin = K_ / 9 if c3 else K_
+                sm_bytes += n_ * (N_ * K_ * 2 + M_ * cin * 2 + M_ * N_ * 2)
+                sm_ms += main_ms + red_ms
+                sm_launch += n_
+        small_maps = None
+        if sm_ms > 0:
+            gbs = sm_bytes / (sm_ms * 1e-3) / 1e9
+            small_maps = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                          "traffic": None, "kernel": "all conv/GEMM launches on the 8x8 and 16x16 maps (M <= 256)",
+                          "launches_per_edit": int(sm_launch), "ms_per_edit": round(sm_ms, 2),
+                          "algorithmic_bytes_per_edit": int(sm_bytes)}
         # one entry per kernel symbol (the name rocprofv3 reports)
         names = ["void igemm2_kernel<128, 128, 4, true, 1>", "void igemm2_kernel<64, 64, 4, true, 1>",
                  "void igemm2_kernel<128, 128, 4, false, 1>", "void igemm2_kernel<64, 64, 4, false, 1>",
@@ -227,7 +327,7 @@ def main():
             "surface_vertices": int(sv.shape[0]), "surface_triangles": int(st.shape[0]),
             "surface_extract_ms": round(surface_ms, 2),
             "surface_extract_ms_sphere256": round(surface_ms_sphere, 2), "sphere256_vertices": int(sv2.shape[0]),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_small_maps": small_maps, "cpu_baseline": cpu,
         }
         if cpu:
             line["speedup_vs_cpu_baseline"] = round(cpu["value"] / sec_per_shape, 1)

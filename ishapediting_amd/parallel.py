@@ -14,25 +14,34 @@ def shard_edits(n_edits: int, world: int, rank: int) -> List[int]:
     return list(range(rank, n_edits, world))
 
 
-def gather_volumes(volumes: Sequence[torch.Tensor], n_edits: int, dst: int = 0) -> Optional[List[torch.Tensor]]:
+def gather_volumes(volumes: Sequence[torch.Tensor], n_edits: int, dst: int = 0, full_shape=None,
+                   recv: Optional[List[torch.Tensor]] = None) -> Optional[List[torch.Tensor]]:
     """Gather every rank's decoded volumes on `dst`, returned in edit order.  Ranks may own different counts
-    (n_edits need not divide the world size): missing slots are padded with an empty-marker volume."""
+    (n_edits need not divide the world size): missing slots are padded with an empty-marker volume.
+    `full_shape` (every rank passes the same value) skips the shape agreement round; `recv` = `world` receive buffers
+    on `dst` to reuse across calls (they are returned, so only when each rank owns one edit)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world == 1:
         return list(volumes)
     per = (n_edits + world - 1) // world
     like = volumes[0] if volumes else None
-    shape = torch.tensor(list(like.shape) if like is not None else [0, 0, 0], device=like.device if like is not None else "cpu")
-    # every rank owns at least one edit when n_edits >= world; otherwise agree on the shape first
-    shapes = [torch.zeros_like(shape) for _ in range(world)]
-    dist.all_gather(shapes, shape)
-    full = max((tuple(int(v) for v in s.tolist()) for s in shapes), key=lambda t: t[0] * t[1] * t[2])
-    dev = like.device if like is not None else shapes[0].device
+    if full_shape is not None:
+        full = tuple(int(v) for v in full_shape)
+        dev = like.device
+    else:
+        shape = torch.tensor(list(like.shape) if like is not None else [0, 0, 0], device=like.device if like is not None else "cpu")
+        # every rank owns at least one edit when n_edits >= world; otherwise agree on the shape first
+        shapes = [torch.zeros_like(shape) for _ in range(world)]
+        dist.all_gather(shapes, shape)
+        full = max((tuple(int(v) for v in s.tolist()) for s in shapes), key=lambda t: t[0] * t[1] * t[2])
+        dev = like.device if like is not None else shapes[0].device
     out_all: List[torch.Tensor] = [None] * n_edits   # type: ignore
     for k in range(per):
         mine = volumes[k] if k < len(volumes) else torch.zeros(full, dtype=torch.float32, device=dev)
-        bufs = [torch.empty(full, dtype=torch.float32, device=dev) for _ in range(world)] if rank == dst else None
+        bufs = None
+        if rank == dst:
+            bufs = recv if (recv is not None and per == 1) else [torch.empty(full, dtype=torch.float32, device=dev) for _ in range(world)]
         dist.gather(mine.contiguous(), bufs, dst=dst)
         if rank == dst:
             for r in range(world):
