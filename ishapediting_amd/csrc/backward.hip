@@ -23,18 +23,31 @@ static int gn_bwd_op(Exec& e, GnBwdArgs g) {
 // dY [N,H,W,cout] -> dX [N,H,W,rows of wT] through the transposed / flipped operand
 // `gb`: the GroupNorm whose activation this gradient arrives at, at the same resolution (GB_SAME) -- its per-channel
 // backward sums are then accumulated in this launch's epilogue (gb->csums allocated here, gb->sums_ready set).
-static int dgrad_op(Exec& e, const ConvW& c, const Tensor& dy, Tensor& dx_out, int n_out, GnBwdArgs* gb = nullptr) {
+// `may_pend`: the only reader of dx_out is a group-local GroupNorm-backward pass, which adds up split-K slices itself.
+static int dgrad_op(Exec& e, const ConvW& c, const Tensor& dy, Tensor& dx_out, int n_out, GnBwdArgs* gb = nullptr,
+                    bool may_pend = false) {
   dx_out = Tensor{nullptr, dy.N, dy.H, dy.W, n_out};
   ISHAP_ALLOC(dx_out.p, e, dx_out.numel());
   if (gb) {
     ISHAP_SALLOC(gb->csums, e, (size_t)gb->N * gb->C * 2);
     gb->sums_ready = 1;
-    ISHAP_REQUIRE(e.dry || gb->csums != nullptr, "stats arena exhausted");
     ISHAP_REQUIRE(gb->C == n_out && gb->gmode == GB_SAME, "fused GroupNorm-backward sums need the gradient at the GN resolution");
   }
   return conv_op(e, dy.p, dy.N, dy.H, dy.W, dy.C, c.wT, c.cout_pad, c.taps, n_out, nullptr, nullptr, 0, dx_out.p, n_out,
-                 IG_OUT_F16, 0, 0, nullptr, gb);
+                 IG_OUT_F16, 0, 0, nullptr, gb, nullptr, 0, 0, nullptr, 0, may_pend ? &dx_out.pend : nullptr);
 }
+
+// group-local input gradient of act(film(GN(x))) on a small map; `up` may still be pending (norm_local.hip)
+static int gn_bwd_local_op(Exec& e, const GnBwdArgs& g, Tensor& up) {
+  GnBwdLocalArgs a;
+  a.g = up.p; a.slab = up.pend; a.x = g.x; a.add = g.add; a.add2 = g.add2; a.dx = g.dx; a.dx2 = g.dx2; a.csplit = g.csplit;
+  a.stats = g.stats; a.gamma = g.gamma; a.beta = g.beta; a.emb = g.emb; a.emb_ld = g.emb_ld;
+  a.N = g.N; a.H = g.H; a.W = g.W; a.C = g.C; a.film = g.film; a.act = g.act; a.gmode = g.gmode;
+  up.pend = SlabSrc{};
+  if (e.dry) return 0;
+  return gn_bwd_local_launch(a, e.s);
+}
+static bool local_gn_bwd(int HW, int C, int gmode) { return small_map(HW) && gn_bwd_local_fits(HW, C, gmode); }
 
 // `split` > 0: the block input was a skip concatenation [h | skip]; its gradient is written as two dense tensors
 // (dx = first `split` channels, *dx2 = the rest) so no slicing pass is needed afterwards.
@@ -54,18 +67,21 @@ static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int spli
     g.x = h1.p; g.stats = sv.stats2; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
     g.emb = u->d_film + L.emb_off; g.emb_ld = u->film_rows;
     g.N = h1.N; g.H = h1.H; g.W = h1.W; g.C = L.cout; g.film = 1; g.act = 1; g.gmode = GB_SAME;
-    ISHAP_TRY(dgrad_op(e, L.c2, dy, dc, L.cout, &g));
+    const bool loc = local_gn_bwd(h1.H * h1.W, L.cout, GB_SAME);
+    ISHAP_TRY(dgrad_op(e, L.c2, dy, dc, L.cout, loc ? nullptr : &g, loc));
     ISHAP_ALLOC(dh1.p, e, h1.numel());
     g.g = dc.p; g.dx = dh1.p;
-    ISHAP_TRY(gn_bwd_op(e, g));
+    if (loc) ISHAP_TRY(gn_bwd_local_op(e, g, dc));
+    else ISHAP_TRY(gn_bwd_op(e, g));
   }
   // in_layers: conv1 <- (up/down sample) <- SiLU <- GN1
   GnBwdArgs g1;
   g1.x = x.p; g1.stats = sv.stats1; g1.gamma = L.n1.gamma; g1.beta = L.n1.beta;
   g1.N = x.N; g1.H = x.H; g1.W = x.W; g1.C = L.cin; g1.film = 0; g1.act = 1;
   g1.gmode = L.down ? GB_UNPOOL : (L.up ? GB_SUM4 : GB_SAME);
+  const bool loc1 = local_gn_bwd(x.H * x.W, L.cin, g1.gmode);
   Tensor da;
-  ISHAP_TRY(dgrad_op(e, L.c1, dh1, da, L.cin, g1.gmode == GB_SAME ? &g1 : nullptr));
+  ISHAP_TRY(dgrad_op(e, L.c1, dh1, da, L.cin, (!loc1 && g1.gmode == GB_SAME) ? &g1 : nullptr, loc1));
   const half_t* add = dy.p;     // identity skip: gradient of `x_upd(x)` (unet.py:241,256)
   if (L.has_skip) {
     Tensor dxs;
@@ -86,7 +102,8 @@ static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int spli
   }
   dx.sums = nullptr;
   g1.g = da.p; g1.add = add; g1.dx = dx.p; g1.add2 = add2;
-  ISHAP_TRY(gn_bwd_op(e, g1));
+  if (loc1) ISHAP_TRY(gn_bwd_local_op(e, g1, da));
+  else ISHAP_TRY(gn_bwd_op(e, g1));
   return 0;
 }
 
@@ -115,10 +132,12 @@ static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx) {
     GnBwdArgs g;
     g.x = x.p; g.stats = sv.stats; g.gamma = L.n.gamma; g.beta = L.n.beta;
     g.N = N; g.H = x.H; g.W = x.W; g.C = C; g.film = 0; g.act = 0; g.gmode = GB_SAME;
-    ISHAP_TRY(dgrad_op(e, L.qkv, dqkv, dn, C, &g));
+    const bool loc = local_gn_bwd(T, C, GB_SAME);
+    ISHAP_TRY(dgrad_op(e, L.qkv, dqkv, dn, C, loc ? nullptr : &g, loc));
     ISHAP_ALLOC(dx.p, e, x.numel());
     g.g = dn.p; g.add = dy.p; g.dx = dx.p;
-    ISHAP_TRY(gn_bwd_op(e, g));
+    if (loc) ISHAP_TRY(gn_bwd_local_op(e, g, dn));
+    else ISHAP_TRY(gn_bwd_op(e, g));
   }
   return 0;
 }
@@ -170,13 +189,15 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
     GnBwdArgs a;
     a.x = u->h_final.p; a.stats = u->head_stats; a.gamma = u->head_norm.gamma;
     a.beta = u->head_norm.beta; a.N = N; a.H = S; a.W = S; a.C = u->final_ch; a.act = 1;
-    ISHAP_TRY(dgrad_op(e, u->head, dout, dact, u->final_ch, &a));
+    const bool loc = local_gn_bwd(S * S, u->final_ch, GB_SAME);
+    ISHAP_TRY(dgrad_op(e, u->head, dout, dact, u->final_ch, loc ? nullptr : &a, loc));
     g = u->h_final;
     if (dry) g = Tensor{nullptr, N, S, S, u->final_ch};
     Tensor gh = g;
     ISHAP_ALLOC(gh.p, e, g.numel());
     a.g = dact.p; a.dx = gh.p;
-    ISHAP_TRY(gn_bwd_op(e, a));
+    if (loc) ISHAP_TRY(gn_bwd_local_op(e, a, dact));
+    else ISHAP_TRY(gn_bwd_op(e, a));
     g = gh;
   } else {
     F = dry ? n_out - 1 : u->last_feat;

@@ -66,6 +66,21 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// A convolution result that has not been materialised yet: the split-K slices of an implicit-GEMM launch left as fp32
+// partial sums [nslab][rows][ld].  The next kernel on the tensor (a GroupNorm pass, forward or backward -- it has to read
+// the whole tensor anyway) adds the slices in slice order, applies bias / residual, rounds to fp16 and goes on from
+// there, so the separate reduce launch and the fp32 round trip it ends with disappear.
+struct SlabSrc {
+  const float* ws = nullptr;
+  int nslab = 0;                 // 0: not pending
+  long long zstride = 0;         // floats between slices (= rows * ld)
+  const float* bias = nullptr;
+  const float* bias2 = nullptr;
+  const half_t* res = nullptr;   // residual [rows][ldr], optionally at half resolution (res_ups)
+  int ldr = 0, res_ups = 0;
+  __host__ __device__ bool pending() const { return nslab > 0; }
+};
+
 struct IgemmArgs {
   const half_t* X = nullptr;   // activations
   const half_t* Wt = nullptr;  // [Npad][K] (K contiguous), rows >= N are zero
@@ -89,6 +104,7 @@ struct IgemmArgs {
   int ups = 0;                   // conv3 source map is (H/2, W/2): nearest-neighbour upsample on the fly
   int res_ups = 0;               // residual map is (H/2, W/2)
   int ksplit = 1;
+  int defer_reduce = 0;          // ksplit > 1: leave the fp32 slices in `ws` (no reduce launch); the caller hands a SlabSrc to the consumer
   float alpha = 1.f;
   int out_mode = IG_OUT_F16;
   long long* stat_out = nullptr; // optional [N_img][N][2]: += per-channel (sum, sum of squares) of the fp16 outputs, as 64-bit
@@ -110,5 +126,6 @@ struct IgemmArgs {
 // these events to the dispatch itself (hipExtLaunchKernelGGL), so their elapsed time is the kernel's own duration
 extern hipEvent_t g_igemm_prof_start, g_igemm_prof_stop;
 int igemm_launch(const IgemmArgs& a, hipStream_t s);
+int igemm_reduce_launch(const IgemmArgs& a, hipStream_t s);
 // picks a split so the grid fills the chip; returns workspace floats needed
 int igemm_pick_ksplit(int M, int N, int K, int nbatch);

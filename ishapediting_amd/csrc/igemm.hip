@@ -358,7 +358,7 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
     ISHAP_TRY(fire());
   }
   ISHAP_CHECK_HIP(hipGetLastError());
-  if (a.ksplit > 1) {
+  if (a.ksplit > 1 && !a.defer_reduce) {
     const unsigned rblocks = (unsigned)((long long)a.nbatch * (a.M / 16) * ((a.N + 63) / 64));
     hipLaunchKernelGGL(igemm_splitk_reduce, dim3(rblocks), dim3(256), 0, s, a);
     ISHAP_CHECK_HIP(hipGetLastError());
@@ -391,6 +391,15 @@ int igemm_pick_ksplit(int M, int N, int K, int nbatch) {
   static const int minsteps = [] { const char* e = getenv("ISHAP_SPLIT_MINSTEPS"); return e ? atoi(e) : 6; }();
   while (blocks * split < fill && ks / (split * 2) >= minsteps && split < 32) split *= 2;
   return split;
+}
+
+// the stand-alone reduce of deferred split-K slices (a.ws, a.ksplit, bias / residual / output fields as in the main launch)
+int igemm_reduce_launch(const IgemmArgs& a, hipStream_t s) {
+  ISHAP_REQUIRE(a.ksplit > 1 && a.ws && a.M % 16 == 0 && a.N % 4 == 0, "reduce: split-K slices of a finished launch");
+  const unsigned rblocks = (unsigned)((long long)a.nbatch * (a.M / 16) * ((a.N + 63) / 64));
+  hipLaunchKernelGGL(igemm_splitk_reduce, dim3(rblocks), dim3(256), 0, s, a);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 bool igemm_skinny_applicable(const IgemmArgs& a);                      // igemm_skinny.hip (small maps, one launch)

@@ -59,3 +59,50 @@ struct GnBwdArgs {
   int sums_ready = 0;             // csums were already accumulated by the producing implicit-GEMM epilogue: apply pass only
 };
 int gn_backward_launch(const GnBwdArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Group-local GroupNorm kernels (norm_local.hip) for maps of at most 32 x 32 pixels: one workgroup owns one
+// (image, group) -- H*W pixels x C/32 channels, staged in LDS -- so statistics, normalisation, FiLM, SiLU, pooling and
+// (backward) the group means are ONE launch with no atomics, and the input may be a pending split-K result (SlabSrc).
+// ---------------------------------------------------------------------------------------------------------------
+struct GnLocalArgs {
+  // source A: channels [0, Ca) -- a dense fp16 tensor [N][H*W][Ca] or pending fp32 slices (then `ya` receives the fp16 tensor)
+  const half_t* xa = nullptr;
+  SlabSrc slab;
+  half_t* ya = nullptr;
+  int Ca = 0;
+  // source B: channels [Ca, C) of a skip concatenation (dense fp16 [N][H*W][C-Ca]) or null when Ca == C
+  const half_t* xb = nullptr;
+  half_t* xcopy = nullptr;       // the raw concatenation [N][H*W][C] (written when non-null)
+  half_t* out = nullptr;         // act(film(gn(x))) [N][HWo][C]
+  half_t* xpool = nullptr;       // pool: 2x2 mean of the raw input (may be null)
+  float* stats_out = nullptr;    // [N][32][2] (mean, rstd) for the backward pass
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  const float* emb = nullptr;
+  int emb_ld = 0;
+  int N = 1, H = 0, W = 0, C = 0;
+  int film = 0, act = 1, pool = 0;
+};
+bool gn_local_fits(int HW, int C);              // LDS budget of the forward / backward staging
+int gn_local_launch(const GnLocalArgs& a, hipStream_t s);
+
+struct GnBwdLocalArgs {
+  const half_t* g = nullptr;     // upstream gradient (dense fp16) or pending slices, at the resolution `gmode` says
+  SlabSrc slab;                  // bias / residual unused: an input gradient has neither
+  const half_t* x = nullptr;
+  const half_t* add = nullptr;   // same indexing mode as g
+  const half_t* add2 = nullptr;  // output resolution
+  half_t* dx = nullptr;
+  half_t* dx2 = nullptr;
+  int csplit = 0;
+  const float* stats = nullptr;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  const float* emb = nullptr;
+  int emb_ld = 0;
+  int N = 1, H = 0, W = 0, C = 0;
+  int film = 0, act = 1, gmode = GB_SAME;
+};
+bool gn_bwd_local_fits(int HW, int C, int gmode);
+int gn_bwd_local_launch(const GnBwdLocalArgs& a, hipStream_t s);

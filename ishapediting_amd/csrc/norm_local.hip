@@ -1,0 +1,431 @@
+// Group-local GroupNorm(32) passes for the small maps (H*W <= 1024: the 32x32, 16x16 and 8x8 levels of the UNet).
+// Reference arithmetic: guided_diffusion/nn.py:16-18,92-99 (GroupNorm32 on x.float()), unet.py:236-252 (ResBlock:
+// SiLU, FiLM `gn(h)*(1+scale)+shift`, AvgPool2d / nearest-x2 on both branches), and autograd's input gradient of the same
+// (drag_utils.py:383).
+//
+// One workgroup owns one (image, group): H*W pixels x C/32 channels.  That makes every reduction of the layer local --
+// the statistics (forward) and the two group means of the input gradient (backward) -- so a GroupNorm is ONE launch with
+// no atomics and no finalise prologue, and its input may be a convolution result that is still split over K: the kernel
+// adds the fp32 slices (slice order: bitwise reproducible), bias and residual, rounds to fp16 like a stored activation,
+// writes that tensor for its other consumers (skip connections, the backward pass) and carries on from the registers.
+// The group's values are staged once in LDS (<= 96 KB) between the statistics pass and the apply pass.
+// Rounding points are those of norm.hip / norm_bwd.hip, so both routes give the same values.
+#include "norm.h"
+#include "gn_bwd_terms.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+template <int VEC>
+__device__ __forceinline__ void ld_half(const half_t* p, float* o) {
+  if constexpr (VEC == 8) {
+    const half8 v = *reinterpret_cast<const half8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  } else if constexpr (VEC == 4) {
+    const half4 v = *reinterpret_cast<const half4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (float)v[i];
+  } else if constexpr (VEC == 2) {
+    const half2v v = *reinterpret_cast<const half2v*>(p);
+    o[0] = (float)v[0]; o[1] = (float)v[1];
+  } else {
+    o[0] = (float)p[0];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void st_half(half_t* p, const float* v) {
+  if constexpr (VEC == 8) {
+    half8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (half_t)v[i];
+    *reinterpret_cast<half8*>(p) = h;
+  } else if constexpr (VEC == 4) {
+    half4 h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = (half_t)v[i];
+    *reinterpret_cast<half4*>(p) = h;
+  } else if constexpr (VEC == 2) {
+    half2v h;
+    h[0] = (half_t)v[0]; h[1] = (half_t)v[1];
+    *reinterpret_cast<half2v*>(p) = h;
+  } else {
+    p[0] = (half_t)v[0];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void add_f32(const float* p, float* acc) {
+  if constexpr (VEC == 8) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i] += a[i]; acc[4 + i] += b[i]; }
+  } else if constexpr (VEC == 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += a[i];
+  } else if constexpr (VEC == 2) {
+    const f32x2 a = *reinterpret_cast<const f32x2*>(p);
+    acc[0] += a[0]; acc[1] += a[1];
+  } else {
+    acc[0] += p[0];
+  }
+}
+
+// sum of the pending slices at (row, c .. c+VEC-1), in slice order, four loads in flight
+template <int VEC>
+__device__ __forceinline__ void slab_sum(const SlabSrc& s, long long row, int ld, int c, float* v) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) v[i] = 0.f;
+  const float* p = s.ws + row * ld + c;
+  int z = 0;
+  for (; z + 4 <= s.nslab; z += 4) {
+    float t0[VEC], t1[VEC], t2[VEC], t3[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { t0[i] = 0.f; t1[i] = 0.f; t2[i] = 0.f; t3[i] = 0.f; }
+    add_f32<VEC>(p + (z + 0) * s.zstride, t0);
+    add_f32<VEC>(p + (z + 1) * s.zstride, t1);
+    add_f32<VEC>(p + (z + 2) * s.zstride, t2);
+    add_f32<VEC>(p + (z + 3) * s.zstride, t3);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { v[i] += t0[i]; v[i] += t1[i]; v[i] += t2[i]; v[i] += t3[i]; }
+  }
+  for (; z < s.nslab; ++z) add_f32<VEC>(p + z * s.zstride, v);
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+__device__ __forceinline__ float rh(float v) { return (float)(half_t)v; }
+
+// block-wide sums of two doubles (every thread gets them); `scratch` = 2 * 16 doubles of LDS
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { scratch[wave] = a; scratch[16 + wave] = b; }
+  __syncthreads();
+  a = 0.0; b = 0.0;
+  for (int w = 0; w < nw; ++w) { a += scratch[w]; b += scratch[16 + w]; }      // fixed order
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int VEC, bool FILM, bool ACT, bool POOL>
+__global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* scratch = reinterpret_cast<double*>(smem_raw);                 // 32 doubles
+  half_t* st = reinterpret_cast<half_t*>(smem_raw + 256);                // [HW][cpg]
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int C = a.C, cpg = C / 32, VPP = cpg / VEC, HW = a.H * a.W;
+  const int nunits = HW * VPP, c0g = g * cpg;
+  const int Cb = C - a.Ca;
+  const bool pend = a.slab.pending();
+  double s = 0.0, q = 0.0;
+  for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
+    const int p = u / VPP, cv = u - p * VPP, c = c0g + cv * VEC;
+    const long long row = (long long)n * HW + p;
+    float v[VEC];
+    if (c < a.Ca) {
+      if (pend) {
+        slab_sum<VEC>(a.slab, row, a.Ca, c, v);
+        if (a.slab.bias) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v[i] += a.slab.bias[c + i];
+        }
+        if (a.slab.bias2) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v[i] += a.slab.bias2[c + i];
+        }
+        if (a.slab.res) {
+          long long rrow = row;
+          if (a.slab.res_ups) {
+            const int py = p / a.W, px = p - py * a.W;
+            rrow = (long long)n * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1);
+          }
+          float r[VEC];
+          ld_half<VEC>(a.slab.res + rrow * a.slab.ldr + c, r);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v[i] += r[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = rh(v[i]);                  // the stored activation is fp16
+        if (a.ya) st_half<VEC>(a.ya + row * a.Ca + c, v);
+      } else {
+        ld_half<VEC>(a.xa + row * a.Ca + c, v);
+      }
+    } else {
+      ld_half<VEC>(a.xb + row * Cb + (c - a.Ca), v);
+    }
+    if (a.xcopy) st_half<VEC>(a.xcopy + row * C + c, v);
+    st_half<VEC>(st + p * cpg + cv * VEC, v);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { s += (double)v[i]; q += (double)v[i] * (double)v[i]; }
+  }
+  block_sum2(s, q, scratch);
+  const double cnt = (double)HW * (double)cpg;
+  const double md = s / cnt;
+  double vd = q / cnt - md * md;
+  vd = vd < 0.0 ? 0.0 : vd;
+  const float mean = (float)md, rstd = (float)(1.0 / sqrt(vd + 1e-5));
+  if (threadIdx.x == 0 && a.stats_out) {
+    a.stats_out[(n * 32 + g) * 2] = mean;
+    a.stats_out[(n * 32 + g) * 2 + 1] = rstd;
+  }
+  __syncthreads();                                                     // staging complete (block_sum2 synchronised after the loop as well)
+
+  auto activate = [&](const float* x, int c, float* o) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float y = rh((x[i] - mean) * rstd * a.gamma[c + i] + a.beta[c + i]);
+      if (FILM) {
+        const float sc = rh(1.f + rh(a.emb[(long long)n * a.emb_ld + c + i]));
+        const float sh = rh(a.emb[(long long)n * a.emb_ld + C + c + i]);
+        y = rh(rh(y * sc) + sh);
+      }
+      if (ACT) y = rh(silu_f(y));
+      o[i] = y;
+    }
+  };
+  if (!POOL) {
+    for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
+      const int p = u / VPP, cv = u - p * VPP, c = c0g + cv * VEC;
+      float x[VEC], o[VEC];
+      ld_half<VEC>(st + p * cpg + cv * VEC, x);
+      activate(x, c, o);
+      st_half<VEC>(a.out + ((long long)n * HW + p) * C + c, o);
+    }
+  } else {
+    const int Wo = a.W >> 1, HWo = HW >> 2;
+    for (int u = threadIdx.x; u < HWo * VPP; u += blockDim.x) {
+      const int po = u / VPP, cv = u - po * VPP, c = c0g + cv * VEC;
+      const int yo = po / Wo, xo = po - yo * Wo;
+      float acc[VEC], xacc[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { acc[i] = 0.f; xacc[i] = 0.f; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int p = (2 * yo + (k >> 1)) * a.W + 2 * xo + (k & 1);
+        float x[VEC], o[VEC];
+        ld_half<VEC>(st + p * cpg + cv * VEC, x);
+        activate(x, c, o);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { acc[i] += o[i]; xacc[i] += x[i]; }
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { acc[i] *= 0.25f; xacc[i] *= 0.25f; }
+      st_half<VEC>(a.out + ((long long)n * HWo + po) * C + c, acc);
+      if (a.xpool) st_half<VEC>(a.xpool + ((long long)n * HWo + po) * C + c, xacc);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// upstream gradient of pixel p (GN-input resolution), channels c..c+VEC-1, from a dense fp16 map or pending slices
+template <int VEC>
+__device__ __forceinline__ void upstream(const half_t* g, const SlabSrc& slab, int gmode, int n, int p, int H, int W, int C,
+                                         int c, float* o) {
+  auto at = [&](long long row, float* v) {
+    if (slab.pending()) {
+      slab_sum<VEC>(slab, row, C, c, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i] = rh(v[i]);                    // a stored gradient map is fp16
+    } else {
+      ld_half<VEC>(g + row * C + c, v);
+    }
+  };
+  const int y = p / W, x = p - y * W;
+  if (gmode == GB_SAME) {
+    at((long long)n * H * W + p, o);
+  } else if (gmode == GB_UNPOOL) {
+    at((long long)n * (H >> 1) * (W >> 1) + (y >> 1) * (W >> 1) + (x >> 1), o);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] *= 0.25f;
+  } else {
+    const int W2 = W << 1;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float t[VEC];
+      at((long long)n * (H << 1) * W2 + (2 * y + (k >> 1)) * W2 + 2 * x + (k & 1), t);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] += t[i];
+    }
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void addend(const half_t* g, int gmode, int n, int p, int H, int W, int C, int c, float* o) {
+  SlabSrc none;
+  upstream<VEC>(g, none, gmode, n, p, H, W, C, c, o);
+}
+
+// STAGE32: the staged upstream values are fp32 (GB_UNPOOL / GB_SUM4: a quarter or a sum of four fp16 values is not an fp16 value)
+template <int VEC, bool FILM, bool ACT, bool STAGE32>
+__global__ __launch_bounds__(1024) void gn_bwd_local_kernel(GnBwdLocalArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* scratch = reinterpret_cast<double*>(smem_raw);
+  half_t* st16 = reinterpret_cast<half_t*>(smem_raw + 256);
+  float* st32 = reinterpret_cast<float*>(smem_raw + 256);
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int C = a.C, cpg = C / 32, VPP = cpg / VEC, HW = a.H * a.W;
+  const int nunits = HW * VPP, c0g = g * cpg;
+  const float mu = a.stats[(n * 32 + g) * 2], rs = a.stats[(n * 32 + g) * 2 + 1];
+  double s1 = 0.0, s2 = 0.0;
+  for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
+    const int p = u / VPP, cv = u - p * VPP, c = c0g + cv * VEC;
+    float up[VEC], xv[VEC];
+    upstream<VEC>(a.g, a.slab, a.gmode, n, p, a.H, a.W, C, c, up);
+    ld_half<VEC>(a.x + ((long long)n * HW + p) * C + c, xv);
+    if (STAGE32) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) st32[p * cpg + cv * VEC + i] = up[i];
+    } else {
+      st_half<VEC>(st16 + p * cpg + cv * VEC, up);                    // exact: these values are fp16 (x 1/4)
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float dyh, xh;
+      gn_bwd_term(up[i], xv[i], mu, rs, a.gamma[c + i], (FILM || ACT) ? a.beta[c + i] : 0.f,
+                  FILM ? a.emb[(long long)n * a.emb_ld + c + i] : 0.f, FILM ? a.emb[(long long)n * a.emb_ld + C + c + i] : 0.f,
+                  FILM, ACT, dyh, xh);
+      s1 += (double)dyh;
+      s2 += (double)dyh * (double)xh;
+    }
+  }
+  block_sum2(s1, s2, scratch);
+  const double cnt = (double)HW * (double)cpg;
+  const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt);
+  __syncthreads();
+  for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
+    const int p = u / VPP, cv = u - p * VPP, c = c0g + cv * VEC;
+    const long long pix = (long long)n * HW + p;
+    float up[VEC], xv[VEC], ad[VEC], a2[VEC], o[VEC];
+    if (STAGE32) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) up[i] = st32[p * cpg + cv * VEC + i];
+    } else {
+      ld_half<VEC>(st16 + p * cpg + cv * VEC, up);
+    }
+    ld_half<VEC>(a.x + pix * C + c, xv);
+    if (a.add) addend<VEC>(a.add, a.gmode, n, p, a.H, a.W, C, c, ad);
+    if (a.add2) ld_half<VEC>(a.add2 + pix * C + c, a2);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float dyh, xh;
+      gn_bwd_term(up[i], xv[i], mu, rs, a.gamma[c + i], (FILM || ACT) ? a.beta[c + i] : 0.f,
+                  FILM ? a.emb[(long long)n * a.emb_ld + c + i] : 0.f, FILM ? a.emb[(long long)n * a.emb_ld + C + c + i] : 0.f,
+                  FILM, ACT, dyh, xh);
+      float v = rs * (dyh - m1 - xh * m2);
+      if (a.add) v += ad[i];
+      if (a.add2) v = rh(v) + a2[i];                                   // same rounding as a separate fp16 add of the two maps
+      o[i] = v;
+    }
+    if (a.csplit == 0) st_half<VEC>(a.dx + pix * C + c, o);
+    else if (c < a.csplit) st_half<VEC>(a.dx + pix * a.csplit + c, o);
+    else st_half<VEC>(a.dx2 + pix * (C - a.csplit) + (c - a.csplit), o);
+  }
+}
+
+int pick_vec(int cpg) { return cpg % 8 == 0 ? 8 : (cpg % 4 == 0 ? 4 : (cpg % 2 == 0 ? 2 : 1)); }
+int pick_threads(int nunits) { return nunits >= 1024 ? 1024 : (nunits >= 512 ? 512 : 256); }
+constexpr size_t LOCAL_LDS_CAP = 160 * 1024 - 256;
+
+template <typename K>
+int set_lds(K kern, size_t smem) {
+  // per kernel symbol: raise the dynamic LDS limit once
+  static thread_local const void* done[64];
+  static thread_local int ndone = 0;
+  for (int i = 0; i < ndone; ++i) if (done[i] == (const void*)kern) return 0;
+  ISHAP_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LOCAL_LDS_CAP + 256));
+  if (ndone < 64) done[ndone++] = (const void*)kern;
+  (void)smem;
+  return 0;
+}
+
+}  // namespace
+
+bool gn_local_fits(int HW, int C) {
+  return C % 32 == 0 && (size_t)HW * (C / 32) * sizeof(half_t) <= LOCAL_LDS_CAP;
+}
+bool gn_bwd_local_fits(int HW, int C, int gmode) {
+  return C % 32 == 0 && (size_t)HW * (C / 32) * (gmode != GB_SAME ? sizeof(float) : sizeof(half_t)) <= LOCAL_LDS_CAP;
+}
+
+int gn_local_launch(const GnLocalArgs& a, hipStream_t s) {
+  ISHAP_REQUIRE(a.C % 32 == 0 && a.Ca > 0 && a.Ca <= a.C && a.Ca % 32 == 0, "GroupNorm channels: multiples of 32");
+  ISHAP_REQUIRE((a.Ca == a.C) == (a.xb == nullptr), "second source exactly when the input is a concatenation");
+  ISHAP_REQUIRE(a.slab.pending() || a.xa, "source A: a tensor or pending slices");
+  ISHAP_REQUIRE(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0 && !a.film), "pool variant");
+  const int HW = a.H * a.W, cpg = a.C / 32;
+  ISHAP_REQUIRE(gn_local_fits(HW, a.C), "group does not fit in LDS");
+  const int VEC = pick_vec(cpg);
+  const int T = pick_threads(HW * (cpg / VEC));
+  const size_t smem = 256 + (size_t)HW * cpg * sizeof(half_t);
+  dim3 grid(32, a.N), blk(T);
+#define GL_LAUNCH(V, F, A, P)                                                            \
+  do {                                                                                   \
+    auto kern = gn_local_kernel<V, F, A, P>;                                             \
+    ISHAP_TRY(set_lds(kern, smem));                                                      \
+    hipLaunchKernelGGL(kern, grid, blk, smem, s, a);                                     \
+  } while (0)
+#define GL_VARIANT(V)                                                                    \
+  do {                                                                                   \
+    if (a.pool) GL_LAUNCH(V, false, true, true);                                         \
+    else if (a.film) GL_LAUNCH(V, true, true, false);                                    \
+    else if (a.act) GL_LAUNCH(V, false, true, false);                                    \
+    else GL_LAUNCH(V, false, false, false);                                              \
+  } while (0)
+  ISHAP_REQUIRE(!a.pool || a.act, "the pooled variant carries SiLU (ResBlock in_layers)");
+  ISHAP_REQUIRE(!a.film || a.act, "FiLM is followed by SiLU (ResBlock out_layers)");
+  switch (VEC) {
+    case 8: GL_VARIANT(8); break;
+    case 4: GL_VARIANT(4); break;
+    case 2: GL_VARIANT(2); break;
+    default: GL_VARIANT(1); break;
+  }
+#undef GL_VARIANT
+#undef GL_LAUNCH
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int gn_bwd_local_launch(const GnBwdLocalArgs& a, hipStream_t s) {
+  ISHAP_REQUIRE(a.C % 32 == 0, "GroupNorm channels");
+  ISHAP_REQUIRE(a.csplit == 0 || (a.dx2 && a.csplit % 32 == 0 && a.csplit < a.C), "split output");
+  ISHAP_REQUIRE(a.slab.pending() || a.g, "upstream gradient: a tensor or pending slices");
+  ISHAP_REQUIRE(!a.film || a.act, "FiLM is followed by SiLU");
+  const int HW = a.H * a.W, cpg = a.C / 32;
+  const bool s32 = a.gmode != GB_SAME;      // 0.25 * fp16 and sums of four fp16 values are kept in fp32 between the passes
+  const size_t smem = 256 + (size_t)HW * cpg * (s32 ? sizeof(float) : sizeof(half_t));
+  ISHAP_REQUIRE(smem <= LOCAL_LDS_CAP + 256, "group does not fit in LDS");
+  const int VEC = pick_vec(cpg);
+  const int T = pick_threads(HW * (cpg / VEC));
+  dim3 grid(32, a.N), blk(T);
+#define GB_LAUNCH(V, F, A, S32)                                                          \
+  do {                                                                                   \
+    auto kern = gn_bwd_local_kernel<V, F, A, S32>;                                       \
+    ISHAP_TRY(set_lds(kern, smem));                                                      \
+    hipLaunchKernelGGL(kern, grid, blk, smem, s, a);                                     \
+  } while (0)
+#define GB_VARIANT(V)                                                                    \
+  do {                                                                                   \
+    if (s32) {                                                                           \
+      if (a.film) GB_LAUNCH(V, true, true, true);                                        \
+      else if (a.act) GB_LAUNCH(V, false, true, true);                                   \
+      else GB_LAUNCH(V, false, false, true);                                             \
+    } else {                                                                             \
+      if (a.film) GB_LAUNCH(V, true, true, false);                                       \
+      else if (a.act) GB_LAUNCH(V, false, true, false);                                  \
+      else GB_LAUNCH(V, false, false, false);                                            \
+    }                                                                                    \
+  } while (0)
+  switch (VEC) {
+    case 8: GB_VARIANT(8); break;
+    case 4: GB_VARIANT(4); break;
+    case 2: GB_VARIANT(2); break;
+    default: GB_VARIANT(1); break;
+  }
+#undef GB_VARIANT
+#undef GB_LAUNCH
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -15,6 +15,9 @@ struct Tensor {
   // pass) fills while it reads the two halves (cat_a: first cat_ca channels with sums cat_sa; cat_b: the rest, sums cat_sb)
   const half_t* cat_a = nullptr; const half_t* cat_b = nullptr; const long long* cat_sa = nullptr; const long long* cat_sb = nullptr;
   int cat_ca = 0;
+  // the tensor is still the split-K slices of its producing convolution (common.h SlabSrc): `p` is where the fp16 values go
+  // once the next GroupNorm pass (or slab_materialize) has added them up; cat_pend: the same for cat_a of a lazy concatenation
+  SlabSrc pend, cat_pend;
   long long rows() const { return (long long)N * H * W; }
   long long numel() const { return rows() * C; }
 };
@@ -168,10 +171,16 @@ static inline int aalloc_checked(Exec& e, size_t count, T** out) {
     ISHAP_REQUIRE((ptr) != nullptr, "GroupNorm statistics arena exhausted");                          \
   } while (0)
 // X [N,H,W,ldx] (*) Wt -> out; taps 9 (3x3, pad 1) or 1; picks split-K and uses the context workspace
+// pend_out: the caller's consumer can read split-K slices (a group-local GroupNorm pass): when the launch splits K, the
+// slices stay in an arena buffer described by *pend_out and no reduce kernel runs (fp16 dense outputs only)
 int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps, int cout,
             const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups, int res_ups,
             long long* stat_out = nullptr, const struct GnBwdArgs* gb = nullptr, const half_t* X2 = nullptr, int ldx2 = 0,
-            int K2 = 0, const float* bias2 = nullptr, int ldw = 0);
+            int K2 = 0, const float* bias2 = nullptr, int ldw = 0, SlabSrc* pend_out = nullptr);
+// small maps (<= 32 x 32): GroupNorm passes run group-local (norm_local.hip), producers gather no statistics
+bool small_map(int HW);
+bool local_gn(int HW, int C);
+int slab_materialize(Exec& e, Tensor& t);    // add up a pending tensor with the stand-alone reduce kernel (consumers that cannot)
 long long* salloc(Exec& e, size_t count);   // from the stats arena
 int gn_stats_op(Exec& e, const Tensor& x, float* stats);
 

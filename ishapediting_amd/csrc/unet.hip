@@ -259,10 +259,16 @@ long long* salloc(Exec& e, size_t count) {
   return u->stat_off <= u->stat_cap ? u->stat_base + o : nullptr;
 }
 
+bool small_map(int HW) {
+  static const int on = [] { const char* v = getenv("ISHAP_LOCAL_GN"); return v ? atoi(v) : 1; }();
+  return on && HW <= 1024;
+}
+bool local_gn(int HW, int C) { return small_map(HW) && gn_local_fits(HW, C); }
+
 int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps,
                    int cout, const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups,
                    int res_ups, long long* stat_out, const GnBwdArgs* gb, const half_t* X2, int ldx2, int K2,
-                   const float* bias2, int ldw) {
+                   const float* bias2, int ldw, SlabSrc* pend_out) {
   IgemmArgs a;
   a.stat_out = stat_out;
   if (gb) {       // this launch produces the gradient arriving at act(film(GN(x))): accumulate the GN-backward sums in its epilogue
@@ -279,6 +285,19 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
   a.flops_scale = (Wt == e.u->head.w) ? 1.f / 3.f : 1.f;
   a.ksplit = igemm_pick_ksplit(a.M, a.N, a.K, 1);
   if (!a.conv3 && a.M <= 64 && a.K % 64 == 0) a.ksplit = 1;   // 1x1 GEMMs on the 8x8 maps: the one-launch small-map kernel (10.7 vs 16.2 us at K = 3072)
+  if (pend_out) *pend_out = SlabSrc{};
+  if (pend_out && a.ksplit > 1) {
+    // the consumer adds the slices up itself: they live in the arena until it has run
+    ISHAP_REQUIRE(out_mode == IG_OUT_F16 && ldo == cout && !stat_out && !gb, "deferred reduce: dense fp16 output, no epilogue sums");
+    float* slab = nullptr;
+    ISHAP_ALLOC(slab, e, (size_t)a.ksplit * a.M * a.N);
+    pend_out->ws = slab; pend_out->nslab = a.ksplit; pend_out->zstride = (long long)a.M * a.N;
+    pend_out->bias = bias; pend_out->bias2 = bias2; pend_out->res = res; pend_out->ldr = ldr; pend_out->res_ups = res_ups;
+    if (e.dry) return 0;
+    a.ws = slab;
+    a.defer_reduce = 1;
+    return igemm_launch(a, e.s);
+  }
   size_t need = a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N : 0;
   if (e.dry) {
     if (need > e.u->ws_floats) e.u->ws_floats = need;
@@ -287,6 +306,19 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
   ISHAP_REQUIRE(need <= e.u->ws_floats, "split-K workspace too small");
   a.ws = e.u->ws;
   return igemm_launch(a, e.s);
+}
+
+// A pending tensor whose next consumer cannot add the slices up itself: the stand-alone reduce (bias, residual, fp16).
+int slab_materialize(Exec& e, Tensor& t) {
+  if (!t.pend.pending()) return 0;
+  const SlabSrc p = t.pend;
+  t.pend = SlabSrc{};
+  if (e.dry) return 0;
+  IgemmArgs a;
+  a.ws = const_cast<float*>(p.ws); a.ksplit = p.nslab; a.M = (int)t.rows(); a.N = t.C; a.K = 64;
+  a.bias = p.bias; a.bias2 = p.bias2; a.res = p.res; a.ldr = p.ldr; a.res_ups = p.res_ups;
+  a.H = t.H; a.W = t.W; a.out = t.p; a.ldo = t.C; a.out_mode = IG_OUT_F16;
+  return igemm_reduce_launch(a, e.s);
 }
 
 int gn_stats_op(Exec& e, const Tensor& x, float* stats) {
@@ -299,7 +331,26 @@ int gn_stats_op(Exec& e, const Tensor& x, float* stats) {
   return gn_stats_launch(x.p, e.u->gn_partial, stats, x.N, x.H * x.W, x.C, e.s);
 }
 
-static int res_forward(Exec& e, ResL& L, const Tensor& x, Tensor& y) {
+// GroupNorm (+FiLM) (+SiLU) (+2x2 pool) of `x` into `out` on a small map: one group-local launch that also adds up `x`
+// when it is still pending (and its first half when x is a lazy skip concatenation), see norm_local.hip
+static int gn_local_op(Exec& e, Tensor& x, const NormW& nw, half_t* out, half_t* xpool, float* stats_out, const float* emb,
+                       int emb_ld, int film, int act, int pool) {
+  GnLocalArgs g;
+  if (x.cat_a) {
+    g.xa = x.cat_a; g.slab = x.cat_pend; g.ya = x.cat_pend.pending() ? const_cast<half_t*>(x.cat_a) : nullptr;
+    g.Ca = x.cat_ca; g.xb = x.cat_b; g.xcopy = x.p;
+  } else {
+    g.xa = x.p; g.slab = x.pend; g.ya = x.pend.pending() ? x.p : nullptr; g.Ca = x.C;
+  }
+  x.pend = SlabSrc{};
+  x.cat_pend = SlabSrc{};
+  g.out = out; g.xpool = xpool; g.stats_out = stats_out; g.gamma = nw.gamma; g.beta = nw.beta; g.emb = emb; g.emb_ld = emb_ld;
+  g.N = x.N; g.H = x.H; g.W = x.W; g.C = x.C; g.film = film; g.act = act; g.pool = pool;
+  if (e.dry) return 0;
+  return gn_local_launch(g, e.s);
+}
+
+static int res_forward(Exec& e, ResL& L, Tensor x, Tensor& y) {
   ishap_unet* u = e.u;
   const int N = x.N, H = x.H, W = x.W;
   const int Ho = L.down ? H / 2 : (L.up ? H * 2 : H), Wo = L.down ? W / 2 : (L.up ? W * 2 : W);
@@ -308,43 +359,63 @@ static int res_forward(Exec& e, ResL& L, const Tensor& x, Tensor& y) {
   float* st2 = nullptr; ISHAP_ALLOC(st2, e, (size_t)N * 64);
   const bool lazy_cat = x.cat_a != nullptr;
   ISHAP_REQUIRE(!lazy_cat || (!L.down && !L.up), "a skip concatenation feeds a plain ResBlock");
-  if (!x.sums && !lazy_cat) ISHAP_TRY(gn_stats_op(e, x, st1));
+  const bool loc_in = local_gn(H * W, L.cin), loc_out = local_gn(Ho * Wo, L.cout);
+  const bool nosum_out = small_map(Ho * Wo);      // the consumers of an activation on a small map gather their own statistics
   Tensor a{nullptr, N, L.down ? Ho : H, L.down ? Wo : W, L.cin};
   ISHAP_ALLOC(a.p, e, a.numel());
   Tensor xs = x;
+  xs.pend = SlabSrc{}; xs.cat_pend = SlabSrc{};
   if (L.down) { xs = a; ISHAP_ALLOC(xs.p, e, a.numel()); }
-  if (!e.dry) {
-    GnApplyArgs g;
-    g.x = x.p; g.out = a.p; g.xpool = L.down ? xs.p : nullptr;
-    g.stats = st1; g.sums = x.sums; g.stats_out = x.sums ? st1 : nullptr; g.gamma = L.n1.gamma; g.beta = L.n1.beta;
-    g.N = N; g.H = H; g.W = W; g.C = L.cin; g.act = 1; g.pool = L.down;
-    if (lazy_cat) {
-      g.x = x.cat_a; g.x2 = x.cat_b; g.sums = x.cat_sa; g.sums2 = x.cat_sb; g.csplit = x.cat_ca; g.xcopy = x.p;
-      g.stats_out = st1;
+  if (loc_in) {
+    ISHAP_TRY(gn_local_op(e, x, L.n1, a.p, L.down ? xs.p : nullptr, st1, nullptr, 0, 0, 1, L.down));
+  } else {
+    ISHAP_REQUIRE(!lazy_cat || (x.cat_sa && x.cat_sb), "a lazy concatenation on a large map carries the producers' sums");
+    ISHAP_TRY(slab_materialize(e, x));
+    if (!x.sums && !lazy_cat) ISHAP_TRY(gn_stats_op(e, x, st1));
+    if (!e.dry) {
+      GnApplyArgs g;
+      g.x = x.p; g.out = a.p; g.xpool = L.down ? xs.p : nullptr;
+      g.stats = st1; g.sums = x.sums; g.stats_out = x.sums ? st1 : nullptr; g.gamma = L.n1.gamma; g.beta = L.n1.beta;
+      g.N = N; g.H = H; g.W = W; g.C = L.cin; g.act = 1; g.pool = L.down;
+      if (lazy_cat) {
+        g.x = x.cat_a; g.x2 = x.cat_b; g.sums = x.cat_sa; g.sums2 = x.cat_sb; g.csplit = x.cat_ca; g.xcopy = x.p;
+        g.stats_out = st1;
+      }
+      ISHAP_TRY(gn_apply_launch(g, e.s));
     }
-    ISHAP_TRY(gn_apply_launch(g, e.s));
   }
   Tensor h1{nullptr, N, Ho, Wo, L.cout};
   ISHAP_ALLOC(h1.p, e, h1.numel());
-  ISHAP_SALLOC(h1.sums, e, (size_t)N * L.cout * 2);
+  if (!nosum_out) ISHAP_SALLOC(h1.sums, e, (size_t)N * L.cout * 2);
   ISHAP_TRY(conv_op(e, a.p, N, Ho, Wo, L.cin, L.c1.w, L.c1.kpad, 9, L.cout, L.c1.bias, nullptr, 0, h1.p, L.cout, IG_OUT_F16,
-                    L.up, 0, h1.sums));
+                    L.up, 0, h1.sums, nullptr, nullptr, 0, 0, nullptr, 0, loc_out ? &h1.pend : nullptr));
   Tensor c = h1;
+  c.pend = SlabSrc{};
   ISHAP_ALLOC(c.p, e, h1.numel());
-  if (!e.dry) {
-    GnApplyArgs g;
-    g.x = h1.p; g.out = c.p; g.stats = st2; g.sums = h1.sums; g.stats_out = st2; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
-    g.emb = u->d_film + L.emb_off; g.emb_ld = u->film_rows;
-    g.N = N; g.H = Ho; g.W = Wo; g.C = L.cout; g.film = 1; g.act = 1;
-    ISHAP_TRY(gn_apply_launch(g, e.s));
+  if (loc_out) {
+    ISHAP_TRY(gn_local_op(e, h1, L.n2, c.p, nullptr, st2, u->d_film + L.emb_off, u->film_rows, 1, 1, 0));
+  } else {
+    if (!h1.sums) ISHAP_TRY(gn_stats_op(e, h1, st2));
+    if (!e.dry) {
+      GnApplyArgs g;
+      g.x = h1.p; g.out = c.p; g.stats = st2; g.sums = h1.sums; g.stats_out = h1.sums ? st2 : nullptr; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
+      g.emb = u->d_film + L.emb_off; g.emb_ld = u->film_rows;
+      g.N = N; g.H = Ho; g.W = Wo; g.C = L.cout; g.film = 1; g.act = 1;
+      ISHAP_TRY(gn_apply_launch(g, e.s));
+    }
   }
   y = h1;
+  y.pend = SlabSrc{};
   ISHAP_ALLOC(y.p, e, h1.numel());
-  ISHAP_SALLOC(y.sums, e, (size_t)N * L.cout * 2);
+  y.sums = nullptr;
+  if (!nosum_out) ISHAP_SALLOC(y.sums, e, (size_t)N * L.cout * 2);
+  // the block output's next reader is always a GroupNorm pass (the next ResBlock's, an attention block's, the head's):
+  // on a small map it may stay pending
+  SlabSrc* ypend = small_map(Ho * Wo) ? &y.pend : nullptr;
   if (L.has_skip && L.c2.cat) {
     // y = conv2(c) + skip(x) as ONE launch: the 1x1 skip convolution is L.cin more K columns read from x
     ISHAP_TRY(conv_op(e, c.p, N, Ho, Wo, L.cout, L.c2.cat, L.c2.kpad, 9, L.cout, L.c2.bias, nullptr, 0, y.p, L.cout,
-                      IG_OUT_F16, 0, 0, y.sums, nullptr, xs.p, L.cin, L.skip.kpad, L.skip.bias, L.c2.cat_ld));
+                      IG_OUT_F16, 0, 0, y.sums, nullptr, xs.p, L.cin, L.skip.kpad, L.skip.bias, L.c2.cat_ld, ypend));
   } else if (L.has_skip) {
     ISHAP_TRY(conv_op(e, xs.p, N, Ho, Wo, L.cin, L.skip.w, L.skip.kpad, 1, L.cout, L.skip.bias, nullptr, 0, y.p, L.cout,
                       IG_OUT_F16, 0, 0));
@@ -352,27 +423,36 @@ static int res_forward(Exec& e, ResL& L, const Tensor& x, Tensor& y) {
                       IG_OUT_F16, 0, 0, y.sums));
   } else {
     ISHAP_TRY(conv_op(e, c.p, N, Ho, Wo, L.cout, L.c2.w, L.c2.kpad, 9, L.cout, L.c2.bias, xs.p, L.cin, y.p, L.cout,
-                      IG_OUT_F16, 0, L.up, y.sums));
+                      IG_OUT_F16, 0, L.up, y.sums, nullptr, nullptr, 0, 0, nullptr, 0, ypend));
   }
+  h1.pend = SlabSrc{};
+  x.pend = SlabSrc{}; x.cat_pend = SlabSrc{};
   L.sv.x = x; L.sv.h1 = h1; L.sv.xs = xs; L.sv.stats1 = st1; L.sv.stats2 = st2;
   return 0;
 }
 
-static int attn_forward(Exec& e, AttnL& L, const Tensor& x, Tensor& y) {
+static int attn_forward(Exec& e, AttnL& L, Tensor x, Tensor& y) {
   ishap_unet* u = e.u;
+  (void)u;
   const int N = x.N, T = x.H * x.W, C = L.C, heads = L.heads, d = C / heads;
   ISHAP_REQUIRE(x.C == C, "attention channels");
   ISHAP_REQUIRE(d % 32 == 0, "head width must be a multiple of 32");
   float* st = nullptr; ISHAP_ALLOC(st, e, (size_t)N * 64);
   float* lse = nullptr; ISHAP_ALLOC(lse, e, (size_t)N * heads * T);
-  if (!x.sums) ISHAP_TRY(gn_stats_op(e, x, st));
   Tensor nrm = x;
+  nrm.pend = SlabSrc{};
   ISHAP_ALLOC(nrm.p, e, x.numel());
-  if (!e.dry) {
-    GnApplyArgs g;
-    g.x = x.p; g.out = nrm.p; g.stats = st; g.sums = x.sums; g.stats_out = x.sums ? st : nullptr; g.gamma = L.n.gamma; g.beta = L.n.beta;
-    g.N = N; g.H = x.H; g.W = x.W; g.C = C; g.act = 0;
-    ISHAP_TRY(gn_apply_launch(g, e.s));
+  if (local_gn(T, C)) {
+    ISHAP_TRY(gn_local_op(e, x, L.n, nrm.p, nullptr, st, nullptr, 0, 0, 0, 0));
+  } else {
+    ISHAP_TRY(slab_materialize(e, x));
+    if (!x.sums) ISHAP_TRY(gn_stats_op(e, x, st));
+    if (!e.dry) {
+      GnApplyArgs g;
+      g.x = x.p; g.out = nrm.p; g.stats = st; g.sums = x.sums; g.stats_out = x.sums ? st : nullptr; g.gamma = L.n.gamma; g.beta = L.n.beta;
+      g.N = N; g.H = x.H; g.W = x.W; g.C = C; g.act = 0;
+      ISHAP_TRY(gn_apply_launch(g, e.s));
+    }
   }
   Tensor qkv{nullptr, N, x.H, x.W, 3 * C};
   ISHAP_ALLOC(qkv.p, e, qkv.numel());
@@ -388,10 +468,13 @@ static int attn_forward(Exec& e, AttnL& L, const Tensor& x, Tensor& y) {
     ISHAP_TRY(attn_forward_launch(g, e.s));
   }
   y = x;
+  y.pend = SlabSrc{};
   ISHAP_ALLOC(y.p, e, x.numel());
-  ISHAP_SALLOC(y.sums, e, (size_t)N * C * 2);
+  y.sums = nullptr;
+  const bool nosum = small_map(T);
+  if (!nosum) ISHAP_SALLOC(y.sums, e, (size_t)N * C * 2);
   ISHAP_TRY(conv_op(e, a.p, N, x.H, x.W, C, L.proj.w, L.proj.kpad, 1, C, L.proj.bias, x.p, C, y.p, C, IG_OUT_F16, 0, 0,
-                    y.sums));
+                    y.sums, nullptr, nullptr, 0, 0, nullptr, 0, nosum ? &y.pend : nullptr));
   L.sv.x = x; L.sv.qkv = qkv; L.sv.a = a; L.sv.stats = st; L.sv.lse = lse; L.sv.P = nullptr;
   return 0;
 }
@@ -403,7 +486,7 @@ static int block_forward(Exec& e, BlockL& b, Tensor h, Tensor& out) {
     if (l.kind == 0) {
       y = Tensor{nullptr, h.N, h.H, h.W, u->stem.cout};
       ISHAP_ALLOC(y.p, e, y.numel());
-      ISHAP_SALLOC(y.sums, e, (size_t)h.N * u->stem.cout * 2);
+      if (!small_map(h.H * h.W)) ISHAP_SALLOC(y.sums, e, (size_t)h.N * u->stem.cout * 2);
       ISHAP_TRY(conv_op(e, h.p, h.N, h.H, h.W, h.C, u->stem.w, u->stem.kpad, 9, u->stem.cout, u->stem.bias, nullptr, 0, y.p,
                         u->stem.cout, IG_OUT_F16, 0, 0, y.sums));
     } else if (l.kind == 1) {
@@ -414,7 +497,8 @@ static int block_forward(Exec& e, BlockL& b, Tensor h, Tensor& out) {
     h = y;
   }
   out = h;
-  b.out = h;
+  b.out = h;                      // what later readers see: by then the next GroupNorm pass has added up a pending output
+  b.out.pend = SlabSrc{};
   return 0;
 }
 
@@ -450,6 +534,7 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     ISHAP_TRY(block_forward(e, b, h, y));
     h = y;
     hs.push_back(h);
+    hs.back().pend = SlabSrc{};     // read again only after the next block's first GroupNorm pass has added it up
   }
   {
     Tensor y;
@@ -464,19 +549,26 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     Tensor cat{nullptr, h.N, h.H, h.W, h.C + skip.C};
     ISHAP_REQUIRE(skip.H == h.H && cat.C == b.cin, "skip connection shape");
     ISHAP_ALLOC(cat.p, e, cat.numel());
-    if (h.sums && skip.sums && h.C % 8 == 0 && b.layers[0].kind == 1) {
-      // no copy pass: the ResBlock's first GroupNorm reads both halves and writes the concatenation as it goes
+    const bool first_is_res = b.layers[0].kind == 1;
+    if (first_is_res && local_gn(h.H * h.W, cat.C)) {
+      // no copy pass: the ResBlock's first (group-local) GroupNorm reads both halves -- adding up h if it is still
+      // pending -- and writes the concatenation as it goes
+      cat.cat_a = h.p; cat.cat_b = skip.p; cat.cat_ca = h.C; cat.cat_pend = h.pend;
+    } else if (first_is_res && h.sums && skip.sums && h.C % 8 == 0) {
       cat.cat_a = h.p; cat.cat_b = skip.p; cat.cat_sa = h.sums; cat.cat_sb = skip.sums; cat.cat_ca = h.C;
     } else {
+      ISHAP_TRY(slab_materialize(e, h));
       cat.sums = (h.sums && skip.sums) ? salloc(e, (size_t)cat.N * cat.C * 2) : nullptr;
       if (!dry) ISHAP_TRY(concat2(h.p, skip.p, cat.p, cat.rows(), h.C, skip.C, s, h.sums, skip.sums, cat.sums, cat.N));
     }
     b.cat = cat;
+    b.cat.cat_pend = SlabSrc{};
     Tensor y;
     ISHAP_TRY(block_forward(e, b, cat, y));
     h = y;
-    if ((int)i == feat_layer) u->tap = h;
+    if ((int)i == feat_layer) { u->tap = h; u->tap.pend = SlabSrc{}; }
   }
+  ISHAP_TRY(slab_materialize(e, h));      // the head's GroupNorm runs on the full-size map (never group-local in the real model)
   u->h_final = h;
   // ---- head in fp32 (unet.py:667-669): GroupNorm, SiLU, 3x3 conv with fp32 weights.  The fp32 products are
   //      formed on the fp16 MFMA from hi/lo splits of both operands (3 partial products, fp32 accumulate). ----

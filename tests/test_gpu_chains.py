@@ -321,3 +321,84 @@ def test_checkpoint_tree_generate_cli_and_tri_feat_round_trip(tmp_path, monkeypa
     ds2.train_triplane(tri_feat_path=str(tmp_path / "chw.npy"))
     assert tuple(ds2.w.shape) == (1, 96, 16, 16)
     assert w_first.shape == ds2.w.shape and len(taps_first) == 2
+
+
+# ------------------------------------------------------------------------------------------ small-map kernels
+def _cfg_mid():
+    """64 / 128 / 256 channels on 32^2 / 16^2 / 8^2 maps with attention on the two small levels: every GroupNorm runs
+    group-local (2, 4, 8 channels per group -> the 2-, 4- and 8-wide vector paths), and the 256-channel 3x3 layers on the
+    8x8 maps have >= 36 K-steps, so their split-K slices stay pending and are added up by the next GroupNorm pass
+    (forward) / GroupNorm-backward pass (input gradients)."""
+    return UNetConfig(image_size=32, in_channels=6, model_channels=64, out_channels=12, num_res_blocks=1,
+                      attention_resolutions="16,8", channel_mult=(1, 2, 4), num_head_channels=64)
+
+
+def test_group_local_norms_and_pending_slices_vs_oracle():
+    """Forward (output + every output-block tap) and the input gradient from two taps and from the output, against the
+    fp32 oracle on the same fp16-rounded weights.  Tolerances as for the golden configuration: 1e-2 forward, 2e-2
+    gradients (relative L2)."""
+    from oracle import ref_cpu as O
+    from ishapediting_amd.unet import UNetModel
+    cfg = _cfg_mid()
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 91))
+    spec = build_spec(cfg)
+    m = UNetModel(cfg, dev())
+    m.load_state_dict(sd)
+    net = O.UNetOracle(spec, sd, fp16=False)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 6, 32, 32, generator=g)
+    ts = torch.tensor([617.0])
+    nblk = len(spec.output_blocks)
+    xr = x.clone().requires_grad_(True)
+    ref_out, ref_taps = net.forward(xr, ts, all_taps=True)
+    worst = 0.0
+    for k in range(nblk):
+        out, tap = m(x.to(dev()), ts, feat_layer=k, keep_for_backward=True)
+        r_t = rel(tap, ref_taps[k].detach())
+        worst = max(worst, r_t)
+        assert r_t < 1e-2, (k, r_t)
+        for i in range(len(spec.input_blocks)):
+            pass
+    assert rel(out, ref_out.detach()) < 1e-2
+    for k in (0, nblk - 2):
+        ct = torch.randn(ref_taps[k].shape, generator=g) * 0.1
+        (ref_gx,) = torch.autograd.grad((ref_taps[k] * ct).sum(), xr, retain_graph=True)
+        m(x.to(dev()), ts, feat_layer=k, keep_for_backward=True, want_inter_feat=False)
+        cot = ct[0].permute(1, 2, 0).reshape(-1, ct.shape[1]).contiguous().half().to(dev())
+        gx = m.backward_input(cot)
+        r_g = rel(gx, ref_gx)
+        print(f"mid config tap {k}: grad rel {r_g:.2e}")
+        assert r_g < 2e-2, (k, r_g)
+    ct = torch.randn(ref_out.shape, generator=g)
+    (ref_gx,) = torch.autograd.grad((ref_out * ct).sum(), xr)
+    m(x.to(dev()), ts, feat_layer=-1, keep_for_backward=True)
+    gx = m.backward_from_output(ct.to(dev()))
+    torch.cuda.synchronize()
+    r_g = rel(gx, ref_gx)
+    print(f"mid config: worst tap rel {worst:.2e}, full-depth grad rel {r_g:.2e}")
+    assert r_g < 2e-2
+
+
+def test_group_local_norms_batch_2_equals_single_images():
+    """Per-image groups: batch 2 through the group-local passes (forward + input gradient) against the two images alone.
+    Relative L2 <= 5e-3 / 1e-2 (the split-K policy depends on the row count, so sums may associate differently)."""
+    from ishapediting_amd.unet import UNetModel
+    cfg = _cfg_mid()
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 92))
+    m2, m1 = UNetModel(cfg, dev(), max_batch=2), UNetModel(cfg, dev())
+    m2.load_state_dict(sd)
+    m1.load_state_dict(sd)
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(2, 6, 32, 32, generator=g).to(dev())
+    ts = [77.0, 940.0]
+    k = len(build_spec(cfg).output_blocks) - 3
+    ch, sz = m1.tap_shape(k)
+    cot = (torch.randn(2, sz * sz, ch, generator=g) * 0.1).half().to(dev())
+    out2, _ = m2(x, ts, feat_layer=k, keep_for_backward=True)
+    gx2 = m2.backward_input(cot)
+    for b in range(2):
+        o1, _ = m1(x[b:b + 1], ts[b:b + 1], feat_layer=k, keep_for_backward=True)
+        g1 = m1.backward_input(cot[b:b + 1].contiguous())
+        r_o, r_g = rel(out2[b:b + 1], o1.cpu()), rel(gx2[b:b + 1], g1.cpu())
+        print(f"mid config batch element {b}: out {r_o:.2e} grad {r_g:.2e}")
+        assert r_o < 5e-3 and r_g < 1e-2
