@@ -43,6 +43,9 @@ static int gn_bwd_local_op(Exec& e, const GnBwdArgs& g, Tensor& up) {
   a.g = up.p; a.slab = up.pend; a.x = g.x; a.add = g.add; a.add2 = g.add2; a.dx = g.dx; a.dx2 = g.dx2; a.csplit = g.csplit;
   a.stats = g.stats; a.gamma = g.gamma; a.beta = g.beta; a.emb = g.emb; a.emb_ld = g.emb_ld;
   a.N = g.N; a.H = g.H; a.W = g.W; a.C = g.C; a.film = g.film; a.act = g.act; a.gmode = g.gmode;
+  long long* rec = nullptr;
+  ISHAP_SALLOC(rec, e, (size_t)g.N * 32 * 4);        // zeroed with the rest of the statistics arena
+  a.rec = reinterpret_cast<unsigned long long*>(rec);
   up.pend = SlabSrc{};
   if (e.dry) return 0;
   return gn_bwd_local_launch(a, e.s);

@@ -127,5 +127,7 @@ struct IgemmArgs {
 extern hipEvent_t g_igemm_prof_start, g_igemm_prof_stop;
 int igemm_launch(const IgemmArgs& a, hipStream_t s);
 int igemm_reduce_launch(const IgemmArgs& a, hipStream_t s);
+bool igemm_small3_wanted(const IgemmArgs& a);
+int igemm_small3_slices(const IgemmArgs& a);      // K slices that fill the chip (consumer must be able to add them up)    // the one-launch small-map 3x3 kernel takes this shape (then no split-K)
 // picks a split so the grid fills the chip; returns workspace floats needed
 int igemm_pick_ksplit(int M, int N, int K, int nbatch);

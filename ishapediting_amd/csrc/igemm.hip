@@ -402,6 +402,20 @@ int igemm_reduce_launch(const IgemmArgs& a, hipStream_t s) {
   return 0;
 }
 
+bool igemm_small3_applicable(const IgemmArgs& a);                      // igemm_small3.hip (3x3 on small maps, one launch, weights read once)
+int igemm_small3_launch(const IgemmArgs& a, int nt, hipStream_t s);
+// 3x3 layers on maps of at most 32 x 32 pixels per image: no split-K, no reduce launch (ISHAP_SMALL3=0 restores the tiled route)
+int igemm_small3_slices(const IgemmArgs& a);
+bool igemm_small3_wanted(const IgemmArgs& a) {
+  // 1: the 8x8 maps only (measured: on 16x16 / 32x32 maps every 16-channel tile re-stages its pixels and the tiled kernel
+  // wins, tools/s3_probe.sh), 2: every map up to 32x32, 0: off
+  static const int mode = [] { const char* e = getenv("ISHAP_SMALL3"); return e ? atoi(e) : 1; }();
+  if (!mode || !a.conv3 || a.H * a.W > (mode == 2 ? 1024 : 64)) return false;
+  IgemmArgs t = a;
+  t.ksplit = 1;
+  return igemm_small3_applicable(t);
+}
+
 bool igemm_skinny_applicable(const IgemmArgs& a);                      // igemm_skinny.hip (small maps, one launch)
 int igemm_skinny_launch(const IgemmArgs& a, int mt, hipStream_t s);
 
@@ -426,6 +440,20 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
                             a.gb_stats && a.gb_gamma && a.gb_beta && (!a.gb_film || a.gb_emb)),
                 "fused GroupNorm-backward sums: fp16 dense output, N % 32 == 0, no forward statistics");
   ISHAP_REQUIRE(a.ldx % 8 == 0 && a.ldw % 8 == 0, "row strides must keep 16-byte alignment");
+  if (igemm_small3_wanted(a)) {
+    ISHAP_REQUIRE(a.ksplit == 1 || a.defer_reduce, "the sliced small-map kernel leaves its slices to the consumer");
+    if (!g_prof_on) return igemm_small3_launch(a, 0, s);
+    ProfRec r;
+    r.a = prof_event(); r.b = prof_event(); r.c = nullptr;
+    r.flops = 2.0 * a.M * a.N * a.K * a.flops_scale;
+    r.variant = 7;
+    r.M = a.M; r.N = a.N; r.K = a.K; r.conv3 = 1; r.big = false; r.ksplit = -a.ksplit;      // negative: the small-map 3x3 kernel with that many K slices
+    g_igemm_prof_start = r.a; g_igemm_prof_stop = r.b;
+    const int rc = igemm_small3_launch(a, 0, s);
+    g_igemm_prof_start = nullptr; g_igemm_prof_stop = nullptr;
+    g_prof.push_back(r);
+    return rc;
+  }
   if (use_skinny(a)) {
     if (!g_prof_on) return igemm_skinny_launch(a, 0, s);
     ProfRec r;

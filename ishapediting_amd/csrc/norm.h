@@ -83,6 +83,10 @@ struct GnLocalArgs {
   int emb_ld = 0;
   int N = 1, H = 0, W = 0, C = 0;
   int film = 0, act = 1, pool = 0;
+  // optional zeroed scratch [N][32][4] x 64 bit: lets several workgroups share one (image, group) (they meet through
+  // memory-side integer atomics); null = one workgroup per group.  `parts` is set by the launcher.
+  unsigned long long* rec = nullptr;
+  int parts = 1;
 };
 bool gn_local_fits(int HW, int C);              // LDS budget of the forward / backward staging
 int gn_local_launch(const GnLocalArgs& a, hipStream_t s);
@@ -103,6 +107,8 @@ struct GnBwdLocalArgs {
   int emb_ld = 0;
   int N = 1, H = 0, W = 0, C = 0;
   int film = 0, act = 1, gmode = GB_SAME;
+  unsigned long long* rec = nullptr;   // as in GnLocalArgs
+  int parts = 1;
 };
 bool gn_bwd_local_fits(int HW, int C, int gmode);
 int gn_bwd_local_launch(const GnBwdLocalArgs& a, hipStream_t s);

@@ -72,25 +72,39 @@ __device__ __forceinline__ void add_f32(const float* p, float* acc) {
   }
 }
 
-// sum of the pending slices at (row, c .. c+VEC-1), in slice order, four loads in flight
+// sum of the pending slices at (row, c .. c+VEC-1) in slice order.  Every slice load is issued before the first add
+// (NB loads in flight per lane: these kernels run on 32 CUs per image and are bound by load latency, not bandwidth);
+// NB = the slice count rounded up to a power of two, the surplus loads re-read the last slice and are not added.
+template <int VEC, int NB>
+__device__ __forceinline__ void slab_sum_nb(const SlabSrc& s, const float* p, float* v) {
+  float t[NB][VEC];
+#pragma unroll
+  for (int z = 0; z < NB; ++z) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) t[z][i] = 0.f;
+    const int zz = z < s.nslab ? z : s.nslab - 1;
+    add_f32<VEC>(p + zz * s.zstride, t[z]);
+  }
+#pragma unroll
+  for (int z = 0; z < NB; ++z) {
+    if (z < s.nslab) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i] += t[z][i];
+    }
+  }
+}
 template <int VEC>
 __device__ __forceinline__ void slab_sum(const SlabSrc& s, long long row, int ld, int c, float* v) {
 #pragma unroll
   for (int i = 0; i < VEC; ++i) v[i] = 0.f;
   const float* p = s.ws + row * ld + c;
-  int z = 0;
-  for (; z + 4 <= s.nslab; z += 4) {
-    float t0[VEC], t1[VEC], t2[VEC], t3[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) { t0[i] = 0.f; t1[i] = 0.f; t2[i] = 0.f; t3[i] = 0.f; }
-    add_f32<VEC>(p + (z + 0) * s.zstride, t0);
-    add_f32<VEC>(p + (z + 1) * s.zstride, t1);
-    add_f32<VEC>(p + (z + 2) * s.zstride, t2);
-    add_f32<VEC>(p + (z + 3) * s.zstride, t3);
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) { v[i] += t0[i]; v[i] += t1[i]; v[i] += t2[i]; v[i] += t3[i]; }
+  if (s.nslab <= 2) slab_sum_nb<VEC, 2>(s, p, v);
+  else if (s.nslab <= 4) slab_sum_nb<VEC, 4>(s, p, v);
+  else if (s.nslab <= 8) slab_sum_nb<VEC, 8>(s, p, v);
+  else if (s.nslab <= 16) slab_sum_nb<VEC, 16>(s, p, v);
+  else {
+    for (int z = 0; z < s.nslab; ++z) add_f32<VEC>(p + z * s.zstride, v);
   }
-  for (; z < s.nslab; ++z) add_f32<VEC>(p + z * s.zstride, v);
 }
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
@@ -108,20 +122,55 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
   for (int w = 0; w < nw; ++w) { a += scratch[w]; b += scratch[16 + w]; }      // fixed order
 }
 
+// Several workgroups share one (image, group): each adds its two partial sums to the group's record in global memory
+// and waits until all `parts` have.  Everything that crosses workgroups is a 64-bit integer atomic executed at the
+// memory side (fixed point: integer adds commute, so the totals are bitwise reproducible; and an atomic read-modify-
+// write is coherent across the XCDs' L2s, which plain and sc1 loads are not -- MI355X_MICROARCH.md, inter-workgroup
+// visibility).  rec = {sum a, sum b, arrivals}, zeroed before the launch.  The launcher only uses parts > 1 when the
+// whole grid is resident at once (<= 256 workgroups of <= 1024 threads); the spin is bounded all the same.
+__device__ __forceinline__ void group_rendezvous(double& a, double& b, unsigned long long* rec, int parts, float scale_a,
+                                                 float scale_b, double* scratch) {
+  if (parts <= 1) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long fa = __double2ll_rn(a * (double)scale_a), fb = __double2ll_rn(b * (double)scale_b);
+    // returning atomics: both sums have been applied at the memory side before the arrival is counted
+    const unsigned long long o0 = __hip_atomic_fetch_add(rec + 0, (unsigned long long)fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long o1 = __hip_atomic_fetch_add(rec + 1, (unsigned long long)fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" :: "v"(o0), "v"(o1) : "memory");     // both returned: the sums are in place before the arrival counts
+    // relaxed everywhere: no plain memory crosses workgroups here, so no cache write-back / invalidate is needed
+    __hip_atomic_fetch_add(rec + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_fetch_add(rec + 2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)parts &&
+           ++spins < (1 << 22))
+      __builtin_amdgcn_s_sleep(2);
+    const long long ta = (long long)__hip_atomic_fetch_add(rec + 0, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long tb = (long long)__hip_atomic_fetch_add(rec + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    scratch[0] = (double)ta / (double)scale_a;
+    scratch[1] = (double)tb / (double)scale_b;
+  }
+  __syncthreads();
+  a = scratch[0];
+  b = scratch[1];
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int VEC, bool FILM, bool ACT, bool POOL>
 __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* scratch = reinterpret_cast<double*>(smem_raw);                 // 32 doubles
   half_t* st = reinterpret_cast<half_t*>(smem_raw + 256);                // [HW][cpg]
-  const int g = blockIdx.x, n = blockIdx.y;
+  const int g = blockIdx.x / a.parts, part = blockIdx.x - g * a.parts, n = blockIdx.y;
   const int C = a.C, cpg = C / 32, VPP = cpg / VEC, HW = a.H * a.W;
-  const int nunits = HW * VPP, c0g = g * cpg;
+  const int PP = HW / a.parts, p0 = part * PP;                           // this workgroup's pixels [p0, p0 + PP)
+  const int nunits = PP * VPP, c0g = g * cpg;
   const int Cb = C - a.Ca;
   const bool pend = a.slab.pending();
   double s = 0.0, q = 0.0;
   for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
-    const int p = u / VPP, cv = u - p * VPP, c = c0g + cv * VEC;
+    const int pl = u / VPP, cv = u - pl * VPP, c = c0g + cv * VEC;
+    const int p = p0 + pl;
     const long long row = (long long)n * HW + p;
     float v[VEC];
     if (c < a.Ca) {
@@ -156,17 +205,18 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
       ld_half<VEC>(a.xb + row * Cb + (c - a.Ca), v);
     }
     if (a.xcopy) st_half<VEC>(a.xcopy + row * C + c, v);
-    st_half<VEC>(st + p * cpg + cv * VEC, v);
+    st_half<VEC>(st + pl * cpg + cv * VEC, v);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { s += (double)v[i]; q += (double)v[i] * (double)v[i]; }
   }
   block_sum2(s, q, scratch);
+  group_rendezvous(s, q, a.rec + ((long long)n * 32 + g) * 4, a.parts, STAT_SCALE_SUM, STAT_SCALE_SQ, scratch);
   const double cnt = (double)HW * (double)cpg;
   const double md = s / cnt;
   double vd = q / cnt - md * md;
   vd = vd < 0.0 ? 0.0 : vd;
   const float mean = (float)md, rstd = (float)(1.0 / sqrt(vd + 1e-5));
-  if (threadIdx.x == 0 && a.stats_out) {
+  if (threadIdx.x == 0 && part == 0 && a.stats_out) {
     a.stats_out[(n * 32 + g) * 2] = mean;
     a.stats_out[(n * 32 + g) * 2 + 1] = rstd;
   }
@@ -187,16 +237,18 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
   };
   if (!POOL) {
     for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
-      const int p = u / VPP, cv = u - p * VPP, c = c0g + cv * VEC;
+      const int pl = u / VPP, cv = u - pl * VPP, c = c0g + cv * VEC;
       float x[VEC], o[VEC];
-      ld_half<VEC>(st + p * cpg + cv * VEC, x);
+      ld_half<VEC>(st + pl * cpg + cv * VEC, x);
       activate(x, c, o);
-      st_half<VEC>(a.out + ((long long)n * HW + p) * C + c, o);
+      st_half<VEC>(a.out + ((long long)n * HW + p0 + pl) * C + c, o);
     }
   } else {
-    const int Wo = a.W >> 1, HWo = HW >> 2;
-    for (int u = threadIdx.x; u < HWo * VPP; u += blockDim.x) {
-      const int po = u / VPP, cv = u - po * VPP, c = c0g + cv * VEC;
+    // a part is a whole number of row pairs (launcher), so its 2x2 cells are its own
+    const int Wo = a.W >> 1, HWo = HW >> 2, PPo = PP >> 2, po0 = p0 >> 2;
+    for (int u = threadIdx.x; u < PPo * VPP; u += blockDim.x) {
+      const int pol = u / VPP, cv = u - pol * VPP, c = c0g + cv * VEC;
+      const int po = po0 + pol;
       const int yo = po / Wo, xo = po - yo * Wo;
       float acc[VEC], xacc[VEC];
 #pragma unroll
@@ -205,7 +257,7 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
       for (int k = 0; k < 4; ++k) {
         const int p = (2 * yo + (k >> 1)) * a.W + 2 * xo + (k & 1);
         float x[VEC], o[VEC];
-        ld_half<VEC>(st + p * cpg + cv * VEC, x);
+        ld_half<VEC>(st + (p - p0) * cpg + cv * VEC, x);
         activate(x, c, o);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { acc[i] += o[i]; xacc[i] += x[i]; }
@@ -265,21 +317,23 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(GnBwdLocalArgs a) {
   double* scratch = reinterpret_cast<double*>(smem_raw);
   half_t* st16 = reinterpret_cast<half_t*>(smem_raw + 256);
   float* st32 = reinterpret_cast<float*>(smem_raw + 256);
-  const int g = blockIdx.x, n = blockIdx.y;
+  const int g = blockIdx.x / a.parts, part = blockIdx.x - g * a.parts, n = blockIdx.y;
   const int C = a.C, cpg = C / 32, VPP = cpg / VEC, HW = a.H * a.W;
-  const int nunits = HW * VPP, c0g = g * cpg;
+  const int PP = HW / a.parts, p0 = part * PP;
+  const int nunits = PP * VPP, c0g = g * cpg;
   const float mu = a.stats[(n * 32 + g) * 2], rs = a.stats[(n * 32 + g) * 2 + 1];
   double s1 = 0.0, s2 = 0.0;
   for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
-    const int p = u / VPP, cv = u - p * VPP, c = c0g + cv * VEC;
+    const int pl = u / VPP, cv = u - pl * VPP, c = c0g + cv * VEC;
+    const int p = p0 + pl;
     float up[VEC], xv[VEC];
     upstream<VEC>(a.g, a.slab, a.gmode, n, p, a.H, a.W, C, c, up);
     ld_half<VEC>(a.x + ((long long)n * HW + p) * C + c, xv);
     if (STAGE32) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) st32[p * cpg + cv * VEC + i] = up[i];
+      for (int i = 0; i < VEC; ++i) st32[pl * cpg + cv * VEC + i] = up[i];
     } else {
-      st_half<VEC>(st16 + p * cpg + cv * VEC, up);                    // exact: these values are fp16 (x 1/4)
+      st_half<VEC>(st16 + pl * cpg + cv * VEC, up);                   // exact: these values are fp16
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -292,18 +346,20 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(GnBwdLocalArgs a) {
     }
   }
   block_sum2(s1, s2, scratch);
+  group_rendezvous(s1, s2, a.rec + ((long long)n * 32 + g) * 4, a.parts, STAT_SCALE_SUM, STAT_SCALE_SUM, scratch);
   const double cnt = (double)HW * (double)cpg;
   const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt);
   __syncthreads();
   for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
-    const int p = u / VPP, cv = u - p * VPP, c = c0g + cv * VEC;
+    const int pl = u / VPP, cv = u - pl * VPP, c = c0g + cv * VEC;
+    const int p = p0 + pl;
     const long long pix = (long long)n * HW + p;
     float up[VEC], xv[VEC], ad[VEC], a2[VEC], o[VEC];
     if (STAGE32) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) up[i] = st32[p * cpg + cv * VEC + i];
+      for (int i = 0; i < VEC; ++i) up[i] = st32[pl * cpg + cv * VEC + i];
     } else {
-      ld_half<VEC>(st16 + p * cpg + cv * VEC, up);
+      ld_half<VEC>(st16 + pl * cpg + cv * VEC, up);
     }
     ld_half<VEC>(a.x + pix * C + c, xv);
     if (a.add) addend<VEC>(a.add, a.gmode, n, p, a.H, a.W, C, c, ad);
@@ -325,8 +381,35 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(GnBwdLocalArgs a) {
   }
 }
 
-int pick_vec(int cpg) { return cpg % 8 == 0 ? 8 : (cpg % 4 == 0 ? 4 : (cpg % 2 == 0 ? 2 : 1)); }
-int pick_threads(int nunits) { return nunits >= 1024 ? 1024 : (nunits >= 512 ? 512 : 256); }
+// the widest vector that still gives every one of 1024 threads a unit (latency-bound kernels: lanes in flight matter more than
+// bytes per lane); pending sources read fp32 slices, 16 B per lane per slice at width 4
+int pick_vec(int cpg, int HW, bool pending) {
+  const int cand[4] = {8, 4, 2, 1};
+  int best = 1;
+  for (int k = 0; k < 4; ++k) {
+    const int v = cand[k];
+    if (cpg % v) continue;
+    if (pending && v == 8 && cpg % 4 == 0) continue;
+    best = v;
+    if ((long long)HW * (cpg / v) >= 1024 || v <= 2) break;
+  }
+  return best;
+}
+int pick_threads(int nunits) { return nunits >= 1024 ? 1024 : (nunits <= 256 ? 256 : (nunits + 63) / 64 * 64); }
+// workgroups per (image, group): as many as keep the whole grid resident at once (the rendezvous spins) and leave a part
+// at least `min_pixels` pixels made of whole units of `unit` pixels (a row pair when the kernel pools)
+int pick_parts(int N, int HW, int cpg, int unit, bool have_rec) {
+  static const int maxp = [] { const char* e = getenv("ISHAP_GN_PARTS"); return e ? atoi(e) : 8; }();
+  static const int min_el = [] { const char* e = getenv("ISHAP_GN_PART_ELEMS"); return e ? atoi(e) : 256; }();
+  if (!have_rec) return 1;
+  // the rendezvous costs ~3 atomic round trips (3-4 us), yet more, smaller parts still win down to a few hundred elements
+  // per workgroup (in-situ sweep: 0.2445 / 0.2464 / 0.2500 / 0.2574 s per edit at >= 256 / 1024 / 2048 / 4096 elements)
+  int p = 1;
+  while (p * 2 <= maxp && 32 * N * (p * 2) <= 256 && HW % (p * 2) == 0 && (HW / (p * 2)) % unit == 0 &&
+         (long long)(HW / (p * 2)) * cpg >= min_el)
+    p *= 2;
+  return p;
+}
 constexpr size_t LOCAL_LDS_CAP = 160 * 1024 - 256;
 
 template <typename K>
@@ -357,15 +440,18 @@ int gn_local_launch(const GnLocalArgs& a, hipStream_t s) {
   ISHAP_REQUIRE(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0 && !a.film), "pool variant");
   const int HW = a.H * a.W, cpg = a.C / 32;
   ISHAP_REQUIRE(gn_local_fits(HW, a.C), "group does not fit in LDS");
-  const int VEC = pick_vec(cpg);
-  const int T = pick_threads(HW * (cpg / VEC));
-  const size_t smem = 256 + (size_t)HW * cpg * sizeof(half_t);
-  dim3 grid(32, a.N), blk(T);
+  GnLocalArgs b = a;
+  b.parts = pick_parts(a.N, HW, cpg, a.pool ? 2 * a.W : 1, a.rec != nullptr);
+  const int PP = HW / b.parts;
+  const int VEC = pick_vec(cpg, PP, a.slab.pending());
+  const int T = pick_threads(PP * (cpg / VEC));
+  const size_t smem = 256 + (size_t)PP * cpg * sizeof(half_t);
+  dim3 grid(32 * b.parts, a.N), blk(T);
 #define GL_LAUNCH(V, F, A, P)                                                            \
   do {                                                                                   \
     auto kern = gn_local_kernel<V, F, A, P>;                                             \
     ISHAP_TRY(set_lds(kern, smem));                                                      \
-    hipLaunchKernelGGL(kern, grid, blk, smem, s, a);                                     \
+    hipLaunchKernelGGL(kern, grid, blk, smem, s, b);                                     \
   } while (0)
 #define GL_VARIANT(V)                                                                    \
   do {                                                                                   \
@@ -395,16 +481,19 @@ int gn_bwd_local_launch(const GnBwdLocalArgs& a, hipStream_t s) {
   ISHAP_REQUIRE(!a.film || a.act, "FiLM is followed by SiLU");
   const int HW = a.H * a.W, cpg = a.C / 32;
   const bool s32 = a.gmode != GB_SAME;      // 0.25 * fp16 and sums of four fp16 values are kept in fp32 between the passes
-  const size_t smem = 256 + (size_t)HW * cpg * (s32 ? sizeof(float) : sizeof(half_t));
+  GnBwdLocalArgs b = a;
+  b.parts = pick_parts(a.N, HW, cpg, 1, a.rec != nullptr);
+  const int PP = HW / b.parts;
+  const size_t smem = 256 + (size_t)PP * cpg * (s32 ? sizeof(float) : sizeof(half_t));
   ISHAP_REQUIRE(smem <= LOCAL_LDS_CAP + 256, "group does not fit in LDS");
-  const int VEC = pick_vec(cpg);
-  const int T = pick_threads(HW * (cpg / VEC));
-  dim3 grid(32, a.N), blk(T);
+  const int VEC = pick_vec(cpg, PP, a.slab.pending());
+  const int T = pick_threads(PP * (cpg / VEC));
+  dim3 grid(32 * b.parts, a.N), blk(T);
 #define GB_LAUNCH(V, F, A, S32)                                                          \
   do {                                                                                   \
     auto kern = gn_bwd_local_kernel<V, F, A, S32>;                                       \
     ISHAP_TRY(set_lds(kern, smem));                                                      \
-    hipLaunchKernelGGL(kern, grid, blk, smem, s, a);                                     \
+    hipLaunchKernelGGL(kern, grid, blk, smem, s, b);                                     \
   } while (0)
 #define GB_VARIANT(V)                                                                    \
   do {                                                                                   \

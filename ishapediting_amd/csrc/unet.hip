@@ -261,7 +261,7 @@ long long* salloc(Exec& e, size_t count) {
 
 bool small_map(int HW) {
   static const int on = [] { const char* v = getenv("ISHAP_LOCAL_GN"); return v ? atoi(v) : 1; }();
-  return on && HW <= 1024;
+  return on && HW <= (on == 2 ? 64 : 1024);      // 2: only the 8x8 maps
 }
 bool local_gn(int HW, int C) { return small_map(HW) && gn_local_fits(HW, C); }
 
@@ -285,6 +285,7 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
   a.flops_scale = (Wt == e.u->head.w) ? 1.f / 3.f : 1.f;
   a.ksplit = igemm_pick_ksplit(a.M, a.N, a.K, 1);
   if (!a.conv3 && a.M <= 64 && a.K % 64 == 0) a.ksplit = 1;   // 1x1 GEMMs on the 8x8 maps: the one-launch small-map kernel (10.7 vs 16.2 us at K = 3072)
+  if (igemm_small3_wanted(a)) a.ksplit = pend_out ? igemm_small3_slices(a) : 1;   // 3x3 on maps <= 32x32: igemm_small3.hip, K sliced over workgroups only when the consumer adds slices up
   if (pend_out) *pend_out = SlabSrc{};
   if (pend_out && a.ksplit > 1) {
     // the consumer adds the slices up itself: they live in the arena until it has run
@@ -346,6 +347,9 @@ static int gn_local_op(Exec& e, Tensor& x, const NormW& nw, half_t* out, half_t*
   x.cat_pend = SlabSrc{};
   g.out = out; g.xpool = xpool; g.stats_out = stats_out; g.gamma = nw.gamma; g.beta = nw.beta; g.emb = emb; g.emb_ld = emb_ld;
   g.N = x.N; g.H = x.H; g.W = x.W; g.C = x.C; g.film = film; g.act = act; g.pool = pool;
+  long long* rec = nullptr;
+  ISHAP_SALLOC(rec, e, (size_t)x.N * 32 * 4);        // zeroed with the statistics arena at the start of the forward
+  g.rec = reinterpret_cast<unsigned long long*>(rec);
   if (e.dry) return 0;
   return gn_local_launch(g, e.s);
 }

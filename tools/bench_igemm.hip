@@ -7,6 +7,7 @@
 #include "../ishapediting_amd/csrc/igemm2.hip"
 #include "../ishapediting_amd/csrc/igemm3.hip"
 #include "../ishapediting_amd/csrc/igemm_skinny.hip"
+#include "../ishapediting_amd/csrc/igemm_small3.hip"
 hipEvent_t g_igemm_prof_start = nullptr, g_igemm_prof_stop = nullptr;
 void ishap_set_error(const std::string& m) { fprintf(stderr, "ERR %s\n", m.c_str()); }
 
@@ -15,15 +16,17 @@ int main(int argc, char** argv) {
   int big = argc > 4 ? atoi(argv[4]) : 1, ksplit = argc > 5 ? atoi(argv[5]) : 1, gen = argc > 6 ? atoi(argv[6]) : 2;
   int ksize = argc > 7 ? atoi(argv[7]) : 3;
   int stats = argc > 8 ? atoi(argv[8]) : 0;      // 1: accumulate the per-channel GroupNorm statistics in the epilogue
+  int nbuf = argc > 9 ? atoi(argv[9]) : 1;       // weight copies cycled through (> 256 MB in total = HBM-cold weights, as in the network)
   int M = H * H, K = ksize * ksize * Cin;
   half_t *X, *W, *O; float* ws;
-  hipMalloc(&X, (size_t)M * Cin * 2); hipMalloc(&W, (size_t)((Cout + 127) / 128 * 128) * K * 2); hipMalloc(&O, (size_t)M * Cout * 2);
+  const size_t wel = (size_t)((Cout + 127) / 128 * 128) * K;
+  hipMalloc(&X, (size_t)M * Cin * 2); hipMalloc(&W, wel * 2 * nbuf); hipMalloc(&O, (size_t)M * Cout * 2);
   hipMalloc(&ws, (size_t)ksplit * M * Cout * 4);
   std::vector<half_t> hx((size_t)M * Cin), hw((size_t)((Cout + 127) / 128 * 128) * K);
   for (auto& v : hx) v = (half_t)((rand() % 2001 - 1000) / 1000.f);
   for (auto& v : hw) v = (half_t)((rand() % 2001 - 1000) / 20000.f);
   hipMemcpy(X, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
-  hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+  for (int b = 0; b < nbuf; ++b) hipMemcpy(W + b * wel, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
   IgemmArgs a;
   a.X = X; a.Wt = W; a.out = O; a.M = M; a.N = Cout; a.K = K; a.conv3 = ksize == 3; a.Cin = Cin; a.ldx = Cin; a.ldw = K; a.ldo = Cout;
   a.H = H; a.W = H; a.ksplit = ksplit; a.ws = ws;
@@ -31,23 +34,31 @@ int main(int argc, char** argv) {
   if (stats) { hipMalloc(&st, (size_t)Cout * 2 * 8); hipMemset(st, 0, (size_t)Cout * 2 * 8); a.stat_out = st; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int mt = ksplit;                          // gen 4 (skinny kernel): argument 5 is MT (pixels per workgroup / 16)
-  if (gen == 4) { a.ksplit = 1; }
+  if (gen == 4 || gen == 5) { a.ksplit = 1; }
+  int turn = 0;
   auto run = [&]() {
-    if (gen == 4) igemm_skinny_launch(a, mt, 0);
+    a.Wt = W + (size_t)(turn++ % nbuf) * wel;
+    if (gen == 5) { IgemmArgs b = a; b.ksplit = ksplit; b.ws = ws; igemm_small3_launch(b, 0, 0); }
+    else if (gen == 4) igemm_skinny_launch(a, mt, 0);
     else if (gen == 3 && igemm3_applicable(a, big)) igemm3_launch_main(a, big, 0);
     else igemm2_launch_main(a, big, 0);
   };
-  if (gen == 4) {                                 // check against the tiled kernel
+  if (gen == 4 || gen == 5) {                     // check against the tiled kernel
     half_t* O1; hipMalloc(&O1, (size_t)M * Cout * 2);
-    IgemmArgs b = a; b.out = O1; b.stat_out = nullptr;
+    IgemmArgs b = a; b.out = O1; b.stat_out = nullptr; b.ksplit = 1;
     igemm2_launch_main(b, 0, 0);
     run();
     std::vector<half_t> o((size_t)M * Cout), o1((size_t)M * Cout);
     hipMemcpy(o.data(), O, o.size() * 2, hipMemcpyDeviceToHost);
     hipMemcpy(o1.data(), O1, o1.size() * 2, hipMemcpyDeviceToHost);
+    if (gen == 5 && ksplit > 1) {                 // partial tiles: add the slices up on the host
+      std::vector<float> sl((size_t)ksplit * M * Cout);
+      hipMemcpy(sl.data(), ws, sl.size() * 4, hipMemcpyDeviceToHost);
+      for (size_t i = 0; i < o.size(); ++i) { float v = 0; for (int z = 0; z < ksplit; ++z) v += sl[(size_t)z * M * Cout + i]; o[i] = (half_t)v; }
+    }
     double md = 0, mx = 0;
     for (size_t i = 0; i < o.size(); ++i) { md = fmax(md, fabs((double)o[i] - (double)o1[i])); mx = fmax(mx, fabs((double)o1[i])); }
-    printf("skinny vs tiled: max |diff| %.4g of max |out| %.4g\n", md, mx);
+    printf("one-launch vs tiled: max |diff| %.4g of max |out| %.4g\n", md, mx);
   }
   for (int i = 0; i < 5; ++i) run();
   hipDeviceSynchronize();
