@@ -182,17 +182,24 @@ int ishap_x0_grad_to_cotangent(const float* dplanes, const float* range, const f
 /* ------------------------------------------------------------------ surface of the decoded volume
  * Replaces the third-party CPU calls after the decode: mcubes.marching_cubes(volume, 0) (visualize.py:100),
  * mesh.filter_smooth_simple(10) (drag_utils.py:300) and the nearest-neighbour part of meshProcess.py:18-35.
- * The surface is extracted with marching tetrahedra (6 per cell, shared vertices on grid edges at the linear zero
- * crossing, grid coordinates, deterministic voxel order).  volume: device float[res^3], x slowest.
+ * `method` 1 = MARCHING CUBES (what the reference calls): one vertex per sign-changing grid edge at the linear zero crossing,
+ * shared by the cells around the edge (so the vertex count is the marching-cubes vertex count), triangles from a 256-case
+ * table derived by tools/make_mc_table.py (PyMCubes' own table is not available here: triangle-level parity unpinned).
+ * `method` 0 = marching tetrahedra (6 per cell; extra vertices on face / body diagonals).  Grid coordinates,
+ * deterministic voxel order.  volume: device float[res^3], x slowest.
  * Two calls because the caller allocates the outputs: count -> read counts -> emit. */
 long long ishap_surface_scratch_bytes(int res);
 /* counts: device unsigned[2] = {vertices, triangles} */
-int ishap_surface_count(const float* volume, int res, float level, void* scratch, unsigned* counts, void* stream);
-/* verts: device float[3*vertices]; tris: device int[3*triangles]; same volume / level / scratch as the count call */
-int ishap_surface_emit(const float* volume, int res, float level, void* scratch, float* verts, int* tris, void* stream);
-/* in place: v <- (v + sum of neighbours) / (1 + number of neighbours), `iterations` Jacobi sweeps; scratch: 28*nverts bytes */
-int ishap_mesh_smooth(float* verts, long long nverts, const int* tris, long long ntris, int iterations, void* scratch,
-                      void* stream);
+int ishap_surface_count(const float* volume, int res, float level, int method, void* scratch, unsigned* counts, void* stream);
+/* verts: device float[3*vertices]; tris: device int[3*triangles]; same volume / level / method / scratch as the count call */
+int ishap_surface_emit(const float* volume, int res, float level, int method, void* scratch, float* verts, int* tris,
+                       void* stream);
+/* in place: v <- (v + sum of neighbours) / (1 + number of neighbours), `iterations` Jacobi sweeps (each neighbour once:
+ * Open3D's filter_smooth_simple).  box_max > 0: the vertices are in grid coordinates of a [0, box_max]^3 volume and the
+ * mesh may be open where the surface leaves the box (edges lying in a box face belong to one triangle); box_max <= 0: the
+ * mesh is closed.  scratch: 32*nverts bytes */
+int ishap_mesh_smooth(float* verts, long long nverts, const int* tris, long long ntris, int iterations, float box_max,
+                      void* scratch, void* stream);
 /* out2[0] = mean over a of min_b |a-b|^2, out2[1] = mean over b of min_a |a-b|^2 (device floats; their sum is the
  * reference's chamfer distance); nearest: device scratch float[max(na, nb)] */
 int ishap_chamfer(const float* a, long long na, const float* b, long long nb, float* nearest, float* out2, void* stream);

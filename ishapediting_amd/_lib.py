@@ -76,9 +76,9 @@ SYMBOLS = {
     "ishap_triplane_decode_points": (C.c_int, [c_void_p, C.c_int, C.POINTER(DecoderWeightsC), c_void_p, C.c_longlong,
                                                c_void_p, c_void_p]),
     "ishap_surface_scratch_bytes": (C.c_longlong, [C.c_int]),
-    "ishap_surface_count": (C.c_int, [c_void_p, C.c_int, C.c_float, c_void_p, c_void_p, c_void_p]),
-    "ishap_surface_emit": (C.c_int, [c_void_p, C.c_int, C.c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ishap_mesh_smooth": (C.c_int, [c_void_p, C.c_longlong, c_void_p, C.c_longlong, C.c_int, c_void_p, c_void_p]),
+    "ishap_surface_count": (C.c_int, [c_void_p, C.c_int, C.c_float, C.c_int, c_void_p, c_void_p, c_void_p]),
+    "ishap_surface_emit": (C.c_int, [c_void_p, C.c_int, C.c_float, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ishap_mesh_smooth": (C.c_int, [c_void_p, C.c_longlong, c_void_p, C.c_longlong, C.c_int, C.c_float, c_void_p, c_void_p]),
     "ishap_chamfer": (C.c_int, [c_void_p, C.c_longlong, c_void_p, C.c_longlong, c_void_p, c_void_p, c_void_p]),
     "ishap_mesh_tri_areas": (C.c_int, [c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
     "ishap_mesh_points_on_tris": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),

@@ -12,6 +12,7 @@
 //   emit  : vertices (block-local scan + block offset), per-voxel vertex offsets, then triangles through the
 //           (owner voxel, edge type) -> vertex index lookup.
 #include "common.h"
+#include "mc_table.h"
 
 namespace {
 
@@ -39,6 +40,7 @@ struct SurfArgs {
   unsigned* bsum;           // [2][nblocks] per-block (vertices, triangles) -> exclusive prefix after the scan
   unsigned* counts;         // [2] totals
   int nblocks;
+  int method;               // 0: marching tetrahedra (7 edge types per voxel), 1: marching cubes (the 3 axis edges, 256-case table)
 };
 
 // inside bits of the 8 corners of the cell at (x, y, z); corners outside the grid read as "same as the voxel itself",
@@ -106,7 +108,8 @@ __global__ __launch_bounds__(SB_THREADS) void surf_count_kernel(SurfArgs a) {
     unsigned m = 0;
 #pragma unroll
     for (int d = 1; d < 8; ++d) m |= ((((bits >> d) & 1u) ^ in0) & 1u) << (d - 1);   // out-of-grid corners equal in0: never cross
-    const int tc = cell ? cell_triangles(bits) : 0;
+    if (a.method == 1) m &= 0x0Bu;                                                    // marching cubes: only the axis edges d = 1, 2, 4
+    const int tc = !cell ? 0 : (a.method == 1 ? (int)c_mc_ntri[bits] : cell_triangles(bits));
     a.emask[p] = (unsigned char)m;
     a.tcnt[p] = (unsigned char)tc;
     nv += __popc(m);
@@ -197,6 +200,23 @@ __global__ __launch_bounds__(SB_THREADS) void surf_emit_triangles_kernel(SurfArg
     const int z = (int)(p % r), y = (int)((p / r) % r), x = (int)(p / ((long long)r * r));
     bool cell;
     const unsigned bits = corner_bits(a, x, y, z, cell);
+    if (a.method == 1) {
+      // marching cubes: each table entry names a cube edge = (lower corner, axis); its vertex is owned by that corner's
+      // voxel under direction bit d = 1 << axis
+      const int ntri = c_mc_ntri[bits];
+      for (int tr = 0; tr < ntri; ++tr) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int e = c_mc_tri[bits][3 * tr + c];
+          const unsigned lo = c_mc_edge_lo[e], d = 1u << (e >> 2);
+          const long long owner = p + ((long long)(lo & 1) * r + ((lo >> 1) & 1)) * r + ((lo >> 2) & 1);
+          const unsigned below = (unsigned)a.emask[owner] & ((1u << (d - 1)) - 1u);
+          tris[3LL * idx + c] = (int)(a.voff[owner] + __popc(below));
+        }
+        ++idx;
+      }
+      continue;
+    }
     for (int k = 0; k < 6; ++k) {
       unsigned code = 0;
 #pragma unroll
@@ -225,23 +245,44 @@ __global__ __launch_bounds__(SB_THREADS) void surf_emit_triangles_kernel(SurfArg
 // Accumulation in 64-bit fixed point keeps the result independent of the atomic order.
 constexpr float SMOOTH_SCALE = 1048576.f;     // 2^20: coordinates < 2^11, valence sums < 2^20 -> < 2^51
 
+// which of the six faces of the grid box [0, bmax]^3 a vertex lies on (bit 2*axis: coordinate 0, bit 2*axis+1: bmax)
+__global__ void smooth_boundary_mask_kernel(const float* __restrict__ v, long long nverts, float bmax, unsigned* __restrict__ mask) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nverts) return;
+  unsigned m = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float x = v[3 * i + c];
+    m |= (x <= 0.f ? 1u : 0u) << (2 * c);
+    m |= (x >= bmax ? 1u : 0u) << (2 * c + 1);
+  }
+  mask[i] = m;
+}
+// An edge of a level-set mesh that lies IN a face of the grid box belongs to one triangle only (there is no cell on the
+// other side), every other edge to two; the lone occurrence of a boundary edge therefore counts double, so that after the
+// halving in smooth_apply each neighbour has weight one -- Open3D's unique-adjacency rule -- on open meshes too.
 __global__ void smooth_accumulate_kernel(const float* __restrict__ v, const int* __restrict__ tris, long long ntris,
-                                         long long* __restrict__ acc, unsigned* __restrict__ cnt) {
+                                         long long* __restrict__ acc, unsigned* __restrict__ cnt, const unsigned* __restrict__ bmask) {
   const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= ntris) return;
   const int i[3] = {tris[3 * f], tris[3 * f + 1], tris[3 * f + 2]};
+  unsigned bm[3] = {0u, 0u, 0u};
+  if (bmask) { bm[0] = bmask[i[0]]; bm[1] = bmask[i[1]]; bm[2] = bmask[i[2]]; }
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
     const int tail = i[e];
+    unsigned n = 0;
 #pragma unroll
     for (int o = 1; o < 3; ++o) {
       const int head = i[(e + o) % 3];
+      const float w = (bm[e] & bm[(e + o) % 3]) ? 2.f : 1.f;
+      n += (bm[e] & bm[(e + o) % 3]) ? 2u : 1u;
 #pragma unroll
       for (int c = 0; c < 3; ++c)
         atomicAdd(reinterpret_cast<unsigned long long*>(acc + 3LL * tail + c),
-                  (unsigned long long)__float2ll_rn(v[3LL * head + c] * SMOOTH_SCALE));
+                  (unsigned long long)__float2ll_rn(v[3LL * head + c] * (w * SMOOTH_SCALE)));
     }
-    atomicAdd(cnt + tail, 2u);
+    atomicAdd(cnt + tail, n);
   }
 }
 __global__ void smooth_apply_kernel(float* __restrict__ v, long long nverts, long long* __restrict__ acc, unsigned* __restrict__ cnt) {
@@ -367,6 +408,7 @@ int fill(SurfArgs& a, const float* volume, int res, float level, void* scratch, 
   a.emask = (unsigned char*)s;         s += a.n;
   a.tcnt = (unsigned char*)s;
   a.counts = counts;
+  a.method = 0;
   return 0;
 }
 
@@ -378,10 +420,12 @@ extern "C" long long ishap_surface_scratch_bytes(int res) {
   return n * 6 + 2 * nb * 4 + 256;
 }
 
-extern "C" int ishap_surface_count(const float* volume, int res, float level, void* scratch, unsigned* counts, void* stream) {
+extern "C" int ishap_surface_count(const float* volume, int res, float level, int method, void* scratch, unsigned* counts,
+                                   void* stream) {
   SurfArgs a;
   ISHAP_TRY(fill(a, volume, res, level, scratch, counts));
-  ISHAP_REQUIRE(counts, "null argument");
+  ISHAP_REQUIRE(counts && (method == 0 || method == 1), "method: 0 marching tetrahedra, 1 marching cubes");
+  a.method = method;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(surf_count_kernel, dim3(a.nblocks), dim3(SB_THREADS), 0, s, a);
   hipLaunchKernelGGL(surf_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, a);
@@ -389,10 +433,12 @@ extern "C" int ishap_surface_count(const float* volume, int res, float level, vo
   return 0;
 }
 
-extern "C" int ishap_surface_emit(const float* volume, int res, float level, void* scratch, float* verts, int* tris, void* stream) {
+extern "C" int ishap_surface_emit(const float* volume, int res, float level, int method, void* scratch, float* verts, int* tris,
+                                  void* stream) {
   SurfArgs a;
   ISHAP_TRY(fill(a, volume, res, level, scratch, nullptr));
-  ISHAP_REQUIRE(verts && tris, "null argument");
+  ISHAP_REQUIRE(verts && tris && (method == 0 || method == 1), "null argument / method");
+  a.method = method;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(surf_emit_vertices_kernel, dim3(a.nblocks), dim3(SB_THREADS), 0, s, a, verts);
   hipLaunchKernelGGL(surf_emit_triangles_kernel, dim3(a.nblocks), dim3(SB_THREADS), 0, s, a, tris);
@@ -400,16 +446,18 @@ extern "C" int ishap_surface_emit(const float* volume, int res, float level, voi
   return 0;
 }
 
-extern "C" int ishap_mesh_smooth(float* verts, long long nverts, const int* tris, long long ntris, int iterations, void* scratch,
-                                 void* stream) {
+extern "C" int ishap_mesh_smooth(float* verts, long long nverts, const int* tris, long long ntris, int iterations, float box_max,
+                                 void* scratch, void* stream) {
   ISHAP_REQUIRE(verts && tris && scratch && nverts >= 0 && ntris >= 0 && iterations >= 0, "mesh_smooth arguments");
   if (nverts == 0 || ntris == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   long long* acc = (long long*)scratch;
   unsigned* cnt = (unsigned*)(acc + 3 * nverts);
+  unsigned* bmask = box_max > 0.f ? cnt + nverts : nullptr;
   ISHAP_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)nverts * 28, s));
+  if (bmask) hipLaunchKernelGGL(smooth_boundary_mask_kernel, dim3((unsigned)((nverts + 255) / 256)), dim3(256), 0, s, verts, nverts, box_max, bmask);
   for (int it = 0; it < iterations; ++it) {
-    hipLaunchKernelGGL(smooth_accumulate_kernel, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, s, verts, tris, ntris, acc, cnt);
+    hipLaunchKernelGGL(smooth_accumulate_kernel, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, s, verts, tris, ntris, acc, cnt, bmask);
     hipLaunchKernelGGL(smooth_apply_kernel, dim3((unsigned)((nverts + 255) / 256)), dim3(256), 0, s, verts, nverts, acc, cnt);
   }
   ISHAP_CHECK_HIP(hipGetLastError());

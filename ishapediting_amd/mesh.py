@@ -1,10 +1,11 @@
 """Mesh side of get_mesh (reference: triplane_decoder/visualize.py:100-104 = PyMCubes marching cubes at level 0 +
 vertices/res*2-1; drag_utils.py:300 = Open3D filter_smooth_simple(10); meshProcess.py:18-35 = Chamfer distance).
 
-Those are third-party CPU calls outside the kernel path.  When PyMCubes and Open3D are
-importable the reference's exact calls are used.  Otherwise the surface is produced ON THE DEVICE by
-csrc/surface.hip (marching tetrahedra on the resident volume, smoothing, nearest-neighbour Chamfer) through the C ABI
-(ishap_surface_count / _emit, ishap_mesh_smooth, ishap_chamfer); this module only allocates the outputs.
+Those are third-party CPU calls outside the kernel path.  Here the surface is produced ON THE
+DEVICE by csrc/surface.hip (marching cubes on the resident volume, smoothing, nearest-neighbour Chamfer on area-uniform
+surface samples) through the C ABI (ishap_surface_count / _emit, ishap_mesh_smooth, ishap_chamfer); this module only
+allocates the outputs.  The backend is an explicit choice, never an import probe: BACKEND = "device" (default) or
+"third_party" (the reference's own PyMCubes / Open3D calls on the host, for users who have them and want that exact mesh).
 """
 from __future__ import annotations
 
@@ -17,6 +18,8 @@ from . import _lib
 
 
 MAX_OBJ_VERTICES = 4_000_000      # text export limit (a 256^3 shape has well under a million surface vertices)
+BACKEND = "device"                # "device" | "third_party"; set explicitly, results never depend on what happens to be installed
+METHODS = {"marching_tetrahedra": 0, "marching_cubes": 1}
 
 
 def _need_gpu(t: torch.Tensor, what: str):
@@ -24,9 +27,11 @@ def _need_gpu(t: torch.Tensor, what: str):
         raise RuntimeError(f"{what} runs on the GPU (libishap_hip.so); there is no CPU fallback")
 
 
-def extract_surface(volume: torch.Tensor, level: float = 0.0):
+def extract_surface(volume: torch.Tensor, level: float = 0.0, method: str = "marching_cubes"):
     """Level-`level` triangle mesh of a [res,res,res] volume: (vertices [V,3] float32 in grid coordinates,
-    triangles [F,3] int32), both on the device, in voxel order (deterministic)."""
+    triangles [F,3] int32), both on the device, in voxel order (deterministic).  method: "marching_cubes" (what the
+    reference calls, visualize.py:100) or "marching_tetrahedra"."""
+    meth = METHODS[method]
     _need_gpu(volume, "extract_surface")
     assert volume.dim() == 3 and volume.shape[0] == volume.shape[1] == volume.shape[2]
     res = volume.shape[0]
@@ -37,18 +42,19 @@ def extract_surface(volume: torch.Tensor, level: float = 0.0):
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         s = _lib.stream_ptr(dev)
-        _lib.check(L.ishap_surface_count(vol.data_ptr(), res, float(level), scratch.data_ptr(), counts.data_ptr(), s))
+        _lib.check(L.ishap_surface_count(vol.data_ptr(), res, float(level), meth, scratch.data_ptr(), counts.data_ptr(), s))
         nv, nt = (int(c) for c in counts.tolist())                 # the one host read-back: output sizes
         verts = torch.empty((nv, 3), dtype=torch.float32, device=dev)
         tris = torch.empty((nt, 3), dtype=torch.int32, device=dev)
         if nv and nt:
-            _lib.check(L.ishap_surface_emit(vol.data_ptr(), res, float(level), scratch.data_ptr(), verts.data_ptr(),
+            _lib.check(L.ishap_surface_emit(vol.data_ptr(), res, float(level), meth, scratch.data_ptr(), verts.data_ptr(),
                                             tris.data_ptr(), s))
     return verts, tris
 
 
-def surface_counts(volume: torch.Tensor, level: float = 0.0):
+def surface_counts(volume: torch.Tensor, level: float = 0.0, method: str = "marching_cubes"):
     """(vertices, triangles) of the level surface without emitting it."""
+    meth = METHODS[method]
     _need_gpu(volume, "surface_counts")
     res = volume.shape[0]
     dev = volume.device
@@ -57,23 +63,24 @@ def surface_counts(volume: torch.Tensor, level: float = 0.0):
     scratch = torch.empty(int(L.ishap_surface_scratch_bytes(res)), dtype=torch.uint8, device=dev)
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(L.ishap_surface_count(vol.data_ptr(), res, float(level), scratch.data_ptr(), counts.data_ptr(),
+        _lib.check(L.ishap_surface_count(vol.data_ptr(), res, float(level), meth, scratch.data_ptr(), counts.data_ptr(),
                                          _lib.stream_ptr(dev)))
     nv, nt = counts.tolist()
     return int(nv), int(nt)
 
 
-def smooth_mesh(verts: torch.Tensor, tris: torch.Tensor, iterations: int = 10) -> torch.Tensor:
-    """filter_smooth_simple (drag_utils.py:300) on the device; returns new vertex positions."""
+def smooth_mesh(verts: torch.Tensor, tris: torch.Tensor, iterations: int = 10, box_max: float = 0.0) -> torch.Tensor:
+    """filter_smooth_simple (drag_utils.py:300) on the device; returns new vertex positions.  box_max > 0: `verts` are grid
+    coordinates of a [0, box_max]^3 volume whose surface may be cut open by the box (each neighbour still counts once)."""
     _need_gpu(verts, "smooth_mesh")
     out = verts.detach().to(torch.float32).contiguous().clone()
     tris = tris.detach().to(torch.int32).contiguous()
     if out.shape[0] == 0 or tris.shape[0] == 0 or iterations <= 0:
         return out
-    scratch = torch.empty(out.shape[0] * 28, dtype=torch.uint8, device=out.device)
+    scratch = torch.empty(out.shape[0] * 32, dtype=torch.uint8, device=out.device)
     with torch.cuda.device(out.device):
         _lib.check(_lib.lib().ishap_mesh_smooth(out.data_ptr(), out.shape[0], tris.data_ptr(), tris.shape[0], int(iterations),
-                                                scratch.data_ptr(), _lib.stream_ptr(out.device)))
+                                                float(box_max), scratch.data_ptr(), _lib.stream_ptr(out.device)))
     return out
 
 
@@ -101,6 +108,19 @@ def chamfer_distance(pa: torch.Tensor, pb: torch.Tensor, point_num=20000, seed: 
     return float(d[0] + d[1])
 
 
+def mesh_chamfer(mesh_a, mesh_b, point_num: int = 20000, seed: int = 0) -> float:
+    """calc_chamfer (meshProcess.py:18-35): `point_num` points sampled uniformly BY AREA on each surface
+    (sample_points_uniformly), then the two mean squared nearest-neighbour distances.  mesh_*: (vertices, triangles) pairs
+    or OccupancyMesh objects, on the device."""
+    def vt(m):
+        return (m.vertices, m.triangles) if isinstance(m, OccupancyMesh) else m
+    (va, ta), (vb, tb) = vt(mesh_a), vt(mesh_b)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    pa = sample_surface_points(va, ta, point_num, g)
+    pb = sample_surface_points(vb, tb, point_num, g)
+    return chamfer_distance(pa, pb, point_num=None)
+
+
 class OccupancyMesh:
     """The mesh get_mesh returns when PyMCubes/Open3D are absent: the device volume plus, on first use, its surface
     (vertices in the reference's convention grid/res*2-1, visualize.py:101) after `smooth_iterations` sweeps."""
@@ -114,8 +134,8 @@ class OccupancyMesh:
     def _build(self):
         if self._mesh is None:
             v, t = extract_surface(self.volume, 0.0)
-            v = v / self.res * 2 - 1
-            self._mesh = (smooth_mesh(v, t, self.smooth_iterations), t)
+            v = smooth_mesh(v, t, self.smooth_iterations, box_max=float(self.res - 1))     # in grid coordinates: the box is known
+            self._mesh = (v / self.res * 2 - 1, t)
         return self._mesh
 
     @property
@@ -136,12 +156,15 @@ class OccupancyMesh:
         return m
 
 
-def volume_to_mesh(volume: torch.Tensor, res: int, smooth_iterations: int = 10):
-    try:
-        import mcubes           # noqa: F401
-        import open3d as o3d    # noqa: F401
-    except Exception:
+def volume_to_mesh(volume: torch.Tensor, res: int, smooth_iterations: int = 10, backend: str = None):
+    """get_mesh's mesh (drag_utils.py:298-300).  backend None -> the module-level BACKEND."""
+    backend = BACKEND if backend is None else backend
+    if backend == "device":
         return OccupancyMesh(volume, res, smooth_iterations)
+    if backend != "third_party":
+        raise ValueError(f"unknown mesh backend {backend!r}")
+    import mcubes
+    import open3d as o3d
     vertices, triangles = mcubes.marching_cubes(volume.detach().cpu().numpy(), 0)
     vertices = vertices / res * 2 - 1                      # visualize.py:101 (create_obj_o3d's own convention)
     mesh = o3d.geometry.TriangleMesh()
@@ -225,15 +248,14 @@ def sample_surface_points(verts: torch.Tensor, tris: torch.Tensor, n: int, gener
 
 def sample_occupancy(mesh, mesh_path, center_mesh, points_size, uniform_ratio, device=None, generator=None):
     """drag_utils.py:411-440: `points_size` samples (a `uniform_ratio` share uniform in [-1,1]^3, the rest on the surface
-    plus N(0, 0.01) noise) with their occupancy.  Open3D (RaycastingScene) when importable, exactly as the reference;
-    otherwise the mesh (an OBJ file, or a (vertices, triangles) pair) is sampled on the device.
+    plus N(0, 0.01) noise) with their occupancy.  BACKEND "third_party": Open3D (RaycastingScene) exactly as the
+    reference; "device" (default): the mesh (an OBJ file, or a (vertices, triangles) pair) is sampled on the device.
     Returns (None, None) when no mesh is given."""
     if mesh is None and mesh_path is None:
         return None, None
-    try:
+    o3d = None
+    if BACKEND == "third_party":
         import open3d as o3d
-    except ImportError:
-        o3d = None
     if o3d is not None and not isinstance(mesh, tuple):
         if mesh is None:
             mesh = o3d.io.read_triangle_mesh(mesh_path)
@@ -277,17 +299,15 @@ def sample_occupancy(mesh, mesh_path, center_mesh, points_size, uniform_ratio, d
     return pts.cpu().numpy(), occ.reshape(-1, 1).cpu().numpy()
 
 
-def export_obj(volume: torch.Tensor, path: str, scale_div: float = 255.0):
-    """visualize.py:71-73 (create_obj): surface at 0, vertices / 255 * 2 - 1, Wavefront OBJ.
-    PyMCubes when importable (the reference's exact call); the device extraction otherwise."""
-    try:
+def export_obj(volume: torch.Tensor, path: str, scale_div: float = 255.0, backend: str = None):
+    """visualize.py:71-73 (create_obj): surface at 0, vertices / 255 * 2 - 1, Wavefront OBJ."""
+    backend = BACKEND if backend is None else backend
+    if backend == "third_party":
         import mcubes
         vertices, triangles = mcubes.marching_cubes(volume.detach().cpu().numpy(), 0)
         vertices = vertices / scale_div * 2 - 1
         mcubes.export_obj(vertices, triangles, path)
         return
-    except ImportError:
-        pass
     nv, nt = surface_counts(volume, 0.0)
     if nv > MAX_OBJ_VERTICES:                      # not a surface (e.g. random weights decode to noise): do not write GBs of text
         with open(path, "w") as f:

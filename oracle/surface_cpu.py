@@ -117,6 +117,74 @@ def marching_tetrahedra(volume: torch.Tensor, max_cells: int = 4_000_000):
 
 
 
+_MC = None
+
+
+def _mc_tables():
+    """The 256-case table, rebuilt from its derivation (tools/make_mc_table.py: loop tracing on the cube with the
+    'separate the inside corners' face rule).  PyMCubes' own table is not available here (parity unpinned)."""
+    global _MC
+    if _MC is None:
+        import importlib.util
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "make_mc_table.py")
+        spec = importlib.util.spec_from_file_location("make_mc_table", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        table = mod.build()
+        tri = torch.full((256, 15), -1, dtype=torch.long)
+        for b, t in enumerate(table):
+            flat = [e for x in t for e in x]
+            tri[b, :len(flat)] = torch.tensor(flat, dtype=torch.long)
+        ntri = torch.tensor([len(t) for t in table])
+        lo = torch.tensor([e[0] for e in mod.EDGES])
+        axis = torch.tensor([e[2] for e in mod.EDGES])
+        _MC = (tri, ntri, lo, axis)
+    return _MC
+
+
+def marching_cubes(volume: torch.Tensor, level: float = 0.0, max_cells: int = 4_000_000):
+    """visualize.py:100 (`mcubes.marching_cubes(volume, 0)`) restated: one vertex per sign-changing grid edge at the linear
+    crossing, shared by the cells around it; triangles from the 256-case table.  Returns (vertices [V,3] in grid
+    coordinates, faces [F,3]); vertices are ordered by (owner voxel, axis x < y < z) like the device kernel's."""
+    tri, ntri, elo, eaxis = _mc_tables()
+    v = volume.float() - level
+    R = v.shape
+    occ = v > 0
+    code = torch.zeros((R[0] - 1, R[1] - 1, R[2] - 1), dtype=torch.long)
+    for c in range(8):
+        dx, dy, dz = c & 1, (c >> 1) & 1, (c >> 2) & 1
+        code += occ[dx:R[0] - 1 + dx, dy:R[1] - 1 + dy, dz:R[2] - 1 + dz].long() << c
+    cells = ((code > 0) & (code < 255)).nonzero()
+    if cells.shape[0] == 0:
+        return torch.zeros((0, 3)), torch.zeros((0, 3), dtype=torch.long)
+    if cells.shape[0] > max_cells:
+        raise RuntimeError(f"{cells.shape[0]} surface cells: volume is not a surface (noise?)")
+    cc = code[cells[:, 0], cells[:, 1], cells[:, 2]]
+    flat = v.reshape(-1)
+    fe_lo, fe_ax = [], []
+    for k in range(5):
+        m = ntri[cc] > k
+        e = tri[cc[m]][:, 3 * k:3 * k + 3]                                   # [F,3] cube edge ids
+        lo = elo[e]                                                          # lower corner of each edge
+        base = cells[m][:, None, :] + torch.stack([lo & 1, (lo >> 1) & 1, (lo >> 2) & 1], dim=-1)
+        fe_lo.append((base[..., 0] * R[1] + base[..., 1]) * R[2] + base[..., 2])
+        fe_ax.append(eaxis[e])
+    lo_lin = torch.cat(fe_lo).reshape(-1)
+    ax = torch.cat(fe_ax).reshape(-1)
+    key = lo_lin * 3 + ax                                                    # (owner voxel, axis): the device's vertex order
+    uniq, inv = torch.unique(key, return_inverse=True)
+    a = uniq // 3
+    axis = uniq % 3
+    stride = torch.tensor([R[1] * R[2], R[2], 1])[axis]
+    b = a + stride
+    va, vb = flat[a], flat[b]
+    t = va / (va - vb)
+    pos = torch.stack([a // (R[1] * R[2]), (a // R[2]) % R[1], a % R[2]], dim=-1).float()
+    pos[torch.arange(pos.shape[0]), axis] += t
+    return pos, inv.reshape(-1, 3)
+
+
 def smooth_simple(verts: torch.Tensor, faces: torch.Tensor, iterations: int = 10) -> torch.Tensor:
     """Open3D filter_smooth_simple (drag_utils.py:300): v <- (v + sum over adjacent vertices) / (1 + valence), Jacobi
     sweeps, adjacency = the unique vertex pairs of the faces."""

@@ -1,5 +1,5 @@
-"""csrc/surface.hip (marching tetrahedra, smoothing, Chamfer on the device) against the CPU statement of the same
-algorithms in oracle/surface_cpu.py, through the C ABI.  Parity with the reference's third-party calls (PyMCubes /
+"""csrc/surface.hip (marching cubes / marching tetrahedra, smoothing, Chamfer on the device) against the CPU statement of
+the same algorithms in oracle/surface_cpu.py, through the C ABI.  Parity with the reference's third-party calls (PyMCubes /
 Open3D) is unpinned (absent here, versions unpinned upstream); what is pinned is the algorithm stated in the oracle
 plus analytic properties at the full 256^3 size."""
 import numpy as np
@@ -39,19 +39,30 @@ def canon_faces(faces, index_map=None):
     return sorted(out)
 
 
-@pytest.mark.parametrize("case", ["sphere", "field", "empty", "full"])
-def test_surface_matches_cpu_statement(case):
+def torus(res, R, r):
+    ax = torch.arange(res, dtype=torch.float32) - (res - 1) / 2
+    x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    return r - torch.sqrt((torch.sqrt(x * x + y * y) - R) ** 2 + z * z)
+
+
+@pytest.mark.parametrize("method", ["marching_cubes", "marching_tetrahedra"])
+@pytest.mark.parametrize("case", ["sphere", "field", "noise", "empty", "full"])
+def test_surface_matches_cpu_statement(case, method):
     from ishapediting_amd.mesh import extract_surface, surface_counts
     res = 24
     vol = {"sphere": sphere(res, 7.3), "field": smooth_field(res, 3), "empty": -torch.ones((res,) * 3),
-           "full": torch.ones((res,) * 3)}[case]
-    v_d, f_d = extract_surface(vol.to(dev()))
+           "full": torch.ones((res,) * 3),
+           "noise": torch.randn((res,) * 3, generator=torch.Generator().manual_seed(8))}[case]   # every ambiguous case
+    v_d, f_d = extract_surface(vol.to(dev()), method=method)
     if case in ("empty", "full"):
-        assert v_d.shape == (0, 3) and f_d.shape == (0, 3) and surface_counts(vol.to(dev())) == (0, 0)
+        assert v_d.shape == (0, 3) and f_d.shape == (0, 3) and surface_counts(vol.to(dev()), method=method) == (0, 0)
         return
-    v_o, f_o = S.marching_tetrahedra(vol)
+    v_o, f_o = S.marching_cubes(vol) if method == "marching_cubes" else S.marching_tetrahedra(vol)
     assert v_d.shape == v_o.shape and f_d.shape == f_o.shape
-    assert surface_counts(vol.to(dev())) == (v_o.shape[0], f_o.shape[0])
+    assert surface_counts(vol.to(dev()), method=method) == (v_o.shape[0], f_o.shape[0])
+    if method == "marching_cubes":
+        # the quantity north_star names: the marching-cubes vertex count = the sign-changing grid edges
+        assert v_d.shape[0] == S.mc_vertices(vol).shape[0]
     # same vertex set: every device vertex has exactly one oracle vertex within 2e-5 (both are one fp32 interpolation
     # of the same two samples), and the map is a bijection
     d = torch.cdist(v_d.cpu().double(), v_o.double())
@@ -84,15 +95,76 @@ def test_smoothing_and_chamfer_match_cpu_statement():
     assert abs(c_s - S.chamfer_distance(pa.cpu(), pb.cpu(), 2000, seed=4)) <= 1e-5 * max(1.0, c_o)
 
 
+def _closed_and_oriented(v, f):
+    fl = f.long()
+    e = torch.cat([fl[:, [0, 1]], fl[:, [1, 2]], fl[:, [2, 0]]]).sort(dim=1).values
+    _, counts = torch.unique(e[:, 0] * v.shape[0] + e[:, 1], return_counts=True)
+    de = torch.cat([fl[:, [0, 1]], fl[:, [1, 2]], fl[:, [2, 0]]])
+    dkey = de[:, 0] * v.shape[0] + de[:, 1]
+    closed = int(counts.min()) == 2 and int(counts.max()) == 2
+    oriented = torch.unique(dkey).numel() == dkey.numel()
+    return closed, oriented, v.shape[0] - counts.numel() + f.shape[0]
+
+
+def test_marching_cubes_topology_on_analytic_shapes():
+    """The derived 256-case table on shapes of known topology: a sphere (Euler characteristic 2) and a torus (0) come out
+    closed, consistently oriented with outward normals (positive signed volume ~ the analytic volume), and with exactly
+    the marching-cubes vertex count (one vertex per sign-changing grid edge) -- equal to the CPU statement's."""
+    from ishapediting_amd.mesh import extract_surface
+    res = 96
+    for name, vol, chi, volume in (("sphere", sphere(res, 30.3), 2, 4 / 3 * np.pi * 30.3 ** 3),
+                                   ("torus", torus(res, 28.0, 9.4), 0, 2 * np.pi ** 2 * 28.0 * 9.4 ** 2)):
+        v, f = extract_surface(vol.to(dev()))
+        closed, oriented, euler = _closed_and_oriented(v, f)
+        assert closed and oriented and euler == chi, (name, closed, oriented, euler)
+        assert v.shape[0] == S.mc_vertices(vol).shape[0]
+        A, B, Cc = v[f[:, 0].long()].double(), v[f[:, 1].long()].double(), v[f[:, 2].long()].double()
+        signed = float((A * torch.cross(B, Cc, dim=1)).sum() / 6)
+        assert abs(signed - volume) < 0.01 * volume, (name, signed, volume)
+
+
+def test_smoothing_of_an_open_surface_matches_unique_adjacency():
+    """A sphere that leaves the volume is cut open by the box: edges in the box faces belong to one triangle.  The device
+    smoothing (per-face gathering with boundary edges counted double, then halved) must equal Open3D's rule -- every
+    neighbour once -- as stated in oracle/surface_cpu.py:smooth_simple."""
+    from ishapediting_amd.mesh import extract_surface, smooth_mesh
+    res = 32
+    vol = sphere(res, 14.0, centre=8.0)                               # pokes through three faces of the box
+    v, f = extract_surface(vol.to(dev()))
+    closed, _, _ = _closed_and_oriented(v, f)
+    assert not closed
+    sm_d = smooth_mesh(v, f, 10, box_max=float(res - 1))
+    sm_o = S.smooth_simple(v.cpu(), f.cpu().long(), 10)
+    assert float((sm_d.cpu() - sm_o).abs().max()) < 1e-4
+    wrong = smooth_mesh(v, f, 10)                                      # treating it as closed under-weights the rim
+    assert float((wrong.cpu() - sm_o).abs().max()) > 1e-3
+
+
+def test_mesh_chamfer_on_area_uniform_samples():
+    """calc_chamfer (meshProcess.py:18-35) samples the SURFACES uniformly by area.  Two concentric spheres of radii r and
+    r + d: every sample of one lies d from the other surface, so the distance is ~ 2 d^2, while vertex sampling would carry
+    the grid's vertex density pattern."""
+    from ishapediting_amd.mesh import extract_surface, mesh_chamfer
+    res, r, d = 64, 20.0, 1.5
+    a = extract_surface(sphere(res, r).to(dev()))
+    b = extract_surface(sphere(res, r + d).to(dev()))
+    c = mesh_chamfer(a, b, point_num=20000, seed=1)
+    assert abs(c - 2 * d * d) < 0.08 * 2 * d * d, c
+    # two independent samplings of ONE surface: the sampling floor, 2 / (pi * density) for uniform samples
+    floor = 2 * (4 * np.pi * r * r) / (np.pi * 20000)
+    assert abs(mesh_chamfer(a, a, point_num=20000, seed=1) - floor) < 0.15 * floor
+
+
 def test_full_size_surface_is_a_closed_sphere():
     """256^3 (BASELINE's shape_resolution): an off-centre sphere SDF -> every edge lies in exactly two triangles,
-    Euler characteristic 2, vertices on the sphere, and the result is bitwise repeatable."""
+    Euler characteristic 2, vertices on the sphere, the marching-cubes vertex count of the CPU statement, bitwise repeatable."""
     from ishapediting_amd.mesh import extract_surface
     r = 90.4
     vol = sphere(256, r, centre=120.3).to(dev())
     v, f = extract_surface(vol)
     v2, f2 = extract_surface(vol)
     assert torch.equal(v, v2) and torch.equal(f, f2)
+    assert v.shape[0] == S.mc_vertices(vol.cpu()).shape[0]
     rad = torch.linalg.norm(v - 120.3, dim=1)
     assert float((rad - r).abs().max()) < 0.02
     fl = f.long()
@@ -112,7 +184,10 @@ def test_occupancy_mesh_and_obj_export(tmp_path):
     from ishapediting_amd.mesh import OccupancyMesh, export_obj, volume_to_mesh, write_mesh
     vol = sphere(32, 9.3).to(dev())
     m = volume_to_mesh(vol, 32, smooth_iterations=10)
-    if isinstance(m, OccupancyMesh):                                  # PyMCubes/Open3D absent: the device mesh
+    assert isinstance(m, OccupancyMesh)                               # the backend is explicit ("device"), never an import probe
+    with pytest.raises(ValueError):
+        volume_to_mesh(vol, 32, backend="whatever")
+    if True:
         nv, nt = m.counts()
         assert m.vertices.shape == (nv, 3) and m.triangles.shape == (nt, 3)
         assert float(m.vertices.abs().max()) <= 1.0                   # visualize.py:101 convention: grid / res * 2 - 1

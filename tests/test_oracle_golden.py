@@ -277,3 +277,30 @@ def test_generate_path_p_sample_loop(gold, B):
     lo, hi = T(g["lower_bound"]).reshape(1, -1, 1, 1), T(g["upper_bound"]).reshape(1, -1, 1, 1)
     arr = (img * ((hi - lo) / 2) + (lo + hi) / 2).permute(0, 2, 3, 1)
     close(arr, g[f"b{B}_arr"], rtol=1e-3, atol=1e-4)
+
+
+def test_marching_cubes_statement_topology():
+    """The CPU statement of marching cubes (oracle/surface_cpu.py:marching_cubes, table derived in tools/make_mc_table.py):
+    sphere -> Euler characteristic 2, torus -> 0, both closed and consistently oriented with outward normals, vertex count =
+    the number of sign-changing grid edges; a noise volume (every ambiguous face configuration occurs) has no edge shared
+    by more than two triangles."""
+    from oracle.surface_cpu import marching_cubes, mc_vertices
+    res = 32
+    ax = torch.arange(res, dtype=torch.float32) - (res - 1) / 2
+    x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    for vol, chi in ((9.3 - torch.sqrt(x * x + y * y + z * z), 2),
+                     (3.4 - torch.sqrt((torch.sqrt(x * x + y * y) - 9.0) ** 2 + z * z), 0)):
+        v, f = marching_cubes(vol)
+        assert v.shape[0] == mc_vertices(vol).shape[0]
+        e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        _, counts = torch.unique(e.sort(dim=1).values, dim=0, return_counts=True)
+        assert int(counts.min()) == 2 and int(counts.max()) == 2
+        assert torch.unique(e[:, 0] * v.shape[0] + e[:, 1]).numel() == e.shape[0]
+        assert v.shape[0] - counts.numel() + f.shape[0] == chi
+        A, B, C = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+        assert float((A * torch.cross(B, C, dim=1)).sum()) > 0
+    noise = torch.randn(12, 12, 12, generator=torch.Generator().manual_seed(0))
+    v, f = marching_cubes(noise)
+    e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]).sort(dim=1).values
+    _, counts = torch.unique(e, dim=0, return_counts=True)
+    assert int(counts.max()) == 2 and v.shape[0] == mc_vertices(noise).shape[0]
