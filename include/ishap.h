@@ -103,7 +103,11 @@ typedef struct {
   int clip_denoised;
   int mode;             /* 0: mean + sqrt(var)*noise (p_sample_guidance :503/:508)
                            1: mean + exp(0.5*logvar)*noise (p_sample :443)
-                           2: mean + variance_noise (:498-499; `noise` holds variance_noise) */
+                           2: mean + variance_noise (:498-499; `noise` holds variance_noise)
+                           3: DDIM (ddim_sample :654-705): x0*ddim_a + ddim_b*eps(x0) + nonzero*ddim_sigma*noise */
+  float ddim_a;         /* sqrt(alphas_cumprod_prev[t]) */
+  float ddim_b;         /* sqrt(1 - alphas_cumprod_prev[t] - sigma^2) */
+  float ddim_sigma;     /* eta * sqrt((1-abar_prev)/(1-abar)) * sqrt(1 - abar/abar_prev) */
 } ishap_step_coefs;
 /* any of sample / pred_xstart / variance / mean may be NULL; noise NULL = zeros; variance_in optional */
 int ishap_ddpm_step(const float* x, const float* model_out, const float* noise, const float* variance_in,

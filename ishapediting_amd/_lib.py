@@ -25,7 +25,8 @@ class UNetConfigC(C.Structure):
 class StepCoefs(C.Structure):
     _fields_ = [("min_log", C.c_float), ("max_log", C.c_float), ("sqrt_recip", C.c_float),
                 ("sqrt_recipm1", C.c_float), ("coef1", C.c_float), ("coef2", C.c_float),
-                ("nonzero", C.c_float), ("clip_denoised", C.c_int), ("mode", C.c_int)]
+                ("nonzero", C.c_float), ("clip_denoised", C.c_int), ("mode", C.c_int),
+                ("ddim_a", C.c_float), ("ddim_b", C.c_float), ("ddim_sigma", C.c_float)]
 
 
 class DragArgsC(C.Structure):

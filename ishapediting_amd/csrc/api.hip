@@ -16,7 +16,7 @@ int ishap_ddpm_step(const float* x, const float* model_out, const float* noise, 
                     const ishap_step_coefs* k, int N, int C, int HW, float* sample, float* pred_xstart,
                     float* variance, float* mean, void* stream) {
   ISHAP_REQUIRE(x && model_out && k, "null argument");
-  ISHAP_REQUIRE(k->mode >= 0 && k->mode <= 2, "mode");
+  ISHAP_REQUIRE(k->mode >= 0 && k->mode <= 3, "mode");
   ISHAP_REQUIRE(k->mode != 2 || noise, "mode 2 needs variance_noise in `noise`");
   DdpmStepArgs a;
   a.x = x; a.model_out = model_out; a.noise = noise; a.variance_in = variance_in;
@@ -24,6 +24,7 @@ int ishap_ddpm_step(const float* x, const float* model_out, const float* noise, 
   a.N = N; a.C = C; a.HW = HW;
   a.min_log = k->min_log; a.max_log = k->max_log; a.sqrt_recip = k->sqrt_recip; a.sqrt_recipm1 = k->sqrt_recipm1;
   a.coef1 = k->coef1; a.coef2 = k->coef2; a.nonzero = k->nonzero; a.clip = k->clip_denoised; a.mode = k->mode;
+  a.ddim_a = k->ddim_a; a.ddim_b = k->ddim_b; a.ddim_sigma = k->ddim_sigma;
   return ddpm_step_launch(a, (hipStream_t)stream);
 }
 

@@ -2,7 +2,7 @@
 #include "common.h"
 #include <algorithm>
 
-enum { DDPM_MODE_SQRT_VAR = 0, DDPM_MODE_EXP_HALF_LOGVAR = 1, DDPM_MODE_VARIANCE_NOISE = 2 };
+enum { DDPM_MODE_SQRT_VAR = 0, DDPM_MODE_EXP_HALF_LOGVAR = 1, DDPM_MODE_VARIANCE_NOISE = 2, DDPM_MODE_DDIM = 3 };
 
 struct DdpmStepArgs {
   const float* x = nullptr;          // [N][C][HW]
@@ -16,6 +16,7 @@ struct DdpmStepArgs {
   int N = 1, C = 0, HW = 0;
   float min_log = 0, max_log = 0, sqrt_recip = 0, sqrt_recipm1 = 0, coef1 = 0, coef2 = 0;
   float nonzero = 1.f;
+  float ddim_a = 0, ddim_b = 0, ddim_sigma = 0;   // mode 3: sqrt(abar_prev), sqrt(1 - abar_prev - sigma^2), sigma
   int clip = 1;
   int mode = DDPM_MODE_SQRT_VAR;
 };

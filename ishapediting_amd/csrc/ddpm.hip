@@ -30,7 +30,11 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(DdpmStepArgs a) {
       if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
       float mean = a.coef1 * x0 + a.coef2 * x[k];
       float s;
-      if (a.mode == DDPM_MODE_VARIANCE_NOISE) s = mean + nz[k];                           // :498-499
+      if (a.mode == DDPM_MODE_DDIM) {
+        // ddim_sample (:654-705): eps re-derived from the (clipped) x0 (:350-354), Equation 12
+        const float e2 = (a.sqrt_recip * x[k] - x0) / a.sqrt_recipm1;
+        s = (x0 * a.ddim_a + a.ddim_b * e2) + a.nonzero * a.ddim_sigma * nz[k];
+      } else if (a.mode == DDPM_MODE_VARIANCE_NOISE) s = mean + nz[k];                           // :498-499
       else if (a.mode == DDPM_MODE_EXP_HALF_LOGVAR) s = mean + a.nonzero * expf(0.5f * logvar) * nz[k];   // :443
       else s = mean + a.nonzero * sqrtf(a.variance_in ? var_in[k] : var) * nz[k];          // :503 / :508
       o_sample[k] = s; o_x0[k] = x0; o_var[k] = var; o_mean[k] = mean;

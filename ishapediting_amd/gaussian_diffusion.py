@@ -3,8 +3,8 @@
 Schedule tables are float64 numpy like the reference's (gaussian_diffusion.py:118-169, respace.py:71-85);
 each per-step lookup is cast to fp32 exactly where `_extract_into_tensor` does (:1035-1048).  The step
 arithmetic itself (p_mean_variance :232-331, sample variants :443/:498-510) is one HIP kernel
-(`ishap_ddpm_step`); the model call goes to the HIP UNet.  DDIM, training losses and the VLB are not on
-the path (use_ddim=False, no training) and are not provided.
+(`ishap_ddpm_step`); the model call goes to the HIP UNet.  DDIM sampling (:654-847; optional faster sampler,
+SURVEY 8f rank 4) is mode 3 of the same kernel.  Training losses and the VLB are not on the path.
 """
 from __future__ import annotations
 
@@ -93,12 +93,19 @@ class SpacedDiffusion:
             return int(t[0])
         return int(t)
 
-    def _coefs(self, t: int, clip_denoised: bool, mode: int) -> _lib.StepCoefs:
+    def _coefs(self, t: int, clip_denoised: bool, mode: int, eta: float = 0.0) -> _lib.StepCoefs:
         f32 = lambda a: float(np.float32(a[t]))                    # noqa: E731  (float64 table -> fp32, :1045)
+        da = db = ds = 0.0
+        if mode == 3:
+            # ddim_sample (:688-699): the reference forms these from fp32 extracts with fp32 tensor ops, in this order
+            ab, abp = np.float32(self.alphas_cumprod[t]), np.float32(self.alphas_cumprod_prev[t])
+            one = np.float32(1)
+            sigma = np.float32(eta) * np.sqrt((one - abp) / (one - ab)) * np.sqrt(one - ab / abp)
+            da, db, ds = float(np.sqrt(abp)), float(np.sqrt(one - abp - sigma * sigma)), float(sigma)
         return _lib.StepCoefs(f32(self.posterior_log_variance_clipped), f32(self._log_betas),
                               f32(self.sqrt_recip_alphas_cumprod), f32(self.sqrt_recipm1_alphas_cumprod),
                               f32(self.posterior_mean_coef1), f32(self.posterior_mean_coef2),
-                              0.0 if t == 0 else 1.0, int(bool(clip_denoised)), mode)
+                              0.0 if t == 0 else 1.0, int(bool(clip_denoised)), mode, da, db, ds)
 
     def _model(self, model, x, t: int, feat_layer: int, **model_kwargs):
         ts = torch.tensor([self.timestep_map[t]] * x.shape[0])      # _WrappedModel, respace.py:122-127
@@ -106,12 +113,12 @@ class SpacedDiffusion:
             return model(x, ts, **model_kwargs), None
         return model(x, ts, feat_layer=feat_layer, **model_kwargs)
 
-    def _step(self, x, model_output, t, noise, variance_in, clip_denoised, mode, want=("sample",)):
+    def _step(self, x, model_output, t, noise, variance_in, clip_denoised, mode, want=("sample",), eta=0.0):
         N, Cc = x.shape[:2]
         HW = int(np.prod(x.shape[2:]))
         assert model_output.shape[1] == 2 * Cc
         outs = {k: torch.empty_like(x) for k in want}
-        k = self._coefs(t, clip_denoised, mode)
+        k = self._coefs(t, clip_denoised, mode, eta)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().ishap_ddpm_step(
                 x.data_ptr(), model_output.data_ptr(), _lib.ptr(noise), _lib.ptr(variance_in), C.byref(k), N, Cc, HW,
@@ -181,6 +188,41 @@ class SpacedDiffusion:
         for sample in self.p_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
                                                      model_kwargs=model_kwargs, device=device, progress=progress,
                                                      step_noise=step_noise):
+            final = sample
+        return final["sample"]
+
+    # ------------------------------------------------------------------ DDIM (gaussian_diffusion.py:654-847)
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0,
+                    noise=None, feat_layer=-1, **kwargs):
+        """gaussian_diffusion.py:654-705.  `noise` injectable for parity runs (default randn_like as there)."""
+        assert denoised_fn is None and cond_fn is None
+        ti = self._t_index(t)
+        x = self._prep(x)
+        mo, inter = self._model(model, x, ti, feat_layer, **(model_kwargs or {}))
+        noise = self._prep(noise if noise is not None else torch.randn_like(x))
+        o = self._step(x, mo, ti, noise, None, clip_denoised, 3, ("sample", "pred_xstart"), eta=eta)
+        return {"sample": o["sample"], "pred_xstart": o["pred_xstart"], "inter_feat": inter,
+                "model_output": mo[:, :x.shape[1]]}
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                     model_kwargs=None, device=None, progress=False, eta=0.0, step_noise=None):
+        """gaussian_diffusion.py:797-846."""
+        if device is None:
+            device = next(model.parameters()).device
+        img = noise if noise is not None else torch.randn(*shape, device=device)
+        for i in list(range(self.num_timesteps))[::-1]:
+            out = self.ddim_sample(model, img, i, clip_denoised=clip_denoised, model_kwargs=model_kwargs, eta=eta,
+                                   noise=None if step_noise is None else step_noise(i))
+            yield out
+            img = out["sample"]
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                         model_kwargs=None, device=None, progress=False, eta=0.0, step_noise=None, **_ignored):
+        """gaussian_diffusion.py:762-795."""
+        final = None
+        for sample in self.ddim_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
+                                                        model_kwargs=model_kwargs, device=device, progress=progress,
+                                                        eta=eta, step_noise=step_noise):
             final = sample
         return final["sample"]
 

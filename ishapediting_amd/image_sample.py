@@ -50,11 +50,9 @@ def noise2shape(args=None, state_dict=None, bounds=None, noise=None, step_noise=
     if args.use_fp16:
         model.convert_to_fp16()
     model.eval()
-    if getattr(args, "use_ddim", False):
-        raise NotImplementedError("use_ddim=False on the path (generate.py:65)")
     shape = (args.batch_size, 96, args.image_size, args.image_size)
-    sample = diffusion.p_sample_loop(model, shape, noise=noise, clip_denoised=args.clip_denoised, device=device,
-                                     step_noise=step_noise)
+    sample_fn = diffusion.p_sample_loop if not getattr(args, "use_ddim", False) else diffusion.ddim_sample_loop   # :166-168
+    sample = sample_fn(model, shape, noise=noise, clip_denoised=args.clip_denoised, device=device, step_noise=step_noise)
     if args.explicit_normalization:
         if bounds is not None:
             sample = unnormalize(sample, lower_bound=bounds[0], upper_bound=bounds[1])

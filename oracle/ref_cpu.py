@@ -32,8 +32,14 @@ def linear_betas(n: int) -> np.ndarray:
 
 
 def space_timesteps(num_timesteps: int, section_counts) -> List[int]:
-    """gd/respace.py:6-59 (non-ddim branch)."""
+    """gd/respace.py:6-59."""
     if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):                      # :27-37: a fixed integer stride that gives exactly N steps
+            want = int(section_counts[4:])
+            for stride in range(1, num_timesteps):
+                if len(range(0, num_timesteps, stride)) == want:
+                    return sorted(range(0, num_timesteps, stride))
+            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
         section_counts = [int(x) for x in section_counts.split(",")]
     size_per = num_timesteps // len(section_counts)
     extra = num_timesteps % len(section_counts)
@@ -263,6 +269,18 @@ class DiffusionOracle:
         nonzero = 0.0 if t == 0 else 1.0
         return {"sample": out["mean"] + nonzero * torch.exp(0.5 * out["log_variance"]) * noise,
                 "pred_xstart": out["pred_xstart"]}
+
+    def ddim_sample(self, unet, x, t: int, noise, eta: float = 0.0, clip_denoised=True):
+        """gd/gaussian_diffusion.py:654-705 (eps re-derived from the clipped x0, :350-354; Equation 12)."""
+        tb = self.tb
+        out = self.mean_variance_from_output(self.model_call(unet, x, t, -1), x, t, clip_denoised)
+        x0 = out["pred_xstart"]
+        eps = (tb.f32(tb.sqrt_recip_alphas_cumprod, t) * x - x0) / tb.f32(tb.sqrt_recipm1_alphas_cumprod, t)
+        ab, abp = tb.f32(tb.alphas_cumprod, t), tb.f32(tb.alphas_cumprod_prev, t)
+        sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+        mean_pred = x0 * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma ** 2) * eps
+        nonzero = 0.0 if t == 0 else 1.0
+        return {"sample": mean_pred + nonzero * sigma * noise, "pred_xstart": x0}
 
     def ddpm_inversion(self, unet, x0, steps: int, noises: List[torch.Tensor], clip_denoised=True, feat_layer=-1):
         """gd/gaussian_diffusion.py:512-532; `noises[i]` stands in for randn_like at :522."""

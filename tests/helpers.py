@@ -41,3 +41,15 @@ def redraw_generate_noise(g, B: int):
     got = np.array([float(init.double().sum()), float(steps.double().pow(2).sum()), float(steps[-1, -1, -1, -1, -1])])
     np.testing.assert_allclose(got, chk, rtol=1e-12, atol=0, err_msg="torch's CPU RNG stream differs from the one the fixture was made with")
     return init, steps
+
+
+def redraw_ddim_noise(g):
+    """Golden G13's RNG stream: th.randn(*shape) then one randn per step under torch.manual_seed(seed)."""
+    Tn = int(g["T"])
+    shape = (2, 96, 16, 16)
+    torch.manual_seed(int(g["seed"]))
+    init = torch.randn(*shape)
+    steps = torch.stack([torch.randn(*shape) for _ in range(Tn)])
+    got = np.array([float(init.double().sum()), float(steps.double().pow(2).sum()), float(steps[-1, -1, -1, -1, -1])])
+    np.testing.assert_allclose(got, g["noise_check"], rtol=1e-12, atol=0, err_msg="torch's CPU RNG stream differs from the fixture's")
+    return init, steps

@@ -402,3 +402,29 @@ def test_group_local_norms_batch_2_equals_single_images():
         r_o, r_g = rel(out2[b:b + 1], o1.cpu()), rel(gx2[b:b + 1], g1.cpu())
         print(f"mid config batch element {b}: out {r_o:.2e} grad {r_g:.2e}")
         assert r_o < 5e-3 and r_g < 1e-2
+
+
+# ------------------------------------------------------------------------------------------ f4: DDIM
+@pytest.mark.parametrize("eta", [0.0, 0.7])
+def test_ddim_sampling_vs_reference_run(gold, eta):
+    """SpacedDiffusion.ddim_sample_loop (mode 3 of the step kernel) through noise2shape(use_ddim=True) against the
+    reference's ddim_sample_loop (gaussian_diffusion.py:762-846) on small96_config, timestep_respacing='ddim8', batch 2;
+    eta = 0 (deterministic) and eta = 0.7 (injected per-step noise).  Tolerance 2e-2 relative L2 (fp16 torso vs fp32, 8
+    chained steps; measured ~2e-3)."""
+    from ishapediting_amd.gaussian_diffusion import create_gaussian_diffusion
+    from ishapediting_amd.unet import UNetModel
+    from tests.helpers import redraw_ddim_noise
+    g = gold("g13_ddim")
+    Tn = int(g["T"])
+    init, steps = redraw_ddim_noise(g)
+    cfg = small96_config()
+    m = UNetModel(cfg, dev(), max_batch=2)
+    m.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 404)))
+    d = create_gaussian_diffusion(timestep_respacing="ddim8")
+    assert d.timestep_map == g["timestep_map"].tolist() and d.num_timesteps == Tn
+    sd = steps.to(dev())
+    out = d.ddim_sample_loop(m, (2, 96, 16, 16), noise=init.to(dev()), eta=eta, step_noise=lambda i: sd[Tn - 1 - i])
+    torch.cuda.synchronize()
+    r = rel(out, g[f"eta{eta}_sample"])
+    print(f"ddim eta={eta}: rel {r:.2e}")
+    assert r < 2e-2

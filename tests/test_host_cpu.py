@@ -75,6 +75,12 @@ def _worker(rank, world, port, n_edits, q):
     mine = shard_edits(n_edits, world, rank)
     vols = [torch.full((4, 4, 4), float(i)) for i in mine]
     out = gather_volumes(vols, n_edits, dst=0)
+    if n_edits == world:
+        # bench.py's form: the shape is known on every rank and rank 0 reuses its receive buffers
+        recv = [torch.empty((4, 4, 4)) for _ in range(world)] if rank == 0 else None
+        out2 = gather_volumes(vols, n_edits, dst=0, full_shape=(4, 4, 4), recv=recv)
+        if rank == 0:
+            assert all(torch.equal(a, b) for a, b in zip(out, out2)) and out2[0] is recv[0]
     if rank == 0:
         q.put([float(v[0, 0, 0]) for v in out])
     dist.barrier()

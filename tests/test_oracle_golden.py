@@ -304,3 +304,21 @@ def test_marching_cubes_statement_topology():
     e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]).sort(dim=1).values
     _, counts = torch.unique(e, dim=0, return_counts=True)
     assert int(counts.max()) == 2 and v.shape[0] == mc_vertices(noise).shape[0]
+
+
+@pytest.mark.parametrize("eta", [0.0, 0.7])
+def test_ddim_sample_loop(gold, eta):
+    """ddim_sample_loop (gaussian_diffusion.py:762-846, timestep_respacing='ddim8') vs the reference's own run."""
+    from tests.helpers import small96_config, redraw_ddim_noise
+    g = gold("g13_ddim")
+    Tn = int(g["T"])
+    init, steps = redraw_ddim_noise(g)
+    cfg = small96_config()
+    net = O.UNetOracle(build_spec(cfg), synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 404)), fp16=False)
+    d = O.DiffusionOracle(O.Tables("ddim8"))
+    assert d.tb.timestep_map == g["timestep_map"].tolist()
+    img = init
+    with torch.no_grad():
+        for k, i in enumerate(range(Tn - 1, -1, -1)):
+            img = d.ddim_sample(net, img, i, steps[k], eta=eta)["sample"]
+    close(img, g[f"eta{eta}_sample"], rtol=1e-3, atol=1e-4)

@@ -521,6 +521,26 @@ def g12_generate():
     save("g12_generate", **out)
 
 
+def g13_ddim():
+    """ddim_sample_loop (gaussian_diffusion.py:762-846) on small96_config with timestep_respacing='ddim8': eta = 0 (the
+    deterministic sampler) and eta = 0.7 (per-step noise drawn under torch.manual_seed, redrawn by the tests)."""
+    cfg = small96_config()
+    model, diff = load_ref_unet(cfg, 404, "ddim8")
+    out = {"T": diff.num_timesteps, "timestep_map": np.array(diff.timestep_map)}
+    shape = (2, 96, 16, 16)
+    for eta in (0.0, 0.7):
+        torch.manual_seed(600)
+        sample = diff.ddim_sample_loop(model, shape, clip_denoised=True, model_kwargs={}, eta=eta)
+        out[f"eta{eta}_sample"] = sample
+    torch.manual_seed(600)
+    init = torch.randn(*shape)
+    steps = torch.stack([torch.randn(*shape) for _ in range(diff.num_timesteps)])
+    out["seed"] = 600
+    out["noise_check"] = np.array([float(init.double().sum()), float(steps.double().pow(2).sum()),
+                                   float(steps[-1, -1, -1, -1, -1])], dtype=np.float64)
+    save("g13_ddim", **out)
+
+
 def g10_full_keys():
     """Key table + parameter count of the full-size model (structure only, no tensors stored)."""
     cfg = full_config()
@@ -539,7 +559,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = _WHICH
     todo = [g1_schedules, g2_steps, g3_primitives, g3b_block_primitives, g4_tiny_unet, g4b_block_outputs, g6_decoder, g7_drag,
-            g8_g9_tiny_loops, g10_full_keys, g11_reconstruct, g12_generate]
+            g8_g9_tiny_loops, g10_full_keys, g11_reconstruct, g12_generate, g13_ddim]
     if which:
         todo = [f for f in todo if f.__name__ in which]
     with torch.no_grad():
