@@ -4,16 +4,22 @@
 // (Linear128-ReLU-Linear128-ReLU-Linear1); triplane_decoder/visualize.py:79-97 (dense grid,
 // 50 000-point chunks with a host round trip each -- here the whole grid stays on the device).
 //
-// The reference decoder is fp32, so this kernel uses v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
-// One wave owns 32 query points (lane&31 = point, lane>>5 = which half of the K pair it feeds).
+// The reference decoder is fp32.  The Fourier projection (K = 32, feeds sin / cos of phases up to tens of radians) runs
+// on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).  The two 128 x 128 layers -- 93 % of the FLOPs -- run on the fp16
+// matrix pipe at fp32 grade: weights and activations are split x = x_hi + x_lo (two fp16 each), the product is formed as
+// w_hi x_hi + w_lo x_hi + w_hi x_lo with fp32 accumulation (the dropped w_lo x_lo term is 2^-22 relative), i.e. three
+// v_mfma_f32_32x32x16_f16 (32 cycles each, K = 16) where the fp32 pipe needs sixteen 64-cycle MFMAs: 5.3x fewer matrix
+// cycles for fp32-grade results (parity tests: 1e-4 abs + 1e-4 rel against the fp32 reference, unchanged).
+// One wave owns 32 query points (lane&31 = point, lane>>5 = which half of the K slots it feeds).
 // Weights are the MFMA A operand (rows = output neuron) read from LDS; activations are the B operand
 // (column = point).  D[neuron][point] keeps the point on the lane, so a layer's accumulator registers
-// ARE the next layer's B operands: register s of lane-half h holds neuron (s&3)+8*(s>>2)+4h, and the
-// next layer simply reads its weight column for that same neuron.  Activations never touch LDS.
+// ARE the next layer's B operands: register s of lane-half h holds neuron (s&3)+8*(s>>2)+4h; for the fp16 layers
+// registers 8s..8s+7 (converted pairwise) are the fragment of K-step s, and the weights are stored in LDS in that same
+// permuted K order (cdna_hip_programming.md, "An accumulator tile as the next MFMA's operand").  Activations never touch LDS.
 #include "decode.h"
 
-#define LDW 132   // padded row strides (floats): conflict-free ds_read_b128, 16-byte aligned rows
-#define LDB 36
+#define LDH 136   // padded row stride (halfs) of the split weight images: 272 B = 16 B mod 256 -> conflict-free ds_read_b128
+#define LDB 36    // padded row stride (floats) of the Fourier matrix
 
 __device__ __forceinline__ int kmap(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 
@@ -62,17 +68,24 @@ int planes_prepare_launch(const float* latent, const float* rng, const float* mi
 
 __global__ __launch_bounds__(512) void triplane_decode_kernel(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sW1 = lds;                    // [128][LDW]
-  float* sW2 = sW1 + 128 * LDW;
-  float* sBt = sW2 + 128 * LDW;        // [64][LDB]   Bt[y][k] = _B[k][y]
+  half_t* sW1h = reinterpret_cast<half_t*>(lds);          // [128][LDH] hi parts, K in fragment order
+  half_t* sW1l = sW1h + 128 * LDH;
+  half_t* sW2h = sW1l + 128 * LDH;
+  half_t* sW2l = sW2h + 128 * LDH;
+  float* sBt = reinterpret_cast<float*>(sW2l + 128 * LDH);   // [64][LDB]   Bt[y][k] = _B[k][y]
   float* sb1 = sBt + 64 * LDB;
   float* sb2 = sb1 + 128;
   float* sw3 = sb2 + 128;
   const int tid = threadIdx.x;
   for (int i = tid; i < 128 * 128; i += 512) {
-    int r = i >> 7, c = i & 127;
-    sW1[r * LDW + c] = a.W1[i];
-    sW2[r * LDW + c] = a.W2[i];
+    // LDS position p of row r holds input neuron k = 32 qb + 16 s + 8 (j >> 2) + 4 hh + (j & 3),  p = ((qb*2 + s)*2 + hh)*8 + j
+    const int r = i >> 7, p = i & 127;
+    const int j = p & 7, hh = (p >> 3) & 1, st = (p >> 4) & 1, qb = p >> 5;
+    const int k = 32 * qb + 16 * st + 8 * (j >> 2) + 4 * hh + (j & 3);
+    const float w1 = a.W1[r * 128 + k], w2 = a.W2[r * 128 + k];
+    const half_t h1 = (half_t)w1, h2 = (half_t)w2;
+    sW1h[r * LDH + p] = h1; sW1l[r * LDH + p] = (half_t)(w1 - (float)h1);
+    sW2h[r * LDH + p] = h2; sW2l[r * LDH + p] = (half_t)(w2 - (float)h2);
   }
   for (int i = tid; i < 64 * 32; i += 512) {
     int y = i >> 5, k = i & 31;
@@ -154,47 +167,63 @@ __global__ __launch_bounds__(512) void triplane_decode_kernel(DecodeArgs a) {
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float ang = two_pi * d0[q][r];
-        float sv, cv;
-        sincos_cw(ang, sv, cv);
+        // the reference's fp32 angle 2*pi*y (axisnetworks.py:89), then sin / cos on the hardware unit, which takes its
+        // argument in TURNS: ang / 2pi, reduced exactly by v_fract (period 1), v_sin_f32 / v_cos_f32 (4 instructions in
+        // place of a 35-instruction Cody-Waite + polynomial evaluation; the decode kernel is VALU-bound once the big layers
+        // run on the fp16 pipe).  Absolute error ~3e-6 in the features: two orders below the 1e-4 logit tolerance.
+        const float ang = two_pi * d0[q][r];
+        const float turns = ang * 0.15915494309189535f;
+        const float fr = __builtin_amdgcn_fractf(turns);
+        const float sv = __builtin_amdgcn_sinf(fr), cv = __builtin_amdgcn_cosf(fr);
         x1[q][r] = sv;
         x1[2 + q][r] = cv;
       }
-    // ---- layers 1 and 2: 128 -> 128, bias + ReLU on the accumulator registers ----
-    f32x16 x2[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) x2[q][r] = 0.f;
+    // ---- layers 1 and 2: 128 -> 128 on the fp16 pipe with hi/lo-split operands, bias + ReLU on the accumulators ----
+    half8 xh[4][2], xl[4][2];
+    auto split = [&](const f32x16 (&x)[4]) {
 #pragma unroll
       for (int qb = 0; qb < 4; ++qb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 av = *reinterpret_cast<const f32x4*>(sW1 + (32 * q + l31) * LDW + 32 * qb + 8 * g + 4 * h);
+        for (int st = 0; st < 2; ++st)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            x2[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], x1[qb][4 * g + e], x2[q], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) x2[q][r] = fmaxf(x2[q][r] + sb1[32 * q + kmap(r, h)], 0.f);
-    }
-    float partial = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+          for (int j = 0; j < 8; ++j) {
+            const float v = x[qb][8 * st + j];
+            const half_t hi = (half_t)v;
+            xh[qb][st][j] = hi;
+            xl[qb][st][j] = (half_t)(v - (float)hi);
+          }
+    };
+    auto layer = [&](const half_t* wh, const half_t* wl, int q) {
       f32x16 d;
 #pragma unroll
       for (int r = 0; r < 16; ++r) d[r] = 0.f;
 #pragma unroll
       for (int qb = 0; qb < 4; ++qb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 av = *reinterpret_cast<const f32x4*>(sW2 + (32 * q + l31) * LDW + 32 * qb + 8 * g + 4 * h);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], x2[qb][4 * g + e], d, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+        for (int st = 0; st < 2; ++st) {
+          const int off = (32 * q + l31) * LDH + ((qb * 2 + st) * 2 + h) * 8;
+          const half8 ah = *reinterpret_cast<const half8*>(wh + off);
+          const half8 al = *reinterpret_cast<const half8*>(wl + off);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[qb][st], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[qb][st], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[qb][st], d, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);      // keep the weight reads next to their MFMAs (hoisted, they spill)
         }
+      return d;
+    };
+    split(x1);
+    f32x16 x2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      x2[q] = layer(sW1h, sW1l, q);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x2[q][r] = fmaxf(x2[q][r] + sb1[32 * q + kmap(r, h)], 0.f);
+    }
+    split(x2);
+    float partial = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x16 d = layer(sW2h, sW2l, q);
       // ---- output layer folded in: logit = w3 . relu(h2) + b3 ----
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -210,7 +239,7 @@ __global__ __launch_bounds__(512) void triplane_decode_kernel(DecodeArgs a) {
 int triplane_decode_launch(const DecodeArgs& a, hipStream_t s) {
   ISHAP_REQUIRE(a.npts > 0, "no points");
   ISHAP_REQUIRE(a.coords != nullptr || (a.lin != nullptr && a.res > 0), "either coords or a grid axis");
-  const size_t smem = (size_t)(2 * 128 * LDW + 64 * LDB + 3 * 128) * sizeof(float);
+  const size_t smem = (size_t)4 * 128 * LDH * sizeof(half_t) + (size_t)(64 * LDB + 3 * 128) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     ISHAP_CHECK_HIP(hipFuncSetAttribute((const void*)triplane_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -9,7 +9,11 @@ timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
 tail -c 400 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --shape-profile $O/shapes.csv > $O/trace_bench.json 2> $O/trace.err || exit 1
-f=$(find $O/trace -name "*kernel_trace.csv"); python3 $R/tools/trace_by_grid.py $f > $O/kernel_by_grid.txt; rm -f $f
+f=$(find $O/trace -name "*kernel_trace.csv")
+python3 $R/tools/trace_by_grid.py $f > $O/kernel_by_grid.txt
+python3 $R/tools/step_timeline.py $f > $O/step_timeline.txt
+rm -f $f
 cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
+python3 $R/tools/shape_table.py $O/shapes.csv > $O/shapes.txt
 echo trace done
 rm -rf $O/trace
