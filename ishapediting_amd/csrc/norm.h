@@ -83,8 +83,8 @@ struct GnLocalArgs {
   int emb_ld = 0;
   int N = 1, H = 0, W = 0, C = 0;
   int film = 0, act = 1, pool = 0;
-  // optional zeroed scratch [N][32][4] x 64 bit: lets several workgroups share one (image, group) (they meet through
-  // memory-side integer atomics); null = one workgroup per group.  `parts` is set by the launcher.
+  // optional zeroed scratch [N][32][16] x 64 bit: lets up to 8 workgroups share one (image, group) (they exchange their
+  // partial sums as data-tagged granules); null = one workgroup per group.  `parts` is set by the launcher.
   unsigned long long* rec = nullptr;
   int parts = 1;
 };

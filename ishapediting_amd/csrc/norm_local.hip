@@ -122,36 +122,35 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
   for (int w = 0; w < nw; ++w) { a += scratch[w]; b += scratch[16 + w]; }      // fixed order
 }
 
-// Several workgroups share one (image, group): each adds its two partial sums to the group's record in global memory
-// and waits until all `parts` have.  Everything that crosses workgroups is a 64-bit integer atomic executed at the
-// memory side (fixed point: integer adds commute, so the totals are bitwise reproducible; and an atomic read-modify-
-// write is coherent across the XCDs' L2s, which plain and sc1 loads are not -- MI355X_MICROARCH.md, inter-workgroup
-// visibility).  rec = {sum a, sum b, arrivals}, zeroed before the launch.  The launcher only uses parts > 1 when the
-// whole grid is resident at once (<= 256 workgroups of <= 1024 threads); the spin is bounded all the same.
-__device__ __forceinline__ void group_rendezvous(double& a, double& b, unsigned long long* rec, int parts, float scale_a,
-                                                 float scale_b, double* scratch) {
+// Several workgroups share one (image, group): each publishes its two partial sums as data-tagged 8-byte granules
+// {fp32 value, tag} -- ONE naturally aligned agent-scope (sc1, write-through) store each, so a granule is valid by itself and
+// needs no flag, fence or ordering -- and every workgroup polls all 2 * parts granules of its group with agent-scope loads
+// until the tags are there (MI355X_MICROARCH.md, handoff-1to1: ~1 us per hop).  The totals are formed from the parts in
+// part order in double: bitwise reproducible, no atomics.  rec = [parts][2] granules, zeroed before the launch (tag 0 =
+// not yet written).  The launcher only uses parts > 1 when the whole grid is resident at once (<= 256 workgroups of
+// <= 1024 threads); the spin is bounded all the same.
+__device__ __forceinline__ void group_rendezvous(double& a, double& b, unsigned long long* rec, int part, int parts,
+                                                 double* scratch) {
   if (parts <= 1) return;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const long long fa = __double2ll_rn(a * (double)scale_a), fb = __double2ll_rn(b * (double)scale_b);
-    // returning atomics: both sums have been applied at the memory side before the arrival is counted
-    const unsigned long long o0 = __hip_atomic_fetch_add(rec + 0, (unsigned long long)fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long o1 = __hip_atomic_fetch_add(rec + 1, (unsigned long long)fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" :: "v"(o0), "v"(o1) : "memory");     // both returned: the sums are in place before the arrival counts
-    // relaxed everywhere: no plain memory crosses workgroups here, so no cache write-back / invalidate is needed
-    __hip_atomic_fetch_add(rec + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < 2) {
+    const float v = threadIdx.x == 0 ? (float)a : (float)b;
+    const unsigned long long granule = (unsigned long long)__float_as_uint(v) | (1ull << 32);
+    __hip_atomic_store(rec + part * 2 + threadIdx.x, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if ((int)threadIdx.x < 2 * parts) {
+    unsigned long long gr = 0;
     int spins = 0;
-    while (__hip_atomic_fetch_add(rec + 2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)parts &&
-           ++spins < (1 << 22))
-      __builtin_amdgcn_s_sleep(2);
-    const long long ta = (long long)__hip_atomic_fetch_add(rec + 0, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long tb = (long long)__hip_atomic_fetch_add(rec + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    scratch[0] = (double)ta / (double)scale_a;
-    scratch[1] = (double)tb / (double)scale_b;
+    do {
+      gr = __hip_atomic_load(rec + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } while ((gr >> 32) == 0ull && ++spins < (1 << 22));
+    scratch[threadIdx.x] = (double)__uint_as_float((unsigned)(gr & 0xffffffffull));
   }
   __syncthreads();
-  a = scratch[0];
-  b = scratch[1];
+  double ta = 0.0, tb = 0.0;
+  for (int p = 0; p < parts; ++p) { ta += scratch[2 * p]; tb += scratch[2 * p + 1]; }
+  a = ta;
+  b = tb;
   __syncthreads();
 }
 
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
     for (int i = 0; i < VEC; ++i) { s += (double)v[i]; q += (double)v[i] * (double)v[i]; }
   }
   block_sum2(s, q, scratch);
-  group_rendezvous(s, q, a.rec + ((long long)n * 32 + g) * 4, a.parts, STAT_SCALE_SUM, STAT_SCALE_SQ, scratch);
+  group_rendezvous(s, q, a.rec + ((long long)n * 32 + g) * 16, part, a.parts, scratch);
   const double cnt = (double)HW * (double)cpg;
   const double md = s / cnt;
   double vd = q / cnt - md * md;
@@ -346,7 +345,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(GnBwdLocalArgs a) {
     }
   }
   block_sum2(s1, s2, scratch);
-  group_rendezvous(s1, s2, a.rec + ((long long)n * 32 + g) * 4, a.parts, STAT_SCALE_SUM, STAT_SCALE_SUM, scratch);
+  group_rendezvous(s1, s2, a.rec + ((long long)n * 32 + g) * 16, part, a.parts, scratch);
   const double cnt = (double)HW * (double)cpg;
   const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt);
   __syncthreads();
