@@ -238,7 +238,7 @@ def main():
         L.ishap_profile_begin()
         one_edit(ds, src, tgt)
         torch.cuda.synchronize()
-        NV = 7
+        NV = 8
         out = (C.c_double * (NV * 3))()
         L.ishap_profile_end(out, NV)
         buf = C.create_string_buffer(1 << 17)
@@ -265,9 +265,10 @@ def main():
                           "launches_per_edit": int(sm_launch), "ms_per_edit": round(sm_ms, 2),
                           "algorithmic_bytes_per_edit": int(sm_bytes)}
         # one entry per kernel symbol (the name rocprofv3 reports)
-        names = ["void igemm2_kernel<128, 128, 4, true, 1>", "void igemm2_kernel<64, 64, 4, true, 1>",
-                 "void igemm2_kernel<128, 128, 4, false, 1>", "void igemm2_kernel<64, 64, 4, false, 1>",
-                 "void igemm2_kernel<64, 64, 4, true, 2>", "igemm_skinny_kernel<*, false>", "void igemm_kernel<128, 128, 32, 2, 2, true>"]
+        names = ["igemm2_kernel<128, 128, 4, true, 1>", "igemm2_kernel<64, 64, 4, true, 1>",
+                 "igemm2_kernel<128, 128, 4, false, 1>", "igemm2_kernel<64, 64, 4, false, 1>",
+                 "igemm2_kernel<64, 64, 4, true, 2>", "igemm_skinny_kernel<*, false>", "igemm_kernel<128, 128, 32, 2, 2, true>",
+                 "conv3_small_kernel<4>"]
         v = max(range(NV), key=lambda i: out[i * 3 + 1])
         launches, ms, flops = out[v * 3], out[v * 3 + 1], out[v * 3 + 2]
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

@@ -224,8 +224,8 @@ int ishap_mesh_occupancy(const float* verts, const int* tris, long long ntris, c
 /* ------------------------------------------------------------------ measurement aid (bench.py roofline leg)
  * Brackets every implicit-GEMM launch with HIP events on its own stream between begin and end.
  * out[v*3+{0,1,2}] = {launches, total ms, algorithmic FLOPs}; one v per kernel symbol: 0 conv3x3 128^2 tile,
- * 1 conv3x3 64^2 tile, 2 GEMM 128^2 tile, 3 GEMM 64^2 tile, 4 conv3x3 64^2 tile two-team, 5 small-map kernel,
- * 6 register-staged stem kernel. */
+ * 1 conv3x3 64^2 tile, 2 GEMM 128^2 tile, 3 GEMM 64^2 tile, 4 conv3x3 64^2 tile two-team, 5 small-map GEMM kernel,
+ * 6 register-staged stem kernel, 7 small-map 3x3 weight-streaming kernel. */
 int ishap_profile_begin(void);
 int ishap_profile_end(double* out, int nvar);
 /* Per-shape CSV ("M,N,K,conv3,tile,ksplit,launches,main_ms,reduce_ms,gflop" lines) of the same records; call

@@ -9,11 +9,19 @@ import csv
 import re
 import sys
 
+
+def short(name):
+    """kernel symbol with its template arguments, without the argument list / anonymous-namespace prefix"""
+    name = name.replace("(anonymous namespace)::", "")
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([A-Za-z_0-9:]+(<[^()]*>)?)", name)
+    return (m.group(1) if m else name)[:70]
+
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 seen = set()
 for r in csv.DictReader(open(sys.argv[1])):
-    name = re.sub(r"\(.*", "", r["Kernel_Name"])[:70]
+    name = short(r["Kernel_Name"])
     agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
     key = (name, r.get("Dispatch_Id"))
     if key not in seen:

@@ -7,9 +7,17 @@ import csv
 import re
 import sys
 
+
+def short(name):
+    """kernel symbol with its template arguments, without the argument list / anonymous-namespace prefix"""
+    name = name.replace("(anonymous namespace)::", "")
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([A-Za-z_0-9:]+(<[^()]*>)?)", name)
+    return (m.group(1) if m else name)[:70]
+
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for r in csv.DictReader(open(sys.argv[1])):
-    name = re.sub(r"\(.*", "", r["Kernel_Name"])[:70]
+    name = short(r["Kernel_Name"])
     a = agg[name][r["Counter_Name"]]
     a[0] += 1
     a[1] += float(r["Counter_Value"])
