@@ -7,6 +7,7 @@
 // predicating.  One raw s_barrier per K-step; loads stay in flight across it behind a counted s_waitcnt vmcnt.
 #include "common.h"
 #include "igemm_epilogue.h"
+#include <type_traits>
 
 __device__ __attribute__((aligned(128))) half_t g_zero_line[64];   // zero-initialised: source of padded rows
 
@@ -186,44 +187,70 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
       if (s < nk) issue(s);
   }
 
-  for (int k = 0; k < nk_loop; ++k) {
-    if (loader && k < nk) {
-      // stage k must have landed: stages up to min(nk, k+NST-1)-1 are issued, (XI+WI) instructions each
-      if (k + NST - 1 <= nk) {
-      #if defined(ABL_NOX)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (WI)) : "memory");
+  if (loader) {
+    for (int k = 0; k < nk_loop; ++k) {
+      if (k < nk) {
+        // stage k must have landed: stages up to min(nk, k+NST-1)-1 are issued, (XI+WI) instructions each
+        if (k + NST - 1 <= nk) {
+#if defined(ABL_NOX)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (WI)) : "memory");
 #elif defined(ABL_NOW)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (XI)) : "memory");
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (XI)) : "memory");
 #else
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (XI + WI) / LSPLIT) : "memory");
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (XI + WI) / LSPLIT) : "memory");
 #endif
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
       }
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (loader) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
       if (k + NST - 1 < nk) issue((k + NST - 1) % NST);
-      continue;
     }
-    if (k >= nk) continue;                       // the shorter half (odd step count) idles through the last barrier
-    const half_t* bx = lds + (k % NST) * STAGE;
-    const half_t* bw = bx + BM * BK;
+  } else {
+    // MFMA waves.  A K-step is two 32-deep halves; the fragments of the second half are read while the MFMAs of the
+    // first run, and the first half of step k+1 is read (right after that step's barrier) under the MFMAs of the second
+    // half of step k: the matrix pipe never waits for an LDS round trip (the straightforward loop -- read, wait, 16
+    // MFMAs, read, wait ... -- spent 1170 cycles per step on 512 cycles of MFMA work, tools/fixed_cost_probe2.sh).
+    // All fragment reads of step k have returned (lgkmcnt(0)) before this wave enters barrier k+1, after which the
+    // loaders may overwrite that ring slot.
+    // The reads are inline asm with hand-counted s_waitcnt lgkmcnt: hipcc's own counting falls back to lgkmcnt(0) for
+    // reads that are in flight across the loop's back edge, which would expose a full LDS round trip per half step.
+    unsigned xo[2][MT], wo[2][NT];               // fragment byte addresses within ring slot 0, per 32-deep half
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_void*)lds;
 #pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      half8 xf[MT], wf[NT];
+    for (int kk = 0; kk < 2; ++kk) {
       const int ch = (lane >> 4) + 4 * kk;
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int row = wm * TMW + j * 16 + (lane & 15);
-        xf[j] = *reinterpret_cast<const half8*>(bx + row * BK + ((ch ^ ((row >> 1) & 7)) * 8));
+        xo[kk][j] = lds_base + 2 * (row * BK + ((ch ^ ((row >> 1) & 7)) * 8));
       }
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         const int row = wn * TNW + i * 16 + (lane & 15);
-        wf[i] = *reinterpret_cast<const half8*>(bw + row * BK + ((ch ^ ((row >> 1) & 7)) * 8));
+        wo[kk][i] = lds_base + 2 * (BM * BK + row * BK + ((ch ^ ((row >> 1) & 7)) * 8));
       }
+    }
+    half8 xa[MT], wa[NT], xb[MT], wb[NT];
+    auto read_half = [&](int k, int kk, half8 (&xf)[MT], half8 (&wf)[NT]) {
+      const unsigned slot = (unsigned)(k % NST) * (STAGE * 2);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[j]) : "v"(xo[kk][j] + slot) : "memory");
+#pragma unroll
+      for (int i = 0; i < NT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(wf[i]) : "v"(wo[kk][i] + slot) : "memory");
+    };
+    // wait until at most PENDING LDS reads are outstanding; the fragments are tied to the statement so that no MFMA on
+    // them can be scheduled above it
+    auto wait_frags = [&](auto pending, half8 (&xf)[MT], half8 (&wf)[NT]) {
+      static_assert(MT <= 4 && NT <= 4, "operand list");
+      if constexpr (MT == 4 && NT == 4)
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3])
+                     : "n"(decltype(pending)::value) : "memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(wf[0]), "+v"(wf[1]) : "n"(decltype(pending)::value) : "memory");
+    };
+    auto mfma_half = [&](half8 (&xf)[MT], half8 (&wf)[NT]) {
 #ifndef ABL_NOMFMA
 #pragma unroll
       for (int i = 0; i < NT; ++i)
@@ -236,6 +263,31 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[0][j][1] += (float)xf[j][0];
 #endif
+    };
+    // Measured (tools/fixed_cost_probe2.sh, loads ablated): 0.44 us per 128x128x64 step = 1.23 PFLOP/s chip-wide, the
+    // rate an MFMA-dense loop on random data sustains at the clock the chip holds under that load (MI355X_MICROARCH.md,
+    // DVFS); spreading the reads one per MFMA gap instead of in a burst changed nothing.
+    using std::integral_constant;
+    __builtin_amdgcn_s_barrier();                // step 0 has landed
+    asm volatile("" ::: "memory");
+    if (nk > 0) read_half(0, 0, xa, wa);
+    for (int k = 0; k < nk_loop; ++k) {
+      const bool act = k < nk;                   // the shorter half (odd step count) idles through the last barrier
+      if (act) {
+        read_half(k, 1, xb, wb);
+        wait_frags(integral_constant<int, MT + NT>{}, xa, wa);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(xa, wa);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_frags(integral_constant<int, 0>{}, xb, wb);
+      }
+      if (k + 1 < nk_loop) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (k + 1 < nk) read_half(k + 1, 0, xa, wa);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (act) mfma_half(xb, wb);
     }
   }
 
@@ -257,8 +309,11 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
         for (int j = 0; j < MT; ++j) acc[i][j] += red[((i * MT + j) * 4 + wave) * 64 + lane];
     }
   }
-  igemm_epilogue<MT, NT, TMW, TNW, BN>(a, acc, m0, n0, wm, wn, lane, batch, ks_id, reinterpret_cast<float*>(smem_raw),
-                                       !loader && team == 0);
+#ifdef ABL_NOEPI
+  if (a.alpha == 12345.f)                        // harness probe: the launch without its epilogue (never true)
+#endif
+  igemm_epilogue<MT, NT, TMW, TNW, BN, (256 + 64 * IG2_LOADERS) * HALVES>(a, acc, m0, n0, wm, wn, lane, batch, ks_id,
+                                                                        reinterpret_cast<float*>(smem_raw), !loader && team == 0);
 #endif
 }
 

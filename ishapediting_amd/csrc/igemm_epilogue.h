@@ -6,65 +6,161 @@
 #pragma once
 #include "common.h"
 #include "gn_bwd_terms.h"
+#include <type_traits>
 
-template <int MT, int NT, int TMW, int TNW, int BN>
+// STAGE_THREADS > 0 (the LDS-DMA kernels; = threads of the workgroup, all of which call this function): fp16 outputs
+// of an unsplit launch are collected in LDS and leave as full 16-byte-per-lane row segments written by every wave,
+// loader waves included.  The fragment layout's own stores are 8 bytes per lane over 16 rows: issue-bound, ~9 us of
+// a 128^2-map launch against ~2 us this way (tools/fixed_cost_probe2.sh).  Values and their order of evaluation are
+// unchanged, so results are bit-identical to the direct path.
+template <int MT, int NT, int TMW, int TNW, int BN, int STAGE_THREADS = 0>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[NT][MT], int m0, int n0, int wm, int wn,
                                                int lane, int batch, int ks_id, float* lds_f, bool active = true) {
   // `active` = false: a loader wave of a producer/consumer kernel -- it owns no outputs but must take part in the
   // workgroup barriers of the statistics reduction below
+  // fields used inside the unrolled tile loops, read once: left as `a.field` the compiler kept {alpha, out_mode, stat_out}
+  // in a private copy of the argument block and re-read it from scratch behind an s_waitcnt vmcnt(0) before every tile
+  // -- each output store then waited for the previous one to be acknowledged
+  const float alpha = a.alpha;
+  const int out_mode = a.out_mode;
+  const float* const bias = a.bias;
+  const float* const bias2 = a.bias2;
+  const half_t* const resp = a.res;
   const int HW = a.H * a.W;
+  constexpr int BM_T = 2 * TMW;                  // rows of the workgroup tile
+  constexpr int LDT = BN + 8;                    // staged-tile row pitch in halfs (conflict-free 8-byte fragment writes)
+  half_t* const out16 = (half_t*)a.out + (long long)batch * a.bso;
+  const bool staged = STAGE_THREADS > 0 && out_mode == IG_OUT_F16 && a.ksplit == 1 && (a.N & 7) == 0 && (a.ldo & 7) == 0 &&
+                      (reinterpret_cast<unsigned long long>(out16) & 15) == 0;
+  half_t* const tile = reinterpret_cast<half_t*>(lds_f);
+  if (staged) __syncthreads();                   // the K loop's LDS tiles are dead from here on
   float ssum[NT][4], ssq[NT][4];
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int c = 0; c < 4; ++c) { ssum[i][c] = 0.f; ssq[i][c] = 0.f; }
+  // One loop over the wave's MT x NT fragment tiles per output mode, the mode tested OUTSIDE the loop: with the tests
+  // inside, every tile jumped over the other modes' code and the launch paid an instruction-cache miss per jump
+  // (~4 us of a 128x128-tile launch, tools/fixed_cost_probe3.sh).
+  auto col = [&](int i) { return n0 + wn * TNW + i * 16 + (lane >> 4) * 4; };
+  auto row = [&](int j) { return m0 + wm * TMW + j * 16 + (lane & 15); };
+  if (!active) {
+    // nothing to compute
+  } else if (a.ksplit > 1) {
+    // a K slice: the fp32 partial tile goes to the workspace as it is
 #pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    if (!active) break;
-    const int m = m0 + wm * TMW + j * 16 + (lane & 15);
-    int n_img = 0, py = 0, px = 0;
-    if (a.res_ups || a.out_mode == IG_OUT_NCHW_F32) {
-      n_img = m / HW;
-      const int p = m - n_img * HW;
-      py = p / a.W;
-      px = p - py * a.W;
+    for (int j = 0; j < MT; ++j) {
+      float* dst = a.ws + (((long long)ks_id * a.nbatch + batch) * a.M + row(j)) * a.N;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        if (col(i) < a.N) *reinterpret_cast<f32x4*>(dst + col(i)) = acc[i][j];
     }
+  } else {
+    // operands of the whole tile first (all loads in flight together), then the arithmetic
+    f32x4 b1[NT], b2[NT];
+    half4 rr[MT][NT];
+    int pimg[MT], ppy[MT], ppx[MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const int n = n0 + wn * TNW + i * 16 + (lane >> 4) * 4;
-      if (n >= a.N) continue;
-      f32x4 v = acc[i][j];
-      if (a.ksplit > 1) {
-        float* dst = a.ws + (((long long)ks_id * a.nbatch + batch) * a.M + m) * a.N + n;
-        *reinterpret_cast<f32x4*>(dst) = v;
-        continue;
+      b1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      b2[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (col(i) < a.N) {
+        if (bias) b1[i] = *reinterpret_cast<const f32x4*>(bias + col(i));
+        if (bias2) b2[i] = *reinterpret_cast<const f32x4*>(bias2 + col(i));
       }
-      v *= a.alpha;
-      if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-      if (a.bias2) v += *reinterpret_cast<const f32x4*>(a.bias2 + n);
-      if (a.res) {
-        long long rrow = a.res_ups ? ((long long)n_img * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1)) : m;
-        half4 r = *reinterpret_cast<const half4*>(a.res + rrow * a.ldr + n);
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int m = row(j);
+      pimg[j] = 0; ppy[j] = 0; ppx[j] = 0;
+      if (a.res_ups || out_mode == IG_OUT_NCHW_F32) {
+        pimg[j] = m / HW;
+        const int p = m - pimg[j] * HW;
+        ppy[j] = p / a.W;
+        ppx[j] = p - ppy[j] * a.W;
+      }
+      if (resp) {
+        const long long rrow = a.res_ups ? ((long long)pimg[j] * (HW >> 2) + (ppy[j] >> 1) * (a.W >> 1) + (ppx[j] >> 1)) : m;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+          if (col(i) < a.N) rr[j][i] = *reinterpret_cast<const half4*>(resp + rrow * a.ldr + col(i));
+      }
+    }
+    // alpha * acc (+ bias) (+ bias2) (+ residual), in this order
+    auto value = [&](int i, int j) {
+      f32x4 v = acc[i][j];
+      v *= alpha;
+      if (bias) v += b1[i];
+      if (bias2) v += b2[i];
+      if (resp) {
+        const half4 r = rr[j][i];
         v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
       }
-      if (a.out_mode == IG_OUT_F16) {
-        half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        *reinterpret_cast<half4*>((half_t*)a.out + (long long)batch * a.bso + (long long)m * a.ldo + n) = o;
-        if (a.stat_out) {
+      return v;
+    };
+    if (out_mode == IG_OUT_F16) {
+      // two copies of the loop (LDS tile / straight to memory) so that each uses its own address space's stores
+      auto f16_tiles = [&](auto to_lds) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { float f = (float)o[c]; ssum[i][c] += f; ssq[i][c] += f * f; }
+        for (int j = 0; j < MT; ++j) {
+#pragma unroll
+          for (int i = 0; i < NT; ++i) {
+            if (col(i) >= a.N) continue;
+            const f32x4 v = value(i, j);
+            const half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            if constexpr (decltype(to_lds)::value) *reinterpret_cast<half4*>(tile + (row(j) - m0) * LDT + (col(i) - n0)) = o;
+            else *reinterpret_cast<half4*>(out16 + (long long)row(j) * a.ldo + col(i)) = o;
+            // the stored (rounded) values: GroupNorm statistics of the next layer / operand of the backward sums below
+            const f32x4 fo = {(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { ssum[i][c] += fo[c]; ssq[i][c] += fo[c] * fo[c]; }
+            acc[i][j] = fo;
+          }
         }
-        if (a.gb_x) acc[i][j] = (f32x4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};   // the stored gradient, for the pass below
-      } else if (a.out_mode == IG_OUT_F32) {
-        *reinterpret_cast<f32x4*>((float*)a.out + (long long)batch * a.bso + (long long)m * a.ldo + n) = v;
-      } else {
-        float* o = (float*)a.out + ((long long)n_img * a.N + n) * HW + (py * a.W + px);
+      };
+      if (staged) f16_tiles(std::true_type{});
+      else f16_tiles(std::false_type{});
+    } else if (out_mode == IG_OUT_F32) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[(long long)r * HW] = v[r];
+      for (int j = 0; j < MT; ++j) {
+        float* const drow = (float*)a.out + (long long)batch * a.bso + (long long)row(j) * a.ldo;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+          if (col(i) < a.N) *reinterpret_cast<f32x4*>(drow + col(i)) = value(i, j);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          if (col(i) >= a.N) continue;
+          const f32x4 v = value(i, j);
+          float* o = (float*)a.out + ((long long)pimg[j] * a.N + col(i)) * HW + (ppy[j] * a.W + ppx[j]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[(long long)r * HW] = v[r];
+        }
       }
     }
   }
+  if (staged) {
+    __syncthreads();
+    constexpr int CPRW = BN / 8;                 // 16-byte chunks per tile row
+    for (int c = threadIdx.x; c < BM_T * CPRW; c += STAGE_THREADS) {
+      const int row = c / CPRW, ch = c - row * CPRW;
+      const int n = n0 + ch * 8;
+#ifdef ABL_EPI_NOSTORE
+      if (n < a.N && alpha == 12345.f)
+#else
+      if (n < a.N)
+#endif
+        *reinterpret_cast<half8*>(out16 + (long long)(m0 + row) * a.ldo + n) = *reinterpret_cast<const half8*>(tile + row * LDT + ch * 8);
+    }
+  }
   if (a.gb_x && a.ksplit == 1 && active) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { ssum[i][c] = 0.f; ssq[i][c] = 0.f; }
     // GroupNorm-backward sums of this gradient tile (see common.h): channel parameters once per i, pixels over j
     const int n_img = m0 / HW;
     const int cpg = a.N / 32;

@@ -11,6 +11,14 @@
 hipEvent_t g_igemm_prof_start = nullptr, g_igemm_prof_stop = nullptr;
 void ishap_set_error(const std::string& m) { fprintf(stderr, "ERR %s\n", m.c_str()); }
 
+__global__ void empty_kernel(int* p) { if (p) *p = 0; }
+// floor of an epilogue: every workgroup writes `per_wg` bytes as 16-byte stores, nothing else
+__global__ void write_kernel(half8* out, int per_wg) {
+  half8 v = {1, 2, 3, 4, 5, 6, 7, 8};
+  half8* o = out + (size_t)blockIdx.x * (per_wg / 16);
+  for (int c = threadIdx.x; c < per_wg / 16; c += blockDim.x) o[c] = v;
+}
+
 int main(int argc, char** argv) {
   int H = argc > 1 ? atoi(argv[1]) : 128, Cin = argc > 2 ? atoi(argv[2]) : 256, Cout = argc > 3 ? atoi(argv[3]) : 256;
   int big = argc > 4 ? atoi(argv[4]) : 1, ksplit = argc > 5 ? atoi(argv[5]) : 1, gen = argc > 6 ? atoi(argv[6]) : 2;
@@ -63,6 +71,27 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 5; ++i) run();
   hipDeviceSynchronize();
   const int it = 50;
+  if (getenv("BI_EMPTY")) {                       // floor of a dependent launch in this harness
+    const int lds = atoi(getenv("BI_EMPTY"));
+    hipFuncSetAttribute((const void*)empty_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < it; ++i) hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(512), lds, 0, (int*)nullptr);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms0; hipEventElapsedTime(&ms0, e0, e1);
+    printf("empty kernel, 256 x 512 threads, %d B LDS: %.2f us per launch\n", lds, ms0 * 1e3 / it);
+    for (int per = 8192; per <= 65536; per *= 2) {
+      half8* buf; hipMalloc(&buf, (size_t)256 * per);
+      for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(write_kernel, dim3(256), dim3(512), 0, 0, buf, per);
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < it; ++i) hipLaunchKernelGGL(write_kernel, dim3(256), dim3(512), 0, 0, buf, per);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms0, e0, e1);
+      printf("write kernel, 256 WGs x %d B: %.2f us per launch\n", per, ms0 * 1e3 / it);
+      hipFree(buf);
+    }
+  }
   hipEventRecord(e0, 0);
   for (int i = 0; i < it; ++i) run();
   hipEventRecord(e1, 0);
