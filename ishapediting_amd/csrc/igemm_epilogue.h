@@ -56,9 +56,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         if (col(i) < a.N) *reinterpret_cast<f32x4*>(dst + col(i)) = acc[i][j];
     }
   } else {
-    // operands of the whole tile first (all loads in flight together), then the arithmetic
+    // per-channel operands of the whole tile first; the residual is fetched one 16-pixel row of fragments ahead of the
+    // arithmetic (all of it at once cost 32 more live registers and spilled)
     f32x4 b1[NT], b2[NT];
-    half4 rr[MT][NT];
+    half4 rr[2][NT];
     int pimg[MT], ppy[MT], ppx[MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -79,13 +80,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         ppy[j] = p / a.W;
         ppx[j] = p - ppy[j] * a.W;
       }
-      if (resp) {
-        const long long rrow = a.res_ups ? ((long long)pimg[j] * (HW >> 2) + (ppy[j] >> 1) * (a.W >> 1) + (ppx[j] >> 1)) : m;
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-          if (col(i) < a.N) rr[j][i] = *reinterpret_cast<const half4*>(resp + rrow * a.ldr + col(i));
-      }
     }
+    auto fetch_res = [&](int j) {
+      if (!resp || j >= MT) return;
+      const long long rrow = a.res_ups ? ((long long)pimg[j] * (HW >> 2) + (ppy[j] >> 1) * (a.W >> 1) + (ppx[j] >> 1)) : row(j);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        if (col(i) < a.N) rr[j & 1][i] = *reinterpret_cast<const half4*>(resp + rrow * a.ldr + col(i));
+    };
+    fetch_res(0);
     // alpha * acc (+ bias) (+ bias2) (+ residual), in this order
     auto value = [&](int i, int j) {
       f32x4 v = acc[i][j];
@@ -93,7 +96,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
       if (bias) v += b1[i];
       if (bias2) v += b2[i];
       if (resp) {
-        const half4 r = rr[j][i];
+        const half4 r = rr[j & 1][i];
         v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
       }
       return v;
@@ -103,6 +106,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
       auto f16_tiles = [&](auto to_lds) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
+          fetch_res(j + 1);
 #pragma unroll
           for (int i = 0; i < NT; ++i) {
             if (col(i) >= a.N) continue;
@@ -123,6 +127,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     } else if (out_mode == IG_OUT_F32) {
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
+        fetch_res(j + 1);
         float* const drow = (float*)a.out + (long long)batch * a.bso + (long long)row(j) * a.ldo;
 #pragma unroll
         for (int i = 0; i < NT; ++i)
@@ -131,6 +136,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     } else {
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
+        fetch_res(j + 1);
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
           if (col(i) >= a.N) continue;
