@@ -3,8 +3,9 @@
 // Forward and backward are flash-style: the T x T score matrix never leaves the CU.
 //   forward : one workgroup = 64 queries of one (image, head); online softmax over 64-key tiles; writes a and
 //             lse = m + log(sum) per query.
-//   backward: dQ kernel (same tiling) and dK/dV kernel (one workgroup = 64 keys, loops over query tiles); P is
-//             recomputed from q, k and the saved lse; D_q = sum_d dA*A is produced by the dQ kernel for the dK/dV one.
+//   backward: ONE launch holding two kinds of workgroup -- dQ (same tiling as the forward) and dK/dV (one workgroup =
+//             64 keys, loops over query tiles); P is recomputed from q, k and the saved lse; D_q = sum_d dA*A is
+//             computed by each side for the queries it handles, so the two sides share nothing.
 // All products run on v_mfma_f32_16x16x32_f16.  Operand convention used throughout: for a row-major matrix R[idx][k]
 // (k contiguous) lane l loads R[i0 + (l&15)][k0 + 8*(l>>4) .. +7] -- this is the A fragment when idx is the output row
 // and the B fragment when idx is the output column.  The accumulator holds C[row=(l>>4)*4+r][col=l&15].
@@ -152,12 +153,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // per-lane scalars), dS^T is packed in registers as the B operand of dQ^T = K^T dS^T, and K^T comes from the row-major
 // K tile through the transposed LDS read.  Nothing is staged transposed and nothing round-trips through LDS.
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int n, half_t* sK, half_t* sV) {
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
-  __shared__ __attribute__((aligned(16))) half_t sK[64 * RS];
-  __shared__ __attribute__((aligned(16))) half_t sV[64 * RS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+  const int q0 = blockIdx.x * 64, h = blockIdx.y;
   const int ld = 3 * a.C;
   const int g = lane >> 4, col = lane & 15;
   const half_t* base = a.qkv + (long long)n * a.T * ld + h * 3 * D;
@@ -179,7 +178,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   Dq += __shfl_xor(Dq, 16);
   Dq += __shfl_xor(Dq, 32);                  // D of query `col`, in all four lanes of the column
   const float lse = a.lse[bh * a.T + q];
-  if (g == 0) a.Dbuf[bh * a.T + q] = Dq;
   f32x4 dqt[DS];                             // dQ^T: row d = i*16 + 4g + r, column = this lane's query
 #pragma unroll
   for (int i = 0; i < DS; ++i) dqt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -234,12 +232,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 // owns one key and 16 queries of the tile: P and dS are packed in registers as the B operands of dV^T = dA^T P and
 // dK^T = Q^T dS, whose A operands come from the row-major dA / Q tiles through the transposed LDS read.
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, half_t* sQ, half_t* sA, float* sD) {
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
-  __shared__ __attribute__((aligned(16))) half_t sQ[64 * RS];
-  __shared__ __attribute__((aligned(16))) half_t sA[64 * RS];
+  constexpr int CPR = D / 8, NCH = (64 * CPR + 255) / 256;
+  static_assert(CPR == 8 || CPR == 4, "row sums below reduce over CPR consecutive lanes");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+  const int k0 = blockIdx.x * 64, h = blockIdx.y;
   const int ld = 3 * a.C;
   const int g = lane >> 4, col = lane & 15;
   const half_t* base = a.qkv + (long long)n * a.T * ld + h * 3 * D;
@@ -255,35 +253,47 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   f32x4 dkt[DS], dvt[DS];                    // dK^T / dV^T: row d = i*16 + 4g + r, column = this lane's key
 #pragma unroll
   for (int i = 0; i < DS; ++i) { dkt[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvt[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  TileRegs<D> rq, ra;
-  f32x4 lse_n[4], dq_n[4];                   // lse / D of the prefetched tile's queries sub*16 + 4g + (0..3)
+  // D_q = sum_d dA[q][d] * A[q][d] of the tile's 64 queries is recomputed here from the dA tile this workgroup stages
+  // anyway plus the matching rows of the forward output: the dQ and dK/dV passes then share no data and run as ONE
+  // launch (256 instead of 128 workgroups at T = 1024, one launch floor instead of two).
+  TileRegs<D> rq, ra, ro;
+  f32x4 lse_n[4];                            // lse of the prefetched tile's queries sub*16 + 4g + (0..3)
   const half_t* abase = a.dout + (long long)n * a.T * a.C + h * D;
+  const half_t* obase = a.out + (long long)n * a.T * a.C + h * D;
   const float* lsep = a.lse + bh * a.T + 4 * g;
-  const float* dqp = a.Dbuf + bh * a.T + 4 * g;
   load_tile<D>(base, ld, rq, tid);
   load_tile<D>(abase, a.C, ra, tid);
+  load_tile<D>(obase, a.C, ro, tid);
 #pragma unroll
-  for (int sub = 0; sub < 4; ++sub) {
-    lse_n[sub] = *reinterpret_cast<const f32x4*>(lsep + sub * 16);
-    dq_n[sub] = *reinterpret_cast<const f32x4*>(dqp + sub * 16);
-  }
+  for (int sub = 0; sub < 4; ++sub) lse_n[sub] = *reinterpret_cast<const f32x4*>(lsep + sub * 16);
   for (int qt = 0; qt < a.T; qt += 64) {
     __syncthreads();
     store_tile<D>(rq, sQ, tid);
     store_tile<D>(ra, sA, tid);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {          // chunk c = tid + 256 i holds 8 halfs of row c / CPR: CPR consecutive lanes share a row
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dot += (float)ra.v[i][j] * (float)ro.v[i][j];
+      dot += __shfl_xor(dot, 1);
+      dot += __shfl_xor(dot, 2);
+      if (CPR == 8) dot += __shfl_xor(dot, 4);
+      const int c = tid + i * 256;
+      if (c < 64 * CPR && c % CPR == 0) sD[c / CPR] = dot;
+    }
     f32x4 lse_c[4], dq_c[4];
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub) { lse_c[sub] = lse_n[sub]; dq_c[sub] = dq_n[sub]; }
+    for (int sub = 0; sub < 4; ++sub) lse_c[sub] = lse_n[sub];
     if (qt + 64 < a.T) {
       load_tile<D>(base + (long long)(qt + 64) * ld, ld, rq, tid);
       load_tile<D>(abase + (long long)(qt + 64) * a.C, a.C, ra, tid);
+      load_tile<D>(obase + (long long)(qt + 64) * a.C, a.C, ro, tid);
 #pragma unroll
-      for (int sub = 0; sub < 4; ++sub) {
-        lse_n[sub] = *reinterpret_cast<const f32x4*>(lsep + qt + 64 + sub * 16);
-        dq_n[sub] = *reinterpret_cast<const f32x4*>(dqp + qt + 64 + sub * 16);
-      }
+      for (int sub = 0; sub < 4; ++sub) lse_n[sub] = *reinterpret_cast<const f32x4*>(lsep + qt + 64 + sub * 16);
     }
     __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) dq_c[sub] = *reinterpret_cast<const f32x4*>(sD + sub * 16 + 4 * g);
     half8 pb[2], sb[2];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
@@ -323,6 +333,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   }
 }
 
+// blockIdx.z = 2 n + role: role 0 = dQ of 64 queries, role 1 = dK/dV of 64 keys (independent of each other, see above)
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
+  constexpr int RS = D + 8;
+  __shared__ __attribute__((aligned(16))) half_t s0[64 * RS];
+  __shared__ __attribute__((aligned(16))) half_t s1[64 * RS];
+  __shared__ __attribute__((aligned(16))) float sD[64];
+  const int n = blockIdx.z >> 1;
+  if ((blockIdx.z & 1) == 0) attn_bwd_dq_body<D>(a, n, s0, s1);
+  else attn_bwd_dkv_body<D>(a, n, s0, s1, sD);
+}
+
 static int check_attn(const AttnArgs& a) {
   ISHAP_REQUIRE(a.T % 64 == 0 && a.T >= 64, "attention: tokens must be a multiple of 64");
   ISHAP_REQUIRE(a.C == a.heads * a.d && (a.d == 64 || a.d == 32), "attention: head width 64 or 32");
@@ -340,14 +362,9 @@ int attn_forward_launch(const AttnArgs& a, hipStream_t s) {
 
 int attn_backward_launch(const AttnArgs& a, hipStream_t s) {
   ISHAP_TRY(check_attn(a));
-  dim3 g(a.T / 64, a.heads, a.N);
-  if (a.d == 64) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, g, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, g, dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, g, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, g, dim3(256), 0, s, a);
-  }
+  dim3 g(a.T / 64, a.heads, a.N * 2);
+  if (a.d == 64) hipLaunchKernelGGL(attn_bwd_kernel<64>, g, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(attn_bwd_kernel<32>, g, dim3(256), 0, s, a);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
