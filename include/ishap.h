@@ -132,17 +132,23 @@ typedef struct {
   float voxel;          /* 2 / shape_resolution */
   float cof;
   int l1;               /* loss_type == 'l1' */
-  unsigned char* touched; /* device scratch [3*W*W] */
+  unsigned char* touched; /* device scratch [3*W*W], 3*W*W % 4 == 0: bit 0 = the reference's rounded-texel sets, bit 1 = target footprints */
   int* nmask;             /* device scratch [1] */
   void* acc;              /* device scratch, 16 bytes (two 64-bit fixed-point loss sums) */
   void* grad_fx;          /* device scratch, W*W*ld*8 bytes: the gradient scatter accumulates in 64-bit fixed point so
                            * that repeated edits are bitwise identical (integer atomics commute) */
+  unsigned char* chan_weight; /* device scratch [3*ld] bytes: inverse of chmap, filled by ishap_drag_setup */
 } ishap_drag_args;
-/* once per edit: rounded-texel bitmap and complement count (drag_utils.py:322-334) */
+/* once per edit: rounded-texel bitmap and complement count (drag_utils.py:322-334); also zeroes acc and grad_fx, which
+ * every loss call below expects zero on entry and leaves zero on return */
 int ishap_drag_setup(const ishap_drag_args* a, void* stream);
 /* per step: loss (device float[1]) and d loss / d tap as fp32 NHWC [W*W][ld] (drag_utils.py:355-383) */
 int ishap_drag_loss_grad(const ishap_drag_args* a, const void* edit_nhwc_f16, const void* orig_nhwc_f16,
                          float* grad_nhwc, float* loss, void* stream);
+/* the same followed by ishap_grad_to_scaled_f16 (below) on that gradient, as three launches instead of ten: the form the
+ * guided step uses (drag_utils.py:355-383 up to loss.backward()) */
+int ishap_drag_loss_cotangent(const ishap_drag_args* a, const void* edit_nhwc_f16, const void* orig_nhwc_f16,
+                              float* grad_nhwc, float* loss, void* cot_f16, unsigned* bits, float* scale2, void* stream);
 /* fp32 gradient -> fp16 cotangent times a power-of-two loss scale picked from max|g| on the device;
  * bits: device scratch uint32[1]; scale2: device float[2] = {scale, 1/scale} */
 int ishap_grad_to_scaled_f16(const float* grad, void* out_f16, unsigned* bits, float* scale2, long long numel,

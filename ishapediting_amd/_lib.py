@@ -32,7 +32,7 @@ class StepCoefs(C.Structure):
 class DragArgsC(C.Structure):
     _fields_ = [("W", C.c_int), ("ld", C.c_int), ("Cc", C.c_int), ("chmap", c_void_p), ("sources", c_void_p),
                 ("targets", c_void_p), ("B", C.c_int), ("r", C.c_int), ("voxel", C.c_float), ("cof", C.c_float),
-                ("l1", C.c_int), ("touched", c_void_p), ("nmask", c_void_p), ("acc", c_void_p), ("grad_fx", c_void_p)]
+                ("l1", C.c_int), ("touched", c_void_p), ("nmask", c_void_p), ("acc", c_void_p), ("grad_fx", c_void_p), ("chan_weight", c_void_p)]
 
 
 class DecoderWeightsC(C.Structure):
@@ -72,6 +72,8 @@ SYMBOLS = {
     "ishap_axpby": (C.c_int, [c_void_p, c_void_p, C.c_float, C.c_float, C.c_longlong, c_void_p, c_void_p]),
     "ishap_drag_setup": (C.c_int, [C.POINTER(DragArgsC), c_void_p]),
     "ishap_drag_loss_grad": (C.c_int, [C.POINTER(DragArgsC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ishap_drag_loss_cotangent": (C.c_int, [C.POINTER(DragArgsC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p]),
     "ishap_grad_to_scaled_f16": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p]),
     "ishap_planes_prepare": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p]),
     "ishap_triplane_decode_points": (C.c_int, [c_void_p, C.c_int, C.POINTER(DecoderWeightsC), c_void_p, C.c_longlong,

@@ -40,11 +40,13 @@ int ishap_axpby(const float* x, const float* y, float a, float b, long long nume
 }
 
 static int fill_drag(const ishap_drag_args* a, DragArgs& d) {
-  ISHAP_REQUIRE(a && a->chmap && a->sources && a->targets && a->touched && a->nmask && a->acc && a->grad_fx, "null argument");
+  ISHAP_REQUIRE(a && a->chmap && a->sources && a->targets && a->touched && a->nmask && a->acc && a->grad_fx && a->chan_weight,
+                "null argument");
   ISHAP_REQUIRE(a->W > 1 && a->B >= 1 && a->r >= 0 && a->Cc >= 1 && a->ld >= 1, "drag dims");
   d.W = a->W; d.ld = a->ld; d.Cc = a->Cc; d.chmap = a->chmap; d.sources = a->sources; d.targets = a->targets;
   d.B = a->B; d.r = a->r; d.voxel = a->voxel; d.cof = a->cof; d.l1 = a->l1;
   d.touched = a->touched; d.nmask = a->nmask; d.acc = (long long*)a->acc; d.gfx = (long long*)a->grad_fx;
+  d.chw = a->chan_weight;
   return 0;
 }
 
@@ -61,6 +63,15 @@ int ishap_drag_loss_grad(const ishap_drag_args* a, const void* edit, const void*
   ISHAP_REQUIRE(edit && orig && grad && loss, "null argument");
   d.edit = (const half_t*)edit; d.orig = (const half_t*)orig; d.grad = grad; d.loss = loss;
   return drag_loss_grad_launch(d, (hipStream_t)stream);
+}
+
+int ishap_drag_loss_cotangent(const ishap_drag_args* a, const void* edit, const void* orig, float* grad, float* loss,
+                              void* cot_f16, unsigned* bits, float* scale2, void* stream) {
+  DragArgs d;
+  ISHAP_TRY(fill_drag(a, d));
+  ISHAP_REQUIRE(edit && orig && grad && loss && cot_f16 && bits && scale2, "null argument");
+  d.edit = (const half_t*)edit; d.orig = (const half_t*)orig; d.grad = grad; d.loss = loss;
+  return drag_loss_cotangent_launch(d, (half_t*)cot_f16, bits, scale2, (hipStream_t)stream);
 }
 
 int ishap_grad_to_scaled_f16(const float* grad, void* out_f16, unsigned* bits, float* scale2, long long numel,

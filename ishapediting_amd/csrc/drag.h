@@ -15,6 +15,7 @@ struct DragArgs {
   int l1 = 0;
   unsigned char* touched = nullptr;  // [3][W][W]
   int* nmask = nullptr;              // [1]
+  unsigned char* chw = nullptr;      // [3][ld]: (plane, c) pairs mapped onto each tap channel (set up by drag_setup_launch)
   float* grad = nullptr;             // fp32 [W*W][ld] (d loss / d tap)
   long long* gfx = nullptr;          // scratch [W*W][ld]: the scatter accumulates here in 64-bit fixed point (DRAG_FX_SCALE)
   long long* acc = nullptr;          // [2] loss sums, 64-bit fixed point (DRAG_ACC_SCALE)
@@ -25,4 +26,5 @@ constexpr float DRAG_FX_SCALE = 17592186044416.f;    // 2^44: |sum| < 5e5, resol
 constexpr float DRAG_ACC_SCALE = 16777216.f;         // 2^24
 int drag_setup_launch(const DragArgs& a, hipStream_t s);        // touched bitmap + mask count (once per edit)
 int drag_loss_grad_launch(const DragArgs& a, hipStream_t s);
+int drag_loss_cotangent_launch(const DragArgs& a, half_t* cot, unsigned* bits, float* scale2, hipStream_t s);
 int grad_to_scaled_f16_launch(const float* g, half_t* o, unsigned* bits, float* scale2, long long n, hipStream_t s);

@@ -102,6 +102,7 @@ class DragKernels:
         self.Cc = self.chmap.shape[1]
         self.touched = th.zeros(3 * W * W, dtype=th.uint8, device=self.device)
         self.nmask = th.zeros(1, dtype=th.int32, device=self.device)
+        self.chan_weight = th.zeros(3 * ld, dtype=th.uint8, device=self.device)
         self.acc = th.zeros(2, dtype=th.int64, device=self.device)
         self.gfx = th.zeros(W * W * ld, dtype=th.int64, device=self.device)     # fixed-point scatter scratch
         self.grad = th.empty((W * W, ld), dtype=th.float32, device=self.device)
@@ -116,7 +117,8 @@ class DragKernels:
     def _args(self) -> _lib.DragArgsC:
         return _lib.DragArgsC(self.W, self.ld, self.Cc, self.chmap.data_ptr(), self.sources.data_ptr(),
                               self.targets.data_ptr(), self.sources.shape[0], self.r, self.voxel, float(self.cof),
-                              self.l1, self.touched.data_ptr(), self.nmask.data_ptr(), self.acc.data_ptr(), self.gfx.data_ptr())
+                              self.l1, self.touched.data_ptr(), self.nmask.data_ptr(), self.acc.data_ptr(), self.gfx.data_ptr(),
+                              self.chan_weight.data_ptr())
 
     def setup(self, sources, targets, cof: float):
         def pts(v):
@@ -139,6 +141,16 @@ class DragKernels:
     def loss_grad(self, edit: th.Tensor, orig: th.Tensor):
         assert edit.dtype == th.float16 and orig.dtype == th.float16 and edit.is_contiguous() and orig.is_contiguous()
         return self.loss_grad_ptr(edit.data_ptr(), orig.data_ptr())
+
+    def loss_cotangent_ptr(self, edit_ptr: int, orig_ptr: int, loss_out=None):
+        """loss + gradient + scaled fp16 cotangent in one call (three launches); `loss_out`: a device float to write the loss to."""
+        a = self._args()
+        loss = self.loss if loss_out is None else loss_out
+        with th.cuda.device(self.device):
+            _lib.check(self._L.ishap_drag_loss_cotangent(C.byref(a), edit_ptr, orig_ptr, self.grad.data_ptr(), loss.data_ptr(),
+                                                         self.cot.data_ptr(), self.bits.data_ptr(), self.scale2.data_ptr(),
+                                                         _lib.stream_ptr(self.device)))
+        return self.cot, self.scale2
 
     def scaled_cotangent(self):
         """fp32 gradient -> fp16 cotangent * 2^k (k from max|g|) so the fp16 backward neither under- nor overflows."""
@@ -315,6 +327,7 @@ class DragStuff:
                          loss_type=self.args.loss_type)
         dk.setup(self.sources, self.targets, cof)
         self._dk = dk
+        losses = th.zeros(self.args.w_time, dtype=th.float32, device=self.device)   # one slot per iteration, no per-step copy
         self.last_losses = []
         L = _lib.lib()
         for i in range(self.args.w_time - 1, -1, -1):
@@ -325,8 +338,7 @@ class DragStuff:
                                                     keep_for_backward=True, want_inter_feat=False,
                                                     noise=self._noise(i, img))
             origin = self.feature_guidance[self.args.w_time - 1 - i]
-            dk.loss_grad_ptr(self.model.tap_ptr(), origin.data_ptr())
-            cot, scale2 = dk.scaled_cotangent()
+            cot, scale2 = dk.loss_cotangent_ptr(self.model.tap_ptr(), origin.data_ptr(), loss_out=losses[i:i + 1])
             grads1 = self.model.backward_input(cot, scale2)           # = img.grad of the reference (:384)
             new = th.empty_like(img)
             with th.cuda.device(self.device):
@@ -334,7 +346,7 @@ class DragStuff:
                                                  grads1.data_ptr(), float(scale), None, img.numel(), new.data_ptr(),
                                                  _lib.stream_ptr(self.device)))
             img = new
-            self.last_losses.append(dk.loss.clone())
+            self.last_losses.append(losses[i:i + 1])
             yield 1 - i / (self.args.w_time - 1.)
         self.mesh = self.get_mesh(img=img, t=stop_time)
 

@@ -156,7 +156,8 @@ def test_drag_loss_gradient_vs_golden(gold, loss_type, cof):
     dk = DragKernels(dev(), W=16, ld=ld, chmap=chmap, r=int(g["r1"]), voxel=float(g["voxel_size"]),
                      loss_type=loss_type)
     dk.setup(g["sources"], g["targets"], cof)
-    grad, loss = dk.loss_grad(edit.to(dev()), orig.to(dev()))
+    e_d, o_d = edit.to(dev()), orig.to(dev())
+    grad, loss = dk.loss_grad(e_d, o_d)
     torch.cuda.synchronize()
     got = grad.cpu()[:, :60].t().reshape(3, 20, 16, 16)
     want = g[f"{loss_type}_cof{cof}_grad"]
@@ -164,8 +165,16 @@ def test_drag_loss_gradient_vs_golden(gold, loss_type, cof):
     setup = O.DragSetup(g["sources"], g["targets"], int(g["r1"]), float(g["voxel_size"]), 16)
     lw = O.drag_loss(T(g["edit"]), T(g["orig"]), setup, cof, loss_type)
     assert abs(float(loss.cpu()) - float(lw)) <= 1e-5 * abs(float(lw)) + 1e-8
+    # the fused form the guided step uses (terms | gather + max | scale) equals the two separate calls bit for bit
+    cot_a, sc_a = dk.scaled_cotangent()
+    cot_a, sc_a, grad_a, loss_a = cot_a.clone(), sc_a.clone(), grad.clone(), loss.clone()
+    slot = torch.zeros(1, dtype=torch.float32, device=dev())
+    cot_b, sc_b = dk.loss_cotangent_ptr(e_d.data_ptr(), o_d.data_ptr(), loss_out=slot)
+    torch.cuda.synchronize()
+    assert torch.equal(cot_a, cot_b) and torch.equal(sc_a, sc_b) and torch.equal(grad_a, dk.grad) and torch.equal(loss_a, slot)
+    assert int(dk.gfx.abs().max()) == 0 and int(dk.acc.abs().max()) == 0      # scratch left zero for the next call
     # mask bitmap equals the reference's complement sets
-    touched = dk.touched.cpu().reshape(3, 16, 16).bool()
+    touched = (dk.touched.cpu().reshape(3, 16, 16) & 1).bool()      # bit 0; bit 1 marks the motion scatter's footprint
     for p in range(3):
         assert torch.equal(~touched[p], setup.masks[p])
 

@@ -1,4 +1,4 @@
-"""From a rocprofv3 kernel_trace.csv: one guided step = the dispatches between two consecutive drag_motion_kernel launches.
+"""From a rocprofv3 kernel_trace.csv: one guided step = the dispatches between two consecutive drag-loss launches (drag_terms_kernel; drag_motion_kernel in older traces).
 Prints, for the median step: wall span, sum of kernel durations, idle (gaps), launches, and the per-kernel breakdown with
 the gap that precedes each kernel.  Usage: step_timeline.py kernel_trace.csv [--list]"""
 import csv
@@ -10,7 +10,7 @@ rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if r[2].startswith("drag_motion_kernel")]
+marks = [i for i, r in enumerate(rows) if r[2].startswith(("drag_terms_kernel", "drag_motion_kernel"))]
 steps = []
 for a, b in zip(marks, marks[1:]):
     seg = rows[a:b]
