@@ -288,7 +288,7 @@ static int drag_terms_launch(const DragArgs& a, unsigned* bits, hipStream_t s) {
   return 0;
 }
 static unsigned gather_blocks(long long n) {
-  static const int cap = [] { const char* e = getenv("ISHAP_DRAG_OUT_BLOCKS"); return e ? atoi(e) : 256; }();
+  static const int cap = [] { const char* e = getenv("ISHAP_DRAG_OUT_BLOCKS"); return e ? atoi(e) : 512; }();
   return (unsigned)std::min<long long>((n / 8 + 255) / 256, cap);
 }
 
