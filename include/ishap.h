@@ -74,6 +74,12 @@ int ishap_unet_copy_tap(const ishap_unet* u, void* dst, void* stream);
  * [N][channels][size][size] (the reference's layout).  Parity tests use it to localise a mismatch to one block. */
 int ishap_unet_block_output(const ishap_unet* u, int group, int index, int* channels, int* size, void* dst_nchw_f16,
                             void* stream);
+/* Optional, ahead of a sampling loop: compute the timestep-embedding products of n timesteps once (timestep_embedding,
+ * time_embed and every ResBlock's emb_layers, gd/unet.py:651,245-250 -- none of them depends on x).  A later
+ * ishap_unet_forward whose timesteps all equal one prepared value reuses its row and skips those four launches; any other
+ * forward computes them as before.  Results are bit-identical either way.  n = 0 drops the prepared rows; loading a
+ * parameter drops them too. */
+int ishap_unet_prepare_timesteps(ishap_unet* u, const float* timesteps, int n, void* stream);
 /* Device bytes the context holds besides the packed weights: activation arena + split-K partials + GroupNorm scratch
  * (SURVEY 8b's ishap_workspace_bytes; the context allocates them itself at create time, sized by dry runs of
  * forward + backward at every batch size 1..max_batch). */

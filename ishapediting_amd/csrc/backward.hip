@@ -68,7 +68,7 @@ static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int spli
   {
     GnBwdArgs g;
     g.x = h1.p; g.stats = sv.stats2; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
-    g.emb = u->d_film + L.emb_off; g.emb_ld = u->film_rows;
+    g.emb = u->film_cur + L.emb_off; g.emb_ld = u->film_cur_ld;
     g.N = h1.N; g.H = h1.H; g.W = h1.W; g.C = L.cout; g.film = 1; g.act = 1; g.gmode = GB_SAME;
     const bool loc = local_gn_bwd(h1.H * h1.W, L.cout, GB_SAME);
     ISHAP_TRY(dgrad_op(e, L.c2, dy, dc, L.cout, loc ? nullptr : &g, loc));

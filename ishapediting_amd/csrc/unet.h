@@ -128,6 +128,15 @@ struct ishap_unet {
   float *emb_w = nullptr, *emb_b = nullptr;   // concatenated emb_layers [film_rows][ted]
   int film_rows = 0;
   float *d_temb = nullptr, *d_e1 = nullptr, *d_emb = nullptr, *d_film = nullptr;
+  // FiLM rows of timesteps prepared ahead of a sampling loop (ishap_unet_prepare_timesteps): a forward whose timesteps
+  // all equal one prepared value reads its row (stride 0 over the batch) and skips the four embedding launches, among
+  // them the GEMV that streams the 168 MB of emb_layers weights
+  float* film_cache = nullptr;
+  size_t film_cache_rows = 0;
+  std::vector<float> film_cache_ts;
+  float *pc_temb = nullptr, *pc_e1 = nullptr, *pc_emb = nullptr;     // 16-row scratch of the prepare call
+  const float* film_cur = nullptr;   // what the current forward / backward reads: d_film (stride film_rows) or a cache row (stride 0)
+  int film_cur_ld = 0;
   // parameter table
   std::vector<ParamSlot> params;
   std::map<std::string, int> param_index;

@@ -397,13 +397,13 @@ static int res_forward(Exec& e, ResL& L, Tensor x, Tensor& y) {
   c.pend = SlabSrc{};
   ISHAP_ALLOC(c.p, e, h1.numel());
   if (loc_out) {
-    ISHAP_TRY(gn_local_op(e, h1, L.n2, c.p, nullptr, st2, u->d_film + L.emb_off, u->film_rows, 1, 1, 0));
+    ISHAP_TRY(gn_local_op(e, h1, L.n2, c.p, nullptr, st2, u->film_cur + L.emb_off, u->film_cur_ld, 1, 1, 0));
   } else {
     if (!h1.sums) ISHAP_TRY(gn_stats_op(e, h1, st2));
     if (!e.dry) {
       GnApplyArgs g;
       g.x = h1.p; g.out = c.p; g.stats = st2; g.sums = h1.sums; g.stats_out = h1.sums ? st2 : nullptr; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
-      g.emb = u->d_film + L.emb_off; g.emb_ld = u->film_rows;
+      g.emb = u->film_cur + L.emb_off; g.emb_ld = u->film_cur_ld;
       g.N = N; g.H = Ho; g.W = Wo; g.C = L.cout; g.film = 1; g.act = 1;
       ISHAP_TRY(gn_apply_launch(g, e.s));
     }
@@ -519,7 +519,21 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
   u->have_saved = false;
   const int S = cfg.image_size, HW = S * S;
   // ---- timestep embedding -> emb -> every ResBlock's (scale | shift)   (unet.py:651, :245-250) ----
-  if (!dry) {
+  u->film_cur = u->d_film;
+  u->film_cur_ld = u->film_rows;
+  bool prepared = false;
+  if (!dry && !u->film_cache_ts.empty()) {
+    bool same = true;
+    for (int i = 1; i < N; ++i) same = same && ts[i] == ts[0];
+    if (same)
+      for (size_t k = 0; k < u->film_cache_ts.size() && !prepared; ++k)
+        if (u->film_cache_ts[k] == ts[0]) {
+          u->film_cur = u->film_cache + k * (size_t)u->film_rows;
+          u->film_cur_ld = 0;
+          prepared = true;
+        }
+  }
+  if (!dry && !prepared) {
     TsArg ta;
     for (int i = 0; i < 16; ++i) ta.t[i] = i < N ? ts[i] : 0.f;
     ISHAP_TRY(timestep_embedding(ta, u->d_temb, N, cfg.model_channels, s));
@@ -657,6 +671,7 @@ void ishap_unet_destroy(ishap_unet* u) {
   for (auto& a : u->attn) { frc(a.qkv); frc(a.proj); fr(a.n.gamma); fr(a.n.beta); }
   fr(u->te_w0); fr(u->te_b0); fr(u->te_w2); fr(u->te_b2); fr(u->emb_w); fr(u->emb_b);
   fr(u->d_temb); fr(u->d_e1); fr(u->d_emb); fr(u->d_film);
+  fr(u->film_cache); fr(u->pc_temb); fr(u->pc_e1); fr(u->pc_emb);
   fr(u->arena.base); fr(u->ws); fr(u->gn_partial); fr(u->attn_D); fr(u->stat_base);
   delete u;
 }
@@ -684,6 +699,43 @@ int ishap_unet_load_param(ishap_unet* u, const char* name, const float* data, lo
   ISHAP_CHECK_HIP(hipSetDevice(u->device));
   ISHAP_TRY(load_param(u, p, data, (hipStream_t)stream));
   if (!p.loaded) { p.loaded = true; u->n_loaded++; }
+  u->film_cache_ts.clear();            // rows prepared from the previous weights are stale
+  return 0;
+}
+
+// (scale | shift) rows of all ResBlocks for n timesteps, computed once ahead of a sampling loop: forwards at these
+// timesteps then skip timestep_embedding + time_embed + the emb_layers GEMV (gd/unet.py:651 and :245-250 do not depend on
+// x).  n = 0 drops the prepared rows.  Same kernels as the in-forward path, so the values are bit-identical.
+int ishap_unet_prepare_timesteps(ishap_unet* u, const float* ts, int n, void* stream) {
+  ISHAP_REQUIRE(u && (ts || n == 0) && n >= 0 && n <= 4096, "prepare_timesteps arguments");
+  ISHAP_CHECK_HIP(hipSetDevice(u->device));
+  hipStream_t s = (hipStream_t)stream;
+  u->film_cache_ts.clear();
+  if (n == 0) return 0;
+  ISHAP_REQUIRE(u->n_loaded == (int)u->params.size(), "prepare_timesteps before all parameters are loaded");
+  const int mc = u->cfg.model_channels;
+  if ((size_t)n > u->film_cache_rows) {
+    if (u->film_cache) ISHAP_CHECK_HIP(hipFree(u->film_cache));      // hipFree waits for work that may still read it
+    u->film_cache = nullptr;
+    u->film_cache_rows = 0;
+    ISHAP_CHECK_HIP(hipMalloc((void**)&u->film_cache, (size_t)n * u->film_rows * sizeof(float)));
+    u->film_cache_rows = (size_t)n;
+  }
+  if (!u->pc_temb) {
+    ISHAP_CHECK_HIP(hipMalloc((void**)&u->pc_temb, (size_t)16 * mc * sizeof(float)));
+    ISHAP_CHECK_HIP(hipMalloc((void**)&u->pc_e1, (size_t)16 * u->ted * sizeof(float)));
+    ISHAP_CHECK_HIP(hipMalloc((void**)&u->pc_emb, (size_t)16 * u->ted * sizeof(float)));
+  }
+  for (int c0 = 0; c0 < n; c0 += 16) {
+    const int m = std::min(16, n - c0);
+    TsArg ta;
+    for (int i = 0; i < 16; ++i) ta.t[i] = i < m ? ts[c0 + i] : 0.f;
+    ISHAP_TRY(timestep_embedding(ta, u->pc_temb, m, mc, s));
+    ISHAP_TRY(gemv_f32(u->te_w0, u->te_b0, u->pc_temb, u->pc_e1, u->ted, mc, m, 0, s));
+    ISHAP_TRY(gemv_f32(u->te_w2, u->te_b2, u->pc_e1, u->pc_emb, u->ted, u->ted, m, 1, s));
+    ISHAP_TRY(gemv_f32(u->emb_w, u->emb_b, u->pc_emb, u->film_cache + (size_t)c0 * u->film_rows, u->film_rows, u->ted, m, 1, s));
+  }
+  u->film_cache_ts.assign(ts, ts + n);
   return 0;
 }
 

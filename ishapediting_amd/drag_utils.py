@@ -328,6 +328,7 @@ class DragStuff:
         dk.setup(self.sources, self.targets, cof)
         self._dk = dk
         losses = th.zeros(self.args.w_time, dtype=th.float32, device=self.device)   # one slot per iteration, no per-step copy
+        self.diffusion.prepare(self.model, range(self.args.w_time))                 # timestep embeddings of the whole loop, once
         self.last_losses = []
         L = _lib.lib()
         for i in range(self.args.w_time - 1, -1, -1):

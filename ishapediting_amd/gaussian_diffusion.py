@@ -107,6 +107,15 @@ class SpacedDiffusion:
                               f32(self.posterior_mean_coef1), f32(self.posterior_mean_coef2),
                               0.0 if t == 0 else 1.0, int(bool(clip_denoised)), mode, da, db, ds)
 
+    def prepare(self, model, indices, limit: int = 512):
+        """Hand the loop's timesteps to the model ahead of time (UNetModel.prepare_timesteps): the timestep-embedding
+        products do not depend on x, so they are computed once per loop instead of once per step.  Purely an
+        optimisation -- models without the method, or loops longer than `limit`, run as before."""
+        prep = getattr(model, "prepare_timesteps", None)
+        idx = [int(t) for t in indices]
+        if prep is not None and 0 < len(idx) <= limit:
+            prep([self.timestep_map[t] for t in idx])
+
     def _model(self, model, x, t: int, feat_layer: int, **model_kwargs):
         ts = torch.tensor([self.timestep_map[t]] * x.shape[0])      # _WrappedModel, respace.py:122-127
         if feat_layer < 0:
@@ -170,6 +179,7 @@ class SpacedDiffusion:
             device = next(model.parameters()).device
         img = noise if noise is not None else torch.randn(*shape, device=device)
         indices = list(range(self.num_timesteps))[::-1]
+        self.prepare(model, indices)
         if progress:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
@@ -210,6 +220,7 @@ class SpacedDiffusion:
         if device is None:
             device = next(model.parameters()).device
         img = noise if noise is not None else torch.randn(*shape, device=device)
+        self.prepare(model, range(self.num_timesteps))
         for i in list(range(self.num_timesteps))[::-1]:
             out = self.ddim_sample(model, img, i, clip_denoised=clip_denoised, model_kwargs=model_kwargs, eta=eta,
                                    noise=None if step_noise is None else step_noise(i))
@@ -233,6 +244,7 @@ class SpacedDiffusion:
         feat, variance_noise, variance = [], [], []
         x = self._prep(x_0)
         L = _lib.lib()
+        self.prepare(model, range(steps))
         img_inter = [x]
         for i in range(steps):
             cof = np.float32(self.alphas_cumprod[i]) / np.float32(self.alphas_cumprod_prev[i])      # fp32 / fp32, :520

@@ -140,6 +140,14 @@ class UNetModel:
 
     __call__ = forward
 
+    def prepare_timesteps(self, timesteps):
+        """Compute the timestep-dependent FiLM rows of a sampling loop once (they do not depend on x): forwards at these
+        timesteps skip the embedding launches.  An empty list drops them.  Values are bit-identical either way."""
+        ts = [float(t) for t in timesteps]
+        arr = (C.c_float * max(len(ts), 1))(*ts)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ishap_unet_prepare_timesteps(self._h, arr, len(ts), _lib.stream_ptr(self.device)))
+
     def tap_shape(self, feat_layer: int):
         ch, sz = C.c_int(), C.c_int()
         _lib.check(self._L.ishap_unet_tap_shape(self._h, feat_layer, C.byref(ch), C.byref(sz)))

@@ -428,3 +428,24 @@ def test_ddim_sampling_vs_reference_run(gold, eta):
     r = rel(out, g[f"eta{eta}_sample"])
     print(f"ddim eta={eta}: rel {r:.2e}")
     assert r < 2e-2
+
+
+def test_prepared_timesteps_are_bit_identical_to_the_in_forward_embedding():
+    """ishap_unet_prepare_timesteps (the x-independent embedding products of gd/unet.py:651,245-250 computed once per loop)
+    changes no bit of a forward, at batch 1 and at a batch that shares the timestep, and is ignored for other timesteps."""
+    from ishapediting_amd.unet import UNetModel
+    cfg = _cfg_mid()
+    model = UNetModel(cfg, dev(), max_batch=2)
+    model.load_state_dict(synthetic.unet_state_dict(cfg, 5))
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 6, 32, 32), generator=g).to(dev())
+    ref = {t: model(x, [t, t], feat_layer=1)[0].clone() for t in (7.0, 400.0)}
+    ref1 = model(x[:1], [400.0]).clone()
+    model.prepare_timesteps([400.0, 3.0, 19.0])
+    assert torch.equal(model(x, [400.0, 400.0], feat_layer=1)[0], ref[400.0])      # prepared row, stride 0 over the batch
+    assert torch.equal(model(x[:1], [400.0]), ref1)
+    assert torch.equal(model(x, [7.0, 7.0], feat_layer=1)[0], ref[7.0])            # not prepared: computed in the forward
+    mixed = model(x, [400.0, 7.0], feat_layer=1)[0]                                 # different timesteps in one batch
+    assert torch.equal(mixed[0], ref[400.0][0]) and torch.equal(mixed[1], ref[7.0][1])
+    model.prepare_timesteps([])
+    assert torch.equal(model(x, [400.0, 400.0], feat_layer=1)[0], ref[400.0])
