@@ -229,7 +229,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         const float v = lds_f[t] + lds_f[BN * 2 + t];                   // the two wm waves
         const int n_img = m0 / HW;                                        // a tile never straddles images (HW % BM == 0)
         const long long fx = __float2ll_rn(v * ((t & 1) ? scale_q : STAT_SCALE_SUM));
+#ifdef ABL_STAT_COPIES      // harness probe: spread the same-address atomics over ABL_STAT_COPIES copies of the table
+        atomicAdd(reinterpret_cast<unsigned long long*>(sdst + (long long)((m0 / BM_T) % ABL_STAT_COPIES) * a.N * 2 +
+                                                        ((long long)n_img * a.N + n0 + nl) * 2 + (t & 1)),
+#else
         atomicAdd(reinterpret_cast<unsigned long long*>(sdst + ((long long)n_img * a.N + n0 + nl) * 2 + (t & 1)),
+#endif
                   (unsigned long long)fx);
       }
     }

@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
   a.X = X; a.Wt = W; a.out = O; a.M = M; a.N = Cout; a.K = K; a.conv3 = ksize == 3; a.Cin = Cin; a.ldx = Cin; a.ldw = K; a.ldo = Cout;
   a.H = H; a.W = H; a.ksplit = ksplit; a.ws = ws;
   long long* st = nullptr;
-  if (stats) { hipMalloc(&st, (size_t)Cout * 2 * 8); hipMemset(st, 0, (size_t)Cout * 2 * 8); a.stat_out = st; }
+  if (stats) { hipMalloc(&st, (size_t)Cout * 2 * 8 * 64); hipMemset(st, 0, (size_t)Cout * 2 * 8 * 64); a.stat_out = st; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int mt = ksplit;                          // gen 4 (skinny kernel): argument 5 is MT (pixels per workgroup / 16)
   if (gen == 4 || gen == 5) { a.ksplit = 1; }

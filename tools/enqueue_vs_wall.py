@@ -1,5 +1,6 @@
-"""How far ahead of the GPU does the host run?  Times one C3 edit twice: until the Python call returns (everything
-enqueued) and until the device is idle.  enqueue ~ wall => launch-bound; enqueue << wall => GPU-bound."""
+"""How far ahead of the GPU does the host run?  One C3 edit: the host time at which each guided iteration has been
+enqueued (the generator yields) against the device time at which it has finished (an event recorded at the yield).
+host << device => GPU-bound with the host running ahead; host ~ device => the launches themselves are the limit."""
 import os
 import sys
 import time
@@ -21,13 +22,21 @@ def main():
     bench.one_edit(ds, src, tgt)
     torch.cuda.synchronize()
     for _ in range(3):
+        start = torch.cuda.Event(enable_timing=True)
+        start.record()
         t0 = time.time()
+        host, evs = [], []
         for _ in ds.training(src, tgt, scale=1200, cof=0.4):
-            pass
-        t1 = time.time()
+            host.append(time.time() - t0)
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append(e)
         torch.cuda.synchronize()
-        t2 = time.time()
-        print(f"enqueue {1e3 * (t1 - t0):.1f} ms   wall {1e3 * (t2 - t0):.1f} ms", flush=True)
+        wall = time.time() - t0
+        devt = [start.elapsed_time(e) for e in evs]
+        k = len(host) - 1
+        print(f"iteration {k + 1}: enqueued at {1e3 * host[k]:.1f} ms, finished on the device at {devt[k]:.1f} ms; "
+              f"iteration 10: {1e3 * host[9]:.1f} / {devt[9]:.1f} ms; whole edit {1e3 * wall:.1f} ms", flush=True)
 
 
 if __name__ == "__main__":
