@@ -65,6 +65,13 @@ int ishap_unet_forward(ishap_unet* u, const float* x, const float* timesteps, in
 int ishap_unet_tap_shape(const ishap_unet* u, int feat_layer, int* channels, int* size);
 /* device pointer of the resident tap of the last forward: NHWC fp16 [N][S_tap*S_tap][C_tap] */
 const void* ishap_unet_tap_ptr(const ishap_unet* u);
+/* keep_for_backward is a bit set: bit 0 = keep what a following backward re-reads; bit 1 (with feat_layer >= 0) = enqueue
+ * everything AFTER the tapped output block (the remaining output blocks and the fp32 head) on a stream owned by the
+ * context, forked from `stream` at the tap.  The drag step needs only the tap for its loss and backward pass
+ * (drag_utils.py:355-384), the model output only for the DDPM update after them (:385-393): the two then run side by side.
+ * `out` is complete on a stream only after ishap_unet_join_tail(u, that stream); the next ishap_unet_forward, a
+ * full-depth backward and ishap_unet_block_output join by themselves. */
+int ishap_unet_join_tail(ishap_unet* u, void* stream);
 /* copy it into a caller buffer of N*S_tap^2*C_tap halfs (the guidance cache of drag_utils.py:275-276, kept
  * on the device in the tap's own layout instead of resized fp32 copies on the host) */
 int ishap_unet_copy_tap(const ishap_unet* u, void* dst, void* stream);

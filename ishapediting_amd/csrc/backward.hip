@@ -182,6 +182,7 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
   int F;
   Tensor g;
   if (cot_out) {
+    if (!dry) ISHAP_TRY(unet_join_tail(u, s));    // full depth: needs the blocks an overlapped forward put on the side stream
     // head backward: out = conv3x3(silu(gn(h)))  (unet.py:612-616,667-669)
     F = n_out - 1;
     const int S = cfg.image_size, opad = u->head.cout_pad;

@@ -155,6 +155,15 @@ struct ishap_unet {
   size_t stat_cap = 0, stat_off = 0, stat_high = 0, stat_fwd_mark = 0;
   int bwd_since_fwd = 0;
   size_t fwd_mark = 0;          // arena offset after the forward (backward scratch goes above it)
+  // Overlapped forward tail (keep_for_backward bit 1): the output blocks after the tap and the head are enqueued on a
+  // stream of the context's own, forked from the caller's stream at the tap, so that they run beside the loss and the
+  // backward pass the caller enqueues next (those need nothing after the tap).  ishap_unet_join_tail orders a stream
+  // behind them; the next forward / a full-depth backward / a block read-out joins by itself.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_tail = nullptr;
+  bool tail_pending = false;
+  float* ws_side = nullptr;          // the side stream's own copies of the shared scratch buffers
+  float* gn_partial_side = nullptr;
   float* attn_D = nullptr;      // backward attention row sums
   size_t attn_D_floats = 0;
 };
@@ -164,6 +173,8 @@ struct Exec {
   hipStream_t s;
   bool dry;
   bool keep = false;   // the forward keeps what a following backward re-reads
+  float* ws = nullptr;          // split-K / GroupNorm-statistics scratch of this launch sequence (null: the context's)
+  float* gn_partial = nullptr;
 };
 // Arena allocation that FAILS THE CALL when the arena sized by the create-time dry runs is exceeded (a null pointer
 // must never reach a kernel): ISHAP_ALLOC(ptr, e, count) inside any function returning an int status.
@@ -187,6 +198,7 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
             long long* stat_out = nullptr, const struct GnBwdArgs* gb = nullptr, const half_t* X2 = nullptr, int ldx2 = 0,
             int K2 = 0, const float* bias2 = nullptr, int ldw = 0, SlabSrc* pend_out = nullptr);
 // small maps (<= 32 x 32): GroupNorm passes run group-local (norm_local.hip), producers gather no statistics
+int unet_join_tail(ishap_unet* u, hipStream_t s);
 bool small_map(int HW);
 bool local_gn(int HW, int C);
 int slab_materialize(Exec& e, Tensor& t);    // add up a pending tensor with the stand-alone reduce kernel (consumers that cannot)

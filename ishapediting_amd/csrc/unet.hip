@@ -305,7 +305,7 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
     return 0;
   }
   ISHAP_REQUIRE(need <= e.u->ws_floats, "split-K workspace too small");
-  a.ws = e.u->ws;
+  a.ws = e.ws ? e.ws : e.u->ws;
   return igemm_launch(a, e.s);
 }
 
@@ -329,7 +329,7 @@ int gn_stats_op(Exec& e, const Tensor& x, float* stats) {
     return 0;
   }
   ISHAP_REQUIRE(need <= e.u->gn_partial_floats, "GroupNorm statistics scratch too small");
-  return gn_stats_launch(x.p, e.u->gn_partial, stats, x.N, x.H * x.W, x.C, e.s);
+  return gn_stats_launch(x.p, e.gn_partial ? e.gn_partial : e.u->gn_partial, stats, x.N, x.H * x.W, x.C, e.s);
 }
 
 // GroupNorm (+FiLM) (+SiLU) (+2x2 pool) of `x` into `out` on a small map: one group-local launch that also adds up `x`
@@ -506,13 +506,42 @@ static int block_forward(Exec& e, BlockL& b, Tensor h, Tensor& out) {
   return 0;
 }
 
+// order `s` behind a forward tail that is still running on the context's side stream (no-op when there is none)
+int unet_join_tail(ishap_unet* u, hipStream_t s) {
+  if (!u->tail_pending) return 0;
+  ISHAP_CHECK_HIP(hipStreamWaitEvent(s, u->ev_tail, 0));
+  u->tail_pending = false;
+  return 0;
+}
+
 int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int feat_layer, float* out,
                       void* inter_feat, int keep, hipStream_t s, bool dry) {
   const ishap_unet_config& cfg = u->cfg;
   ISHAP_REQUIRE(N >= 1 && N <= cfg.max_batch && N <= 16, "batch size outside [1, max_batch]");
   ISHAP_REQUIRE(feat_layer < (int)u->out_blocks.size(), "feat_layer out of range");
   Exec e{u, s, dry};
-  e.keep = keep != 0;
+  e.keep = (keep & 1) != 0;
+  const bool overlap = (keep & 2) != 0 && !dry && feat_layer >= 0 && feat_layer + 1 < (int)u->out_blocks.size();
+  if (!dry) ISHAP_TRY(unet_join_tail(u, s));       // the previous forward's tail still owns the arena it is about to reuse
+  if (overlap && !u->side) {
+    // lowest priority: the tail is throughput work that should fill what the latency-bound chain on the caller's stream
+    // leaves idle, not compete with it for compute units
+    int prio_least = 0, prio_greatest = 0;
+    ISHAP_CHECK_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    static const int prio_env = [] { const char* e = getenv("ISHAP_TAIL_PRIORITY"); return e ? atoi(e) : 1; }();
+    static const unsigned cu_mask_env = [] { const char* e = getenv("ISHAP_TAIL_CU_MASK"); return e ? (unsigned)strtoul(e, nullptr, 16) : 0u; }();
+    if (cu_mask_env) {                 // experiment: confine the tail to a subset of the compute units
+      unsigned mask[8];
+      for (int i = 0; i < 8; ++i) mask[i] = cu_mask_env;
+      ISHAP_CHECK_HIP(hipExtStreamCreateWithCUMask(&u->side, 8, mask));
+    } else {
+      ISHAP_CHECK_HIP(hipStreamCreateWithPriority(&u->side, hipStreamNonBlocking, prio_env ? prio_least : prio_greatest));
+    }
+    ISHAP_CHECK_HIP(hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming));
+    ISHAP_CHECK_HIP(hipEventCreateWithFlags(&u->ev_tail, hipEventDisableTiming));
+    if (u->ws_floats) ISHAP_CHECK_HIP(hipMalloc((void**)&u->ws_side, u->ws_floats * sizeof(float)));
+    ISHAP_CHECK_HIP(hipMalloc((void**)&u->gn_partial_side, std::max<size_t>(u->gn_partial_floats, 64) * sizeof(float)));
+  }
   u->arena.reset();
   u->stat_off = 0;
   if (!dry && u->stat_cap) ISHAP_CHECK_HIP(hipMemsetAsync(u->stat_base, 0, u->stat_cap * sizeof(long long), s));
@@ -577,14 +606,28 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     } else {
       ISHAP_TRY(slab_materialize(e, h));
       cat.sums = (h.sums && skip.sums) ? salloc(e, (size_t)cat.N * cat.C * 2) : nullptr;
-      if (!dry) ISHAP_TRY(concat2(h.p, skip.p, cat.p, cat.rows(), h.C, skip.C, s, h.sums, skip.sums, cat.sums, cat.N));
+      if (!dry) ISHAP_TRY(concat2(h.p, skip.p, cat.p, cat.rows(), h.C, skip.C, e.s, h.sums, skip.sums, cat.sums, cat.N));
     }
     b.cat = cat;
     b.cat.cat_pend = SlabSrc{};
     Tensor y;
     ISHAP_TRY(block_forward(e, b, cat, y));
     h = y;
-    if ((int)i == feat_layer) { u->tap = h; u->tap.pend = SlabSrc{}; }
+    if ((int)i == feat_layer) {
+      u->tap = h;
+      u->tap.pend = SlabSrc{};
+      if (overlap) {
+        // everything below needs only what exists now; whatever the caller enqueues on `s` after this call (loss,
+        // backward) needs nothing of what follows: fork
+        ISHAP_TRY(slab_materialize(e, h));             // the tap is complete on the caller's stream
+        u->tap = h;
+        ISHAP_CHECK_HIP(hipEventRecord(u->ev_fork, s));
+        ISHAP_CHECK_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
+        e.s = u->side;
+        e.ws = u->ws_side;
+        e.gn_partial = u->gn_partial_side;
+      }
+    }
   }
   ISHAP_TRY(slab_materialize(e, h));      // the head's GroupNorm runs on the full-size map (never group-local in the real model)
   u->h_final = h;
@@ -598,15 +641,19 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     g.x = h.p; g.out = hsplit; g.stats = u->head_stats; g.sums = h.sums; g.stats_out = h.sums ? u->head_stats : nullptr;
     g.gamma = u->head_norm.gamma; g.beta = u->head_norm.beta;
     g.N = N; g.H = S; g.W = S; g.C = h.C; g.act = 1; g.split = 1;
-    ISHAP_TRY(gn_apply_launch(g, s));
+    ISHAP_TRY(gn_apply_launch(g, e.s));
   }
   ISHAP_TRY(conv_op(e, hsplit, N, S, S, 3 * h.C, u->head.w, u->head.kpad, 9, cfg.out_channels, u->head.bias, nullptr, 0, out,
                     0, IG_OUT_NCHW_F32, 0, 0));
   if (feat_layer >= 0 && inter_feat && !dry)
     ISHAP_TRY(nhwc_f16_to_nchw(u->tap.p, inter_feat, 0, N, u->tap.C, u->tap.H * u->tap.W, u->tap.C, s));
+  if (e.s != s) {                                      // the tail ran on the side stream
+    ISHAP_CHECK_HIP(hipEventRecord(u->ev_tail, u->side));
+    u->tail_pending = true;
+  }
   u->last_N = N;
   u->last_feat = feat_layer;
-  u->have_saved = keep != 0 && !dry;
+  u->have_saved = (keep & 1) != 0 && !dry;
   u->fwd_mark = u->arena.off;
   u->stat_fwd_mark = u->stat_off;
   u->bwd_since_fwd = 0;
@@ -672,6 +719,10 @@ void ishap_unet_destroy(ishap_unet* u) {
   fr(u->te_w0); fr(u->te_b0); fr(u->te_w2); fr(u->te_b2); fr(u->emb_w); fr(u->emb_b);
   fr(u->d_temb); fr(u->d_e1); fr(u->d_emb); fr(u->d_film);
   fr(u->film_cache); fr(u->pc_temb); fr(u->pc_e1); fr(u->pc_emb);
+  fr(u->ws_side); fr(u->gn_partial_side);
+  if (u->side) (void)hipStreamDestroy(u->side);
+  if (u->ev_fork) (void)hipEventDestroy(u->ev_fork);
+  if (u->ev_tail) (void)hipEventDestroy(u->ev_tail);
   fr(u->arena.base); fr(u->ws); fr(u->gn_partial); fr(u->attn_D); fr(u->stat_base);
   delete u;
 }
@@ -741,6 +792,12 @@ int ishap_unet_prepare_timesteps(ishap_unet* u, const float* ts, int n, void* st
 
 int ishap_unet_params_loaded(const ishap_unet* u) { return u ? u->n_loaded : 0; }
 
+int ishap_unet_join_tail(ishap_unet* u, void* stream) {
+  ISHAP_REQUIRE(u, "null argument");
+  ISHAP_CHECK_HIP(hipSetDevice(u->device));
+  return unet_join_tail(u, (hipStream_t)stream);
+}
+
 int ishap_unet_forward(ishap_unet* u, const float* x, const float* timesteps, int N, int feat_layer, float* out,
                        void* inter_feat, int keep_for_backward, void* stream) {
   ISHAP_REQUIRE(u && x && timesteps && out, "null argument");
@@ -776,6 +833,7 @@ int ishap_unet_block_output(const ishap_unet* u, int group, int index, int* chan
   if (!dst_nchw_f16) return 0;
   ISHAP_REQUIRE(u->have_saved && b->out.p, "block outputs stay resident only after a forward with keep_for_backward=1");
   ISHAP_CHECK_HIP(hipSetDevice(u->device));
+  ISHAP_TRY(unet_join_tail(const_cast<ishap_unet*>(u), (hipStream_t)stream));
   return nhwc_f16_to_nchw(b->out.p, dst_nchw_f16, 0, b->out.N, b->out.C, b->out.H * b->out.W, b->out.C, (hipStream_t)stream);
 }
 

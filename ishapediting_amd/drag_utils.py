@@ -91,6 +91,9 @@ def resize_feat_align(feature, cat_var=True):
     return feature[0][cm.reshape(-1)].reshape(3, -1, feature.shape[2], feature.shape[3]).type(th.float32)
 
 
+_OVERLAP_TAIL = os.environ.get("ISHAP_OVERLAP_TAIL", "0") == "1"
+
+
 class DragKernels:
     """Device state + calls for the drag loss (drag_utils.py:309-334 setup, :355-383 per step)."""
 
@@ -335,12 +338,23 @@ class DragStuff:
             if not self.train_flag:
                 stop_time = i + 1
                 break
+            origin = self.feature_guidance[self.args.w_time - 1 - i]
+            got = {}
+
+            def loss_and_backward():          # needs the tap only
+                cot, scale2 = dk.loss_cotangent_ptr(self.model.tap_ptr(), origin.data_ptr(), loss_out=losses[i:i + 1])
+                got["grad"] = self.model.backward_input(cot, scale2)           # = img.grad of the reference (:384)
+
+            # ISHAP_OVERLAP_TAIL=1 runs loss + backward beside the part of the forward after the tap (p_sample_guidance's
+            # `between`).  Measured on MI355X: no gain (0.205 vs 0.200 s/edit) -- the tail's 128x128-tile convolutions hold
+            # every CU's LDS, so the latency-bound backward chain waits for them instead of filling idle CUs; stream
+            # priorities change nothing and a CU-masked side stream is far slower (0.30 s).  Off by default.
             outs = self.diffusion.p_sample_guidance(self.model, img, i, feat_layer=self.args.feat_layer,
                                                     keep_for_backward=True, want_inter_feat=False,
-                                                    noise=self._noise(i, img))
-            origin = self.feature_guidance[self.args.w_time - 1 - i]
-            cot, scale2 = dk.loss_cotangent_ptr(self.model.tap_ptr(), origin.data_ptr(), loss_out=losses[i:i + 1])
-            grads1 = self.model.backward_input(cot, scale2)           # = img.grad of the reference (:384)
+                                                    noise=self._noise(i, img), between=loss_and_backward if _OVERLAP_TAIL else None)
+            if not _OVERLAP_TAIL:
+                loss_and_backward()
+            grads1 = got["grad"]
             new = th.empty_like(img)
             with th.cuda.device(self.device):
                 _lib.check(L.ishap_guided_update(outs["sample"].data_ptr(), outs["variance"].data_ptr(),

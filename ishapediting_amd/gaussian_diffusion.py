@@ -142,15 +142,24 @@ class SpacedDiffusion:
     # ------------------------------------------------------------------ reference surface
     def p_sample_guidance(self, model, x, t, noise=None, variance=None, variance_noise=None, clip_denoised=True,
                           denoised_fn=None, cond_fn=None, model_kwargs=None, feat_layer=-1, keep_for_backward=False,
-                          want_inter_feat=True):
-        """gaussian_diffusion.py:446-510.  Returns the same dict keys."""
+                          want_inter_feat=True, between=None):
+        """gaussian_diffusion.py:446-510.  Returns the same dict keys.
+        `between`: a callable run after the model call and before the step arithmetic -- the drag loop passes its loss +
+        backward here; the model then runs the part of the network those do not need (everything after the tap) beside
+        them, and the step arithmetic waits for it.  Results are identical with and without it."""
         assert denoised_fn is None and cond_fn is None, "not used on the path"
         ti = self._t_index(t)
         x = self._prep(x)
         kw = dict(model_kwargs or {})
         if hasattr(model, "tap_ptr"):
             kw.update(keep_for_backward=keep_for_backward, want_inter_feat=want_inter_feat)
+            if between is not None and feat_layer >= 0 and hasattr(model, "join_tail"):
+                kw.update(overlap_tail=True)
         mo, inter = self._model(model, x, ti, feat_layer, **kw)
+        if between is not None:
+            between()
+            if kw.get("overlap_tail"):
+                model.join_tail()
         if variance_noise is not None:
             o = self._step(x, mo, ti, self._prep(variance_noise), None, clip_denoised, 2, ("sample", "variance"))
             return {"sample": o["sample"], "inter_feat": inter, "variance": o["variance"]}

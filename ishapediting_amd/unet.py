@@ -116,7 +116,9 @@ class UNetModel:
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, x: torch.Tensor, timesteps, y=None, feat_layer: int = -1, keep_for_backward: bool = False,
-                want_inter_feat: bool = True):
+                want_inter_feat: bool = True, overlap_tail: bool = False):
+        """`overlap_tail` (with a tap): the blocks after the tap and the head run on the context's own stream beside
+        whatever the caller enqueues next (loss, backward); the returned model output is valid only after `join_tail()`."""
         assert y is None, "class conditioning is not on the path"
         assert x.dim() == 4 and x.shape[1] == self.in_channels and x.shape[2] == x.shape[3] == self.image_size
         N = x.shape[0]
@@ -131,7 +133,7 @@ class UNetModel:
             inter = torch.empty((N, ch.value, sz.value, sz.value), dtype=torch.float16, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self._L.ishap_unet_forward(self._h, x.data_ptr(), ts, N, int(feat_layer), out.data_ptr(),
-                                                  _lib.ptr(inter), int(keep_for_backward),
+                                                  _lib.ptr(inter), int(bool(keep_for_backward)) | (2 if overlap_tail else 0),
                                                   _lib.stream_ptr(self.device)))
         self._last_shape = tuple(x.shape)
         if feat_layer < 0:
@@ -139,6 +141,11 @@ class UNetModel:
         return out, inter
 
     __call__ = forward
+
+    def join_tail(self):
+        """Order the current stream behind an overlapped forward tail (no-op when there is none)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ishap_unet_join_tail(self._h, _lib.stream_ptr(self.device)))
 
     def prepare_timesteps(self, timesteps):
         """Compute the timestep-dependent FiLM rows of a sampling loop once (they do not depend on x): forwards at these

@@ -162,6 +162,40 @@ def test_ddpm_step_with_zero_noise_returns_the_mean(ds):
     assert torch.equal(o0["sample"], o0z["sample"])
 
 
+def test_overlapped_forward_tail_changes_no_bit(ds):
+    """The drag step's loss + backward run beside the part of the forward they do not need (the output blocks after the
+    tap and the head, on the context's own stream; `between=` of p_sample_guidance): sample, variance, model output and
+    the input gradient are bitwise those of the plain sequence, twice in a row (the second forward reuses the arena the
+    first tail wrote)."""
+    d, m, dev = ds.diffusion, ds.model, ds.device
+    k = ds.args.feat_layer
+    ch, width = m.tap_shape(k)
+    x = torch.from_numpy(synthetic.latent(4)).to(dev)
+    noise = synthetic.step_noise(9, tuple(x.shape)).to(dev)
+    cot = (torch.randn((1, width * width, ch), generator=torch.Generator().manual_seed(8)) * 1e-2).half().to(dev)
+    scale2 = torch.ones(2, dtype=torch.float32, device=dev)
+    i = 2
+    plain = d.p_sample_guidance(m, x, i, feat_layer=k, keep_for_backward=True, want_inter_feat=False, noise=noise)
+    g_plain = m.backward_input(cot, scale2).clone()
+    for _ in range(2):
+        got = {}
+        over = d.p_sample_guidance(m, x, i, feat_layer=k, keep_for_backward=True, want_inter_feat=False, noise=noise,
+                                   between=lambda: got.update(g=m.backward_input(cot, scale2)))
+        torch.cuda.synchronize()
+        for key in ("sample", "variance", "model_output", "pred_xstart", "mean"):
+            assert torch.equal(plain[key], over[key]), key
+        assert torch.equal(g_plain, got["g"])
+    # a full-depth backward after an overlapped forward joins the tail by itself
+    out = m(x, [float(d.timestep_map[i])], feat_layer=k, keep_for_backward=True, want_inter_feat=False, overlap_tail=True)[0]
+    gfull = m.backward_from_output(torch.ones_like(out) * 1e-3)
+    m.join_tail()
+    torch.cuda.synchronize()
+    out2 = m(x, [float(d.timestep_map[i])], feat_layer=k, keep_for_backward=True, want_inter_feat=False)[0]
+    gfull2 = m.backward_from_output(torch.ones_like(out2) * 1e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(gfull, gfull2)
+
+
 def test_train_triplane_from_a_mesh_file(ds, tmp_path):
     """The public real-shape route at full size (drag_utils.py:401-471) without Open3D: an OBJ file is sampled on the
     device (200 000 points by default), the guided reconstruction runs the full-depth UNet backward every step, and
