@@ -62,13 +62,20 @@ __device__ __forceinline__ half4 lds_read_tr4(const half_t* p) {
 // of a B operand (8 keys of one query per lane) for O^T = V^T P^T -- they never visit LDS.  The MFMA contraction
 // slots (group g = l>>4, j < 8) stand for keys {sub_a*16 + 4g + j, sub_b*16 + 4g + j-4}; the V^T fragment is read
 // with the same assignment by two transposed LDS reads of the row-major V tile (lds_read_tr4).
+// Two TEAMS of four waves share a workgroup's 64 queries: team t takes the key tiles t, t+2, t+4 ... (its own K / V
+// staging buffers, the same barriers) and the two online-softmax states are merged through LDS at the end.  With one
+// four-wave workgroup per CU (T = 1024, 8 heads: 128 workgroups) every global -> LDS -> MFMA round trip of a tile was
+// exposed; two waves per SIMD on interleaved tiles hide them (T = 1024: 19.9 -> ~11 us).
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
   constexpr int VS = D + 16;                 // V row stride: 160-byte rows keep the transposed reads conflict-free
-  __shared__ __attribute__((aligned(16))) half_t sK[64 * RS];
-  __shared__ __attribute__((aligned(16))) half_t sV[64 * VS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) half_t sK2[2][64 * RS];
+  __shared__ __attribute__((aligned(16))) half_t sV2[2][64 * VS];
+  __shared__ float mrg[256][DS * 4 + 2];
+  const int team = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  half_t* const sK = sK2[team];
+  half_t* const sV = sV2[team];
   const int q0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
   const int ld = 3 * a.C;
   const int g = lane >> 4, col = lane & 15;
@@ -82,17 +89,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < DS; ++i) ot[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   TileRegs<D> rk, rv;
-  load_tile<D>(base + D, ld, rk, tid);
-  load_tile<D>(base + 2 * D, ld, rv, tid);
-  for (int kt = 0; kt < a.T; kt += 64) {
+  const int ntile = a.T / 64, niter = (ntile + 1) / 2;       // the same barrier count for both teams
+  if (team < ntile) {
+    load_tile<D>(base + (long long)(team * 64) * ld + D, ld, rk, tid);
+    load_tile<D>(base + (long long)(team * 64) * ld + 2 * D, ld, rv, tid);
+  }
+  for (int it = 0; it < niter; ++it) {
+    const int kt = (2 * it + team) * 64;
+    const bool live = kt < a.T;
     __syncthreads();
-    store_tile<D>(rk, sK, tid);
-    store_tile<D, VS>(rv, sV, tid);
-    if (kt + 64 < a.T) {
-      load_tile<D>(base + (long long)(kt + 64) * ld + D, ld, rk, tid);
-      load_tile<D>(base + (long long)(kt + 64) * ld + 2 * D, ld, rv, tid);
+    if (live) {
+      store_tile<D>(rk, sK, tid);
+      store_tile<D, VS>(rv, sV, tid);
+      if (kt + 128 < a.T) {
+        load_tile<D>(base + (long long)(kt + 128) * ld + D, ld, rk, tid);
+        load_tile<D>(base + (long long)(kt + 128) * ld + 2 * D, ld, rv, tid);
+      }
     }
     __syncthreads();
+    if (!live) continue;
     f32x4 st[4];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
@@ -137,6 +152,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       }
     }
   }
+  // merge the two teams' states (team 1 -> LDS -> team 0): m' = max, sums rescaled by exp(m - m')
+  if (team == 1) {
+    mrg[tid][0] = m;
+    mrg[tid][1] = lsum;
+#pragma unroll
+    for (int i = 0; i < DS; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mrg[tid][2 + i * 4 + r] = ot[i][r];
+  }
+  __syncthreads();
+  if (team == 1) return;
+  {
+    const float m1 = mrg[tid][0], l1 = mrg[tid][1];
+    const float mn = fmaxf(m, m1);
+    const float c0 = __expf(m - mn), c1 = __expf(m1 - mn);
+    lsum = lsum * c0 + l1 * c1;
+#pragma unroll
+    for (int i = 0; i < DS; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ot[i][r] = ot[i][r] * c0 + mrg[tid][2 + i * 4 + r] * c1;
+    m = mn;
+  }
   const int q = q0 + wave * 16 + col;
   const float inv = 1.f / lsum;
 #pragma unroll
@@ -153,9 +190,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // per-lane scalars), dS^T is packed in registers as the B operand of dQ^T = K^T dS^T, and K^T comes from the row-major
 // K tile through the transposed LDS read.  Nothing is staged transposed and nothing round-trips through LDS.
 template <int D>
-__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int n, half_t* sK, half_t* sV) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int n, int team, half_t* sK, half_t* sV, float* mrg) {
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int q0 = blockIdx.x * 64, h = blockIdx.y;
   const int ld = 3 * a.C;
   const int g = lane >> 4, col = lane & 15;
@@ -182,17 +219,25 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int n, half_
 #pragma unroll
   for (int i = 0; i < DS; ++i) dqt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   TileRegs<D> rk, rv;
-  load_tile<D>(base + D, ld, rk, tid);
-  load_tile<D>(base + 2 * D, ld, rv, tid);
-  for (int kt = 0; kt < a.T; kt += 64) {
+  const int ntile = a.T / 64, niter = (ntile + 1) / 2;       // two teams on alternating key tiles, as in the forward
+  if (team < ntile) {
+    load_tile<D>(base + (long long)(team * 64) * ld + D, ld, rk, tid);
+    load_tile<D>(base + (long long)(team * 64) * ld + 2 * D, ld, rv, tid);
+  }
+  for (int it = 0; it < niter; ++it) {
+    const int kt = (2 * it + team) * 64;
+    const bool live = kt < a.T;
     __syncthreads();
-    store_tile<D>(rk, sK, tid);
-    store_tile<D>(rv, sV, tid);
-    if (kt + 64 < a.T) {
-      load_tile<D>(base + (long long)(kt + 64) * ld + D, ld, rk, tid);
-      load_tile<D>(base + (long long)(kt + 64) * ld + 2 * D, ld, rv, tid);
+    if (live) {
+      store_tile<D>(rk, sK, tid);
+      store_tile<D>(rv, sV, tid);
+      if (kt + 128 < a.T) {
+        load_tile<D>(base + (long long)(kt + 128) * ld + D, ld, rk, tid);
+        load_tile<D>(base + (long long)(kt + 128) * ld + 2 * D, ld, rv, tid);
+      }
     }
     __syncthreads();
+    if (!live) continue;
     half8 sb[2];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
@@ -219,8 +264,20 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int n, half_
         dqt[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, sb[pr], dqt[i], 0, 0, 0);
       }
   }
+  // team 1 hands its sums to team 0 (fixed order: team 0 + team 1)
+  if (team == 1) {
+#pragma unroll
+    for (int i = 0; i < DS; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mrg[(i * 4 + r) * 256 + tid] = dqt[i][r];
+  }
+  __syncthreads();
+  if (team == 1) return;
 #pragma unroll
   for (int i = 0; i < DS; ++i) {
+    if (blockDim.x == 512)                   // (a single tile is launched with one team)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dqt[i][r] += mrg[(i * 4 + r) * 256 + tid];
     const half4 o4 = {(half_t)dqt[i][0], (half_t)dqt[i][1], (half_t)dqt[i][2], (half_t)dqt[i][3]};
     *reinterpret_cast<half4*>(a.dqkv + ((long long)n * a.T + q) * ld + h * 3 * D + i * 16 + 4 * g) = o4;
   }
@@ -232,11 +289,12 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int n, half_
 // owns one key and 16 queries of the tile: P and dS are packed in registers as the B operands of dV^T = dA^T P and
 // dK^T = Q^T dS, whose A operands come from the row-major dA / Q tiles through the transposed LDS read.
 template <int D>
-__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, half_t* sQ, half_t* sA, float* sD) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, int team, half_t* sQ, half_t* sA, float* sD,
+                                                  float* mrg) {
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
   constexpr int CPR = D / 8, NCH = (64 * CPR + 255) / 256;
   static_assert(CPR == 8 || CPR == 4, "row sums below reduce over CPR consecutive lanes");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int k0 = blockIdx.x * 64, h = blockIdx.y;
   const int ld = 3 * a.C;
   const int g = lane >> 4, col = lane & 15;
@@ -261,13 +319,20 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, half
   const half_t* abase = a.dout + (long long)n * a.T * a.C + h * D;
   const half_t* obase = a.out + (long long)n * a.T * a.C + h * D;
   const float* lsep = a.lse + bh * a.T + 4 * g;
-  load_tile<D>(base, ld, rq, tid);
-  load_tile<D>(abase, a.C, ra, tid);
-  load_tile<D>(obase, a.C, ro, tid);
+  const int ntile = a.T / 64, niter = (ntile + 1) / 2;       // two teams on alternating query tiles
+  if (team < ntile) {
+    const long long q0r = (long long)team * 64;
+    load_tile<D>(base + q0r * ld, ld, rq, tid);
+    load_tile<D>(abase + q0r * a.C, a.C, ra, tid);
+    load_tile<D>(obase + q0r * a.C, a.C, ro, tid);
 #pragma unroll
-  for (int sub = 0; sub < 4; ++sub) lse_n[sub] = *reinterpret_cast<const f32x4*>(lsep + sub * 16);
-  for (int qt = 0; qt < a.T; qt += 64) {
+    for (int sub = 0; sub < 4; ++sub) lse_n[sub] = *reinterpret_cast<const f32x4*>(lsep + q0r + sub * 16);
+  }
+  for (int it = 0; it < niter; ++it) {
+    const int qt = (2 * it + team) * 64;
+    const bool live = qt < a.T;
     __syncthreads();
+    if (live) {
     store_tile<D>(rq, sQ, tid);
     store_tile<D>(ra, sA, tid);
 #pragma unroll
@@ -281,17 +346,19 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, half
       const int c = tid + i * 256;
       if (c < 64 * CPR && c % CPR == 0) sD[c / CPR] = dot;
     }
+    }
     f32x4 lse_c[4], dq_c[4];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) lse_c[sub] = lse_n[sub];
-    if (qt + 64 < a.T) {
-      load_tile<D>(base + (long long)(qt + 64) * ld, ld, rq, tid);
-      load_tile<D>(abase + (long long)(qt + 64) * a.C, a.C, ra, tid);
-      load_tile<D>(obase + (long long)(qt + 64) * a.C, a.C, ro, tid);
+    if (live && qt + 128 < a.T) {
+      load_tile<D>(base + (long long)(qt + 128) * ld, ld, rq, tid);
+      load_tile<D>(abase + (long long)(qt + 128) * a.C, a.C, ra, tid);
+      load_tile<D>(obase + (long long)(qt + 128) * a.C, a.C, ro, tid);
 #pragma unroll
-      for (int sub = 0; sub < 4; ++sub) lse_n[sub] = *reinterpret_cast<const f32x4*>(lsep + qt + 64 + sub * 16);
+      for (int sub = 0; sub < 4; ++sub) lse_n[sub] = *reinterpret_cast<const f32x4*>(lsep + qt + 128 + sub * 16);
     }
     __syncthreads();
+    if (!live) continue;
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) dq_c[sub] = *reinterpret_cast<const f32x4*>(sD + sub * 16 + 4 * g);
     half8 pb[2], sb[2];
@@ -323,6 +390,25 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, half
         dkt[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, sb[pr], dkt[i], 0, 0, 0);
       }
   }
+  if (team == 1) {
+#pragma unroll
+    for (int i = 0; i < DS; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        mrg[(i * 4 + r) * 256 + tid] = dkt[i][r];
+        mrg[(DS * 4 + i * 4 + r) * 256 + tid] = dvt[i][r];
+      }
+  }
+  __syncthreads();
+  if (team == 1) return;
+  if (blockDim.x == 512)
+#pragma unroll
+    for (int i = 0; i < DS; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dkt[i][r] += mrg[(i * 4 + r) * 256 + tid];
+        dvt[i][r] += mrg[(DS * 4 + i * 4 + r) * 256 + tid];
+      }
   half_t* row = a.dqkv + ((long long)n * a.T + key) * ld + h * 3 * D;
 #pragma unroll
   for (int i = 0; i < DS; ++i) {
@@ -334,15 +420,17 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, half
 }
 
 // blockIdx.z = 2 n + role: role 0 = dQ of 64 queries, role 1 = dK/dV of 64 keys (independent of each other, see above)
+// Each workgroup is two teams of four waves on alternating tiles (own staging buffers, shared barriers), merged at the end.
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
-  constexpr int RS = D + 8;
-  __shared__ __attribute__((aligned(16))) half_t s0[64 * RS];
-  __shared__ __attribute__((aligned(16))) half_t s1[64 * RS];
-  __shared__ __attribute__((aligned(16))) float sD[64];
-  const int n = blockIdx.z >> 1;
-  if ((blockIdx.z & 1) == 0) attn_bwd_dq_body<D>(a, n, s0, s1);
-  else attn_bwd_dkv_body<D>(a, n, s0, s1, sD);
+__global__ __launch_bounds__(512) void attn_bwd_kernel(AttnArgs a) {
+  constexpr int RS = D + 8, DS = D / 16;
+  __shared__ __attribute__((aligned(16))) half_t s0[2][64 * RS];
+  __shared__ __attribute__((aligned(16))) half_t s1[2][64 * RS];
+  __shared__ __attribute__((aligned(16))) float sD[2][64];
+  __shared__ float mrg[2 * DS * 4 * 256];
+  const int n = blockIdx.z >> 1, team = threadIdx.x >> 8;
+  if ((blockIdx.z & 1) == 0) attn_bwd_dq_body<D>(a, n, team, s0[team], s1[team], mrg);
+  else attn_bwd_dkv_body<D>(a, n, team, s0[team], s1[team], sD[team], mrg);
 }
 
 static int check_attn(const AttnArgs& a) {
@@ -354,8 +442,8 @@ static int check_attn(const AttnArgs& a) {
 int attn_forward_launch(const AttnArgs& a, hipStream_t s) {
   ISHAP_TRY(check_attn(a));
   dim3 g(a.T / 64, a.heads, a.N);
-  if (a.d == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, g, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<32>, g, dim3(256), 0, s, a);
+  if (a.d == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, g, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<32>, g, dim3(512), 0, s, a);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -363,8 +451,9 @@ int attn_forward_launch(const AttnArgs& a, hipStream_t s) {
 int attn_backward_launch(const AttnArgs& a, hipStream_t s) {
   ISHAP_TRY(check_attn(a));
   dim3 g(a.T / 64, a.heads, a.N * 2);
-  if (a.d == 64) hipLaunchKernelGGL(attn_bwd_kernel<64>, g, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(attn_bwd_kernel<32>, g, dim3(256), 0, s, a);
+  const dim3 blk(a.T > 64 ? 512 : 256);      // one tile: the second team would have nothing to do
+  if (a.d == 64) hipLaunchKernelGGL(attn_bwd_kernel<64>, g, blk, 0, s, a);
+  else hipLaunchKernelGGL(attn_bwd_kernel<32>, g, blk, 0, s, a);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
