@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void drag_gather_kernel(DragArgs a, unsigned* 
 
 int drag_setup_launch(const DragArgs& a, hipStream_t s) {
   const int side = 2 * a.r + 1;
+  ISHAP_REQUIRE((3 * a.W * a.W) % 4 == 0 && a.ld % 8 == 0, "drag: 3*W*W must be a multiple of 4 and the tap channels of 8");
   ISHAP_CHECK_HIP(hipMemsetAsync(a.touched, 0, (size_t)3 * a.W * a.W, s));
   // the scatter buffer and the loss sums start at zero here; every loss call leaves them zero again
   ISHAP_CHECK_HIP(hipMemsetAsync(a.gfx, 0, (size_t)a.W * a.W * a.ld * sizeof(long long), s));

@@ -71,6 +71,27 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 5; ++i) run();
   hipDeviceSynchronize();
   const int it = 50;
+  if (getenv("BI_ALT")) {
+    // instruction-cache probe: the same launch back to back vs alternated with a launch of a different kernel (the
+    // other tile size on a small problem of its own): pair time minus the two single times = what the code switch costs
+    IgemmArgs b = a;
+    const int Hb = 32, Mb = Hb * Hb;
+    half_t *Xb, *Ob; hipMalloc(&Xb, (size_t)Mb * Cin * 2); hipMalloc(&Ob, (size_t)Mb * Cout * 2);
+    hipMemset(Xb, 0, (size_t)Mb * Cin * 2);
+    b.X = Xb; b.out = Ob; b.M = Mb; b.H = Hb; b.W = Hb; b.stat_out = nullptr; b.ksplit = 1;
+    auto time_it = [&](int mode) {
+      for (int i = 0; i < 5; ++i) { if (mode != 1) run(); if (mode != 0) igemm2_launch_main(b, !big, 0); }
+      hipDeviceSynchronize();
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < it; ++i) { if (mode != 1) run(); if (mode != 0) igemm2_launch_main(b, !big, 0); }
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float t; hipEventElapsedTime(&t, e0, e1);
+      return t * 1e3 / it;
+    };
+    const double ta = time_it(0), tb = time_it(1), tab = time_it(2);
+    printf("alone A %.2f us, alone B %.2f us, alternated A+B %.2f us: switch cost %.2f us per pair\n", ta, tb, tab, tab - ta - tb);
+  }
   if (getenv("BI_EMPTY")) {                       // floor of a dependent launch in this harness
     const int lds = atoi(getenv("BI_EMPTY"));
     hipFuncSetAttribute((const void*)empty_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
