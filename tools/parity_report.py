@@ -16,16 +16,36 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def surface_report(vol_gpu, vol_cpu, va, res, dev, extract_surface, mesh_chamfer):
+    """the device marching cubes on both volumes: vertex count (= the checker's sign-changing grid edges), closedness, and
+    calc_chamfer as the reference defines it -- 20 000 points sampled uniformly by area on each surface"""
+    out = {}
+    meshes = []
+    for name, vol in (("device", vol_gpu), ("oracle", vol_cpu)):
+        v, t = extract_surface(vol.to(dev), 0.0, method="marching_cubes")
+        meshes.append((v / res * 2 - 1, t))
+        e = torch.cat([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]]).long()
+        key = torch.minimum(e[:, 0], e[:, 1]) * (v.shape[0] + 1) + torch.maximum(e[:, 0], e[:, 1])
+        _, cnt = torch.unique(key, return_counts=True)
+        out[f"device_mc_vertices_on_{name}_volume"] = int(v.shape[0])
+        out[f"device_mc_triangles_on_{name}_volume"] = int(t.shape[0])
+        out[f"device_mc_open_edges_on_{name}_volume"] = int((cnt == 1).sum())      # edges on the volume's faces only
+    out["device_mc_equals_checker_vertex_count"] = out["device_mc_vertices_on_device_volume"] == int(va.shape[0])
+    out["chamfer_area_uniform_20k"] = mesh_chamfer(meshes[0], meshes[1], 20000)
+    out["chamfer_area_uniform_20k_floor"] = mesh_chamfer(meshes[1], (meshes[1][0].clone(), meshes[1][1].clone()), 20000, seed=1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--T", type=int, default=12)
     ap.add_argument("--W", type=int, default=4)
     ap.add_argument("--res", type=int, default=96)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "round1_parity.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "round2_parity.json"))
     a = ap.parse_args()
     from ishapediting_amd import synthetic
     from ishapediting_amd.drag_utils import DragStuff, get_args
-    from ishapediting_amd.mesh import chamfer_distance
+    from ishapediting_amd.mesh import chamfer_distance, extract_surface, mesh_chamfer
     from oracle.surface_cpu import mc_vertices          # checker-side vertex sets for both volumes
     from ishapediting_amd.unet_spec import build_spec, full_config
     from oracle import ref_cpu as O
@@ -82,6 +102,7 @@ def main():
         "chamfer_all_vertices": chamfer_distance(va.to(dev), vb.to(dev), None) if min(va.shape[0], vb.shape[0]) > 0 else None,
         "chamfer_20k_samples": chamfer_distance(va.to(dev), vb.to(dev), 20000) if min(va.shape[0], vb.shape[0]) > 0 else None,
         "chamfer_20k_sampling_floor": chamfer_distance(vb.to(dev), vb.clone().to(dev), 20000, seed=1),
+        **surface_report(vol_gpu, vol_cpu, va, a.res, dev, extract_surface, mesh_chamfer),
         "oracle_drag_losses": losses, "device_drag_losses": [float(l) for l in ds.last_losses],
         "seconds_device": round(t_gpu, 2), "seconds_oracle_cpu": round(t_cpu, 1),
     }
