@@ -85,7 +85,8 @@ int ishap_unet_block_output(const ishap_unet* u, int group, int index, int* chan
  * time_embed and every ResBlock's emb_layers, gd/unet.py:651,245-250 -- none of them depends on x).  A later
  * ishap_unet_forward whose timesteps all equal one prepared value reuses its row and skips those four launches; any other
  * forward computes them as before.  Results are bit-identical either way.  n = 0 drops the prepared rows; loading a
- * parameter drops them too. */
+ * parameter drops them too.  Call it between steps, not between a kept forward and its backward (that forward's
+ * intermediates are invalidated if it used a prepared row). */
 int ishap_unet_prepare_timesteps(ishap_unet* u, const float* timesteps, int n, void* stream);
 /* Device bytes the context holds besides the packed weights: activation arena + split-K partials + GroupNorm scratch
  * (SURVEY 8b's ishap_workspace_bytes; the context allocates them itself at create time, sized by dry runs of

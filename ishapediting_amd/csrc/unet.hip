@@ -762,6 +762,9 @@ int ishap_unet_prepare_timesteps(ishap_unet* u, const float* ts, int n, void* st
   ISHAP_CHECK_HIP(hipSetDevice(u->device));
   hipStream_t s = (hipStream_t)stream;
   u->film_cache_ts.clear();
+  // a kept forward may be reading a prepared row (its backward needs the FiLM values again): the rows are about to be
+  // rewritten, so that forward can no longer be differentiated
+  if (u->film_cur != u->d_film) { u->have_saved = false; u->film_cur = u->d_film; u->film_cur_ld = u->film_rows; }
   if (n == 0) return 0;
   ISHAP_REQUIRE(u->n_loaded == (int)u->params.size(), "prepare_timesteps before all parameters are loaded");
   const int mc = u->cfg.model_channels;
