@@ -8,6 +8,7 @@
 // two-stage deterministic reduction (per-row-chunk partial sums per channel, then one block per
 // (image, group) combining them in double) -- no float atomics, bitwise reproducible.
 #include "norm.h"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------
 // statistics
@@ -244,7 +245,8 @@ int gn_apply_launch(const GnApplyArgs& a, hipStream_t s) {
   const int HWo = a.pool ? (a.H / 2) * (a.W / 2) : a.H * a.W;
   long long total = (long long)a.N * HWo * (a.C / 8);
   int blocks = (int)((total + 255) / 256);
-  if (blocks > (a.sums ? 1024 : 4096)) blocks = a.sums ? 1024 : 4096;   // fewer, fatter blocks amortise the finalise prologue
+  static const int cap_sums = [] { const char* e = getenv("ISHAP_GN_APPLY_BLOCKS"); return e ? atoi(e) : 1024; }();
+  if (blocks > (a.sums ? cap_sums : 4096)) blocks = a.sums ? cap_sums : 4096;   // fewer, fatter blocks amortise the finalise prologue
   // thread count = multiple of CV (a thread owns one 8-channel vector): blocks = multiple of CV / gcd(CV, 256)
   const int CV = a.C / 8;
   int gcd = CV, r256 = 256;
