@@ -432,8 +432,10 @@ class DragStuff:
                 _lib.check(L.ishap_grad_to_scaled_f16(cot.data_ptr(), cot16.data_ptr(), bits.data_ptr(), scale2.data_ptr(),
                                                       cot.numel(), s))
             dx = self.model.backward_from_output(cot16, scale2)
-            grads1 = dx + g_direct                                   # = img.grad of the reference (:459)
+            grads1 = th.empty_like(dx)                               # = img.grad of the reference (:459): UNet path + direct path
             with th.cuda.device(self.device):
+                _lib.check(L.ishap_axpby(dx.data_ptr(), g_direct.data_ptr(), 1.0, 1.0, dx.numel(), grads1.data_ptr(),
+                                         _lib.stream_ptr(self.device)))
                 _lib.check(L.ishap_guided_update(outs["sample"].data_ptr(), outs["variance"].data_ptr(), grads1.data_ptr(),
                                                  float(scale), None, img.numel(), new.data_ptr(), _lib.stream_ptr(self.device)))
             img = new

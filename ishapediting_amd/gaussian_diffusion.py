@@ -273,8 +273,15 @@ class SpacedDiffusion:
                 tap_sink()
             variance.append(outs["variance"])
             feat.append(outs["inter_feat"])
-            variance_noise.append(img_inter[i] - outs["mean"])
-            img = outs["mean"] + variance_noise[-1]
+            # z_i = x_i - mean_i and img = mean_i + z_i (:527-529) through the library's elementwise kernel (a, b = +-1 are
+            # exact, so these are the reference's fp32 subtraction / addition): no torch arithmetic on the path
+            z, nxt = torch.empty_like(img), torch.empty_like(img)
+            with torch.cuda.device(img.device):
+                s_ = _lib.stream_ptr(img.device)
+                _lib.check(L.ishap_axpby(img_inter[i].data_ptr(), outs["mean"].data_ptr(), 1.0, -1.0, img.numel(), z.data_ptr(), s_))
+                _lib.check(L.ishap_axpby(outs["mean"].data_ptr(), z.data_ptr(), 1.0, 1.0, img.numel(), nxt.data_ptr(), s_))
+            variance_noise.append(z)
+            img = nxt
         return {"inter_feat": feat, "latent": img_inter[-1], "variance_noise": variance_noise, "variance": variance,
                 "sample": img}
 
