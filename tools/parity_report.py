@@ -36,6 +36,44 @@ def surface_report(vol_gpu, vol_cpu, va, res, dev, extract_surface, mesh_chamfer
     return out
 
 
+def shape_like_report(dec_sd, dev, res, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices):
+    """The same decode + surface comparison on a SHAPE-LIKE level set: a smooth, low-amplitude triplane latent makes the
+    random-weight decoder a smooth function of position (the edit's own latent comes from a random-weight UNet and gives a
+    volume-filling noise surface)."""
+    from ishapediting_amd.triplane_decoder import MultiTriplane, decode_volume
+    from oracle import ref_cpu as O
+    S = 128
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, S), torch.linspace(-1, 1, S), indexing="ij")
+    g = torch.Generator().manual_seed(17)
+    lat = torch.zeros(1, 96, S, S)
+    for c in range(96):                                  # a few low-frequency modes per channel
+        a, b, p, q = torch.randn(4, generator=g)
+        lat[0, c] = 0.02 * (a * torch.cos(1.5 * xx + p) + b * torch.cos(1.5 * yy + q))
+    dec = MultiTriplane(1, device=dev)
+    dec.net.load_state_dict(dec_sd)
+    vg = decode_volume(dec, lat.to(dev), 1.0, 0.0, res)
+    torch.cuda.synchronize()
+    vc = O.decode_volume(dec_sd, lat, 1.0, 0.0, res)
+    level = float(vc.median())                           # cut the smooth field where it splits the volume in two
+    meshes, out = [], {}
+    for name, vol in (("device", vg), ("oracle", vc.to(dev))):
+        v, t = extract_surface(vol, level, method="marching_cubes")
+        meshes.append((v / res * 2 - 1, t))
+        out[f"vertices_{name}_volume"] = int(v.shape[0])
+        out[f"triangles_{name}_volume"] = int(t.shape[0])
+    va = mc_vertices(vg.cpu(), level) / res * 2 - 1
+    vb = mc_vertices(vc, level) / res * 2 - 1
+    out.update({
+        "res": res, "level": level, "logit_max_abs_err": float((vg.cpu() - vc).abs().max()), "logit_rms": float(vc.pow(2).mean().sqrt()),
+        "sign_flips_about_level": int(((vg.cpu() > level) != (vc > level)).sum()),
+        "checker_vertex_count_device_volume": int(va.shape[0]), "checker_vertex_count_oracle_volume": int(vb.shape[0]),
+        "chamfer_all_vertices": chamfer_distance(va.to(dev), vb.to(dev), None),
+        "chamfer_area_uniform_20k": mesh_chamfer(meshes[0], meshes[1], 20000),
+        "chamfer_area_uniform_20k_floor": mesh_chamfer(meshes[1], (meshes[1][0].clone(), meshes[1][1].clone()), 20000, seed=1),
+    })
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--T", type=int, default=12)
@@ -103,6 +141,7 @@ def main():
         "chamfer_20k_samples": chamfer_distance(va.to(dev), vb.to(dev), 20000) if min(va.shape[0], vb.shape[0]) > 0 else None,
         "chamfer_20k_sampling_floor": chamfer_distance(vb.to(dev), vb.clone().to(dev), 20000, seed=1),
         **surface_report(vol_gpu, vol_cpu, va, a.res, dev, extract_surface, mesh_chamfer),
+        "shape_like_decode": shape_like_report(dec_sd, dev, 128, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices),
         "oracle_drag_losses": losses, "device_drag_losses": [float(l) for l in ds.last_losses],
         "seconds_device": round(t_gpu, 2), "seconds_oracle_cpu": round(t_cpu, 1),
     }
