@@ -44,7 +44,7 @@ static int gn_bwd_local_op(Exec& e, const GnBwdArgs& g, Tensor& up) {
   a.stats = g.stats; a.gamma = g.gamma; a.beta = g.beta; a.emb = g.emb; a.emb_ld = g.emb_ld;
   a.N = g.N; a.H = g.H; a.W = g.W; a.C = g.C; a.film = g.film; a.act = g.act; a.gmode = g.gmode;
   long long* rec = nullptr;
-  ISHAP_SALLOC(rec, e, (size_t)g.N * 32 * 16);       // zeroed with the rest of the statistics arena
+  ISHAP_SALLOC(rec, e, (size_t)g.N * 32 * GN_REC_STRIDE);       // zeroed with the rest of the statistics arena
   a.rec = reinterpret_cast<unsigned long long*>(rec);
   up.pend = SlabSrc{};
   if (e.dry) return 0;

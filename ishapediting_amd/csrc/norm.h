@@ -65,6 +65,8 @@ int gn_backward_launch(const GnBwdArgs& a, hipStream_t s);
 // (image, group) -- H*W pixels x C/32 channels, staged in LDS -- so statistics, normalisation, FiLM, SiLU, pooling and
 // (backward) the group means are ONE launch with no atomics, and the input may be a pending split-K result (SlabSrc).
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int GN_REC_STRIDE = 32;     // 8-byte granules per (image, group) in the rendezvous record: 2 per part, up to 16 parts
+
 struct GnLocalArgs {
   // source A: channels [0, Ca) -- a dense fp16 tensor [N][H*W][Ca] or pending fp32 slices (then `ya` receives the fp16 tensor)
   const half_t* xa = nullptr;

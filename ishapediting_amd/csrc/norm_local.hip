@@ -209,7 +209,7 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
     for (int i = 0; i < VEC; ++i) { s += (double)v[i]; q += (double)v[i] * (double)v[i]; }
   }
   block_sum2(s, q, scratch);
-  group_rendezvous(s, q, a.rec + ((long long)n * 32 + g) * 16, part, a.parts, scratch);
+  group_rendezvous(s, q, a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE, part, a.parts, scratch);
   const double cnt = (double)HW * (double)cpg;
   const double md = s / cnt;
   double vd = q / cnt - md * md;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(GnBwdLocalArgs a) {
     }
   }
   block_sum2(s1, s2, scratch);
-  group_rendezvous(s1, s2, a.rec + ((long long)n * 32 + g) * 16, part, a.parts, scratch);
+  group_rendezvous(s1, s2, a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE, part, a.parts, scratch);
   const double cnt = (double)HW * (double)cpg;
   const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt);
   __syncthreads();
@@ -399,12 +399,15 @@ int pick_threads(int nunits) { return nunits >= 1024 ? 1024 : (nunits <= 256 ? 2
 // at least `min_pixels` pixels made of whole units of `unit` pixels (a row pair when the kernel pools)
 int pick_parts(int N, int HW, int cpg, int unit, bool have_rec) {
   static const int maxp = [] { const char* e = getenv("ISHAP_GN_PARTS"); return e ? atoi(e) : 8; }();
-  static const int min_el = [] { const char* e = getenv("ISHAP_GN_PART_ELEMS"); return e ? atoi(e) : 256; }();
+  static const int min_el = [] { const char* e = getenv("ISHAP_GN_PART_ELEMS"); return e ? atoi(e) : 128; }();
   if (!have_rec) return 1;
   // the rendezvous costs ~3 atomic round trips (3-4 us), yet more, smaller parts still win down to a few hundred elements
-  // per workgroup (in-situ sweep: 0.2445 / 0.2464 / 0.2500 / 0.2574 s per edit at >= 256 / 1024 / 2048 / 4096 elements)
+  // per workgroup (in-situ sweep: 0.2445 / 0.2464 / 0.2500 / 0.2574 s per edit at >= 256 / 1024 / 2048 / 4096 elements;
+  // with the tagged-granule rendezvous, tools/gn_parts_probe.sh: local-GN kernel time 193 / 198 / 216 / 243 at >= 128 / 256 /
+  // 1024 / 2048 elements, 226 / 271 with at most 4 / 2 parts, 203-214 with up to 16 parts)
   int p = 1;
-  while (p * 2 <= maxp && 32 * N * (p * 2) <= 256 && HW % (p * 2) == 0 && (HW / (p * 2)) % unit == 0 &&
+  static const int max_wgs = [] { const char* e = getenv("ISHAP_GN_MAX_WGS"); return e ? atoi(e) : 256; }();
+  while (p * 2 <= maxp && p * 2 <= GN_REC_STRIDE / 2 && 32 * N * (p * 2) <= max_wgs && HW % (p * 2) == 0 && (HW / (p * 2)) % unit == 0 &&
          (long long)(HW / (p * 2)) * cpg >= min_el)
     p *= 2;
   return p;

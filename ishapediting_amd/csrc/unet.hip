@@ -348,7 +348,7 @@ static int gn_local_op(Exec& e, Tensor& x, const NormW& nw, half_t* out, half_t*
   g.out = out; g.xpool = xpool; g.stats_out = stats_out; g.gamma = nw.gamma; g.beta = nw.beta; g.emb = emb; g.emb_ld = emb_ld;
   g.N = x.N; g.H = x.H; g.W = x.W; g.C = x.C; g.film = film; g.act = act; g.pool = pool;
   long long* rec = nullptr;
-  ISHAP_SALLOC(rec, e, (size_t)x.N * 32 * 16);       // zeroed with the statistics arena at the start of the forward
+  ISHAP_SALLOC(rec, e, (size_t)x.N * 32 * GN_REC_STRIDE);       // zeroed with the statistics arena at the start of the forward
   g.rec = reinterpret_cast<unsigned long long*>(rec);
   if (e.dry) return 0;
   return gn_local_launch(g, e.s);
