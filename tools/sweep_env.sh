@@ -1,7 +1,9 @@
 #!/bin/bash
-# in-situ sweep of one policy constant: sweep_env.sh VAR v1 v2 ...   (prints s/shape of bench.py per value)
-var=$1; shift
-for v in "$@"; do
-  r=$(env $var=$v timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; print(json.loads(sys.stdin.read())['value'])")
-  echo "$var=$v s/shape=$r"
+# in-situ A/B of launch-policy switches on one box: bench wall per edit (3 edits) per setting
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+run() { echo "$1: $(timeout -k 5 120 env $1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys;print(json.load(sys.stdin)['value'])" 2>/dev/null || echo failed)"; }
+run "X_DEFAULT=1"
+for kv in ISHAP_S3_WGS=256 ISHAP_S3_WGS=512 ISHAP_S3_WGS=640 ISHAP_TEAM_STEPS=8 ISHAP_TEAM_STEPS=24 ISHAP_TEAM_TILES=512 ISHAP_SKINNY=2 ISHAP_SKINNY=0 ISHAP_SMALL3=2 ISHAP_LOCAL_GN=2; do
+  run "$kv"
 done
+run "X_DEFAULT=2"
