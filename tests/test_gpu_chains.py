@@ -449,3 +449,11 @@ def test_prepared_timesteps_are_bit_identical_to_the_in_forward_embedding():
     assert torch.equal(mixed[0], ref[400.0][0]) and torch.equal(mixed[1], ref[7.0][1])
     model.prepare_timesteps([])
     assert torch.equal(model(x, [400.0, 400.0], feat_layer=1)[0], ref[400.0])
+    # a kept forward that read a prepared row cannot be differentiated once the rows are rewritten: the call says so
+    model.prepare_timesteps([400.0])
+    _, tap = model(x[:1], [400.0], feat_layer=1, keep_for_backward=True)
+    cot = torch.zeros((1, tap.shape[2] * tap.shape[3], tap.shape[1]), dtype=torch.float16, device=dev())
+    model.backward_input(cot)                                   # fine: rows untouched since the forward
+    model.prepare_timesteps([3.0])
+    with pytest.raises(RuntimeError, match="preceding forward"):
+        model.backward_input(cot)
