@@ -137,6 +137,69 @@ def cpu_baseline(seed, reps=3):
             "unguided_step_s": round(mf, 3), "guided_step_s": round(mg, 3), "decode64_s": round(md, 3)}
 
 
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT touching HIP/HSA (torch.cuda.device_count() falls back to hipGetDeviceCount
+    when amdsmi is missing, which would initialise the runtime in a parent that then starts children): the KFD topology
+    in sysfs lists one node per agent, GPUs are the nodes with SIMDs; HIP_/ROCR_/CUDA_VISIBLE_DEVICES narrow that.
+    None = cannot tell (let the ranks fail in set_device, which already ends the run non-zero)."""
+    n = None
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for d in os.listdir(base):
+            props = dict(line.split(None, 1) for line in open(os.path.join(base, d, "properties")) if " " in line)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        n = None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            k = len([t for t in v.split(",") if t.strip() != ""])
+            n = k if n is None else min(n, k)
+    return n
+
+
+def c2_generate_leg(device, steps=1000):
+    """BASELINE.json configs[1] (C2) once at batch 1: the full `steps`-step DDPM sample of the 421M-parameter model
+    (generate.py --num_steps 1000), the 256^3 decode and marching cubes + 10 smoothing sweeps.  Reported next to the
+    headline (extra keys), never part of `value`."""
+    from ishapediting_amd import synthetic
+    from ishapediting_amd.gaussian_diffusion import create_gaussian_diffusion
+    from ishapediting_amd.mesh import extract_surface, smooth_mesh
+    from ishapediting_amd.triplane_decoder import MultiTriplane, decode_volume
+    from ishapediting_amd.unet import UNetModel
+    from ishapediting_amd.unet_spec import full_config
+    cfg = full_config()
+    model = UNetModel(cfg, device, max_batch=1)
+    model.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 1234)))
+    dec = MultiTriplane(1, device=device)
+    dec.net.load_state_dict(synthetic.decoder_state_dict(4321))
+    diff = create_gaussian_diffusion(timestep_respacing=str(steps))
+    g = torch.Generator(device="cpu").manual_seed(5)
+    noise = torch.randn((1, 96, 128, 128), generator=g).to(device)
+    warm = create_gaussian_diffusion(timestep_respacing="4")
+    warm.p_sample_loop(model, noise.shape, noise=noise, device=device)        # kernels loaded, allocator warm
+    torch.cuda.synchronize()
+    t0 = time.time()
+    sample = diff.p_sample_loop(model, noise.shape, noise=noise, device=device)
+    torch.cuda.synchronize()
+    t1 = time.time()
+    vol = decode_volume(dec, sample[:1], 1.0, 0.0, RES)
+    torch.cuda.synchronize()
+    t2 = time.time()
+    verts, tris = extract_surface(vol)
+    smooth_mesh(verts, tris, 10, box_max=float(RES - 1))
+    torch.cuda.synchronize()
+    t3 = time.time()
+    del model
+    return {"c2_s_per_shape": round(t3 - t0, 4), "c2_unet_steps_per_s": round(steps / (t1 - t0), 1),
+            "c2_sample_s": round(t1 - t0, 4), "c2_decode_ms": round((t2 - t1) * 1e3, 2),
+            "c2_marching_cubes_ms": round((t3 - t2) * 1e3, 2), "c2_steps": steps,
+            "c2_note": "random-init weights decode to a noise volume: the marching-cubes time is that of ~16M vertices "
+                       "(a shape-like 256^3 volume takes surface_extract_ms_sphere256)"}
+
+
 def spawn_workers(a):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (each its own
     interpreter; this parent never touches the GPU), relay rank 0's JSON line, exit with the worst status."""
@@ -146,8 +209,8 @@ def spawn_workers(a):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    have = torch.cuda.device_count()                           # counting devices does not initialise the GPU in this parent
-    if a.gpus > have:
+    have = visible_gpu_count()                                 # sysfs / environment only: this parent never loads HIP
+    if have is not None and a.gpus > have:
         sys.exit(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) are visible")
     procs = []
     for r in range(a.gpus):
@@ -176,6 +239,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c2", action="store_true", help="skip the generate-path leg (BASELINE configs[1]) after the headline")
+    ap.add_argument("--c2-steps", type=int, default=1000)
     ap.add_argument("--shape-profile", default=None, help="write the per-shape conv/GEMM timing CSV of one edit here")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -275,13 +340,19 @@ def main():
         # HBM-side bytes per launch of that kernel from the committed PMC passes (profiles/pmc_traffic.json, produced by
         # tools/pmc_only.sh + tools/pmc_summary.py: counters cannot be collected from inside this process)
         traffic = None
+        traffic_source = None
         try:
-            k = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"][names[v]]
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            k = pj["kernels"][names[v]]
             traffic = k["FETCH_SIZE"]["bytes_per_launch"] + k["WRITE_SIZE"]["bytes_per_launch"]
+            traffic_source = ("committed profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                              "tools/pmc_step.py (" + str(pj.get("source", "tools/pmc_only.sh")) + "), FETCH_SIZE doubled per "
+                              "MI355X_MICROARCH.md; not collected live (counters cannot be read from inside this process)")
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": traffic, "kernel": names[v],
+                    "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                    "kernel": names[v],
                     "launches_per_edit": int(launches), "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
                     "flops_per_launch_avg": flops / max(launches, 1),
                     "share_of_edit_time": round(ms * 1e-3 / sec_per_shape / max(world, 1), 3) if world == 1 else None,
@@ -294,7 +365,7 @@ def main():
 
     if rank == 0:
         # surface of the last decoded volume on the device (reported separately from the headline, as BASELINE's metric
-        # does for marching cubes): marching tetrahedra + 10 smoothing sweeps, csrc/surface.hip
+        # does for marching cubes): marching cubes (256-case table) + 10 smoothing sweeps, csrc/surface.hip
         from ishapediting_amd.mesh import extract_surface, smooth_mesh
         extract_surface(vol)
         torch.cuda.synchronize()
@@ -332,6 +403,10 @@ def main():
         }
         if cpu:
             line["speedup_vs_cpu_baseline"] = round(cpu["value"] / sec_per_shape, 1)
+        if world == 1 and not a.no_c2:
+            del ds                                                   # the edit context's arena + guidance cache
+            torch.cuda.empty_cache()
+            line.update(c2_generate_leg(device, a.c2_steps))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -17,6 +17,12 @@ extern "C" {
 #endif
 
 const char* ishap_last_error(void);
+/* Asynchronous device-side failures (the reference's analogue: a CUDA error raised by a later torch call).  A kernel of
+ * this library that cannot go on correctly -- today: a bounded cross-workgroup wait that gave up -- poisons its outputs
+ * with NaN and raises a process-wide status word; every ishap_unet_* call that enqueues work checks the word first and
+ * fails (-3, message in ishap_last_error) if an EARLIER launch raised it.  This call checks on demand, e.g. after a
+ * stream synchronise at the end of a loop: 0 = no failure since the last report; the word is cleared once reported. */
+int ishap_device_status(void);
 int ishap_version(void);
 
 /* ---------------------------------------------------------------- UNet (gd/unet.py:396-671) */
@@ -105,6 +111,28 @@ int ishap_unet_backward_input(ishap_unet* u, const void* cot_nhwc, const float* 
 int ishap_unet_backward_from_output(ishap_unet* u, const void* cot_out, int cot_is_f16, const float* scale2, float* dx,
                                     void* stream);
 /*   cot_out: fp32, or fp16 already multiplied by scale2[0] (ishap_grad_to_scaled_f16); scale2 as above */
+
+/* ---------------------------------------------------------------- GroupNorm32 alone (gd/nn.py:16-18,92-99)
+ * normalization(C) = GroupNorm32(32, C): statistics and normalisation in fp32 on x.float(), eps 1e-5, result cast back
+ * to the torso's fp16; followed by nn.SiLU in ResBlock.in_layers / out_layers and the head (gd/unet.py:179-183,
+ * 205-209, 612-614).  The executor fuses this into the neighbouring kernels and picks one of several statistics
+ * routes by map size; these calls run a chosen route on a caller-given tensor, so the reference's own primitive
+ * fixtures reach each of them.
+ *   x, y, g, dx   NHWC fp16 [N][H*W][C]        stats  [N][32][2] fp32 (mean, rstd): written by the forward, read by the backward
+ *   silu          0: y = GN(x);  1: y = SiLU(GN(x))
+ *   route         0 = the executor's choice for this map; 1 = two-pass statistics; 2 = group-local, one workgroup per
+ *                 (image, group); 3 = group-local, several workgroups meeting in the in-launch rendezvous; 4 (forward
+ *                 only) = fixed-point per-channel sums gathered by an implicit-GEMM epilogue (C % 64 == 0)
+ *   scratch       device buffer of ishap_group_norm32_scratch_bytes(N, H*W, C) bytes (contents irrelevant) */
+long long ishap_group_norm32_scratch_bytes(int N, int HW, int C);
+int ishap_group_norm32(const void* x_nhwc_f16, const float* gamma, const float* beta, int N, int H, int W, int C, int silu,
+                       int route, void* y_nhwc_f16, float* stats, void* scratch, void* stream);
+/* input gradient of sum(y * g) w.r.t. x (no parameter gradients), as autograd derives it at drag_utils.py:383 */
+int ishap_group_norm32_backward(const void* g_nhwc_f16, const void* x_nhwc_f16, const float* stats, const float* gamma,
+                                const float* beta, int N, int H, int W, int C, int silu, int route, void* dx_nhwc_f16,
+                                void* scratch, void* stream);
+/* workgroups per (image, group) route 3 uses for this shape on the current device (> 1: the rendezvous is exercised) */
+int ishap_group_norm32_parts(int N, int HW, int C);
 
 /* ------------------------------------------- diffusion step (gd/gaussian_diffusion.py:232-331, 400-510) */
 typedef struct {

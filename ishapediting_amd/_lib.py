@@ -44,6 +44,13 @@ class DecoderWeightsC(C.Structure):
 SYMBOLS = {
     "ishap_last_error": (C.c_char_p, []),
     "ishap_version": (C.c_int, []),
+    "ishap_device_status": (C.c_int, []),
+    "ishap_group_norm32_scratch_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "ishap_group_norm32": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ishap_group_norm32_backward": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_int, c_void_p, c_void_p, c_void_p]),
+    "ishap_group_norm32_parts": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ishap_unet_create": (C.c_int, [C.POINTER(UNetConfigC), C.c_int, C.POINTER(c_void_p)]),
     "ishap_unet_destroy": (None, [c_void_p]),
     "ishap_unet_num_params": (C.c_int, [c_void_p]),

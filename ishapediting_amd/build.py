@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libishap_hip.so")
-SOURCES = ["igemm.hip", "igemm2.hip", "igemm3.hip", "igemm_skinny.hip", "igemm_small3.hip", "norm.hip", "norm_bwd.hip", "norm_local.hip", "attention.hip", "misc.hip", "ddpm.hip", "decode.hip", "decode_bwd.hip", "drag.hip", "surface.hip", "unet.hip", "backward.hip", "api.hip"]
+SOURCES = ["igemm.hip", "igemm2.hip", "igemm3.hip", "igemm_skinny.hip", "igemm_small3.hip", "norm.hip", "norm_bwd.hip", "norm_local.hip", "norm_api.hip", "attention.hip", "misc.hip", "ddpm.hip", "decode.hip", "decode_bwd.hip", "drag.hip", "surface.hip", "unet.hip", "backward.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 

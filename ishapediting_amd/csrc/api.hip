@@ -8,9 +8,59 @@
 static thread_local std::string g_err;
 void ishap_set_error(const std::string& msg) { g_err = msg; }
 
+#include <atomic>
+#include <mutex>
+static std::atomic<unsigned*> g_status{nullptr};
+static std::mutex g_status_mu;
+unsigned* ishap_status_word() {
+  unsigned* p = g_status.load(std::memory_order_acquire);
+  if (p) return p;
+  std::lock_guard<std::mutex> lk(g_status_mu);
+  p = g_status.load(std::memory_order_relaxed);
+  if (p) return p;
+  void* h = nullptr;
+  if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return nullptr;
+  *(volatile unsigned*)h = 0u;
+  g_status.store((unsigned*)h, std::memory_order_release);
+  return (unsigned*)h;
+}
+static const char* status_text(unsigned code) {
+  switch (code) {
+    case ISHAP_DEV_GN_RENDEZVOUS:
+      return "device-side failure: a group-local GroupNorm rendezvous timed out (its workgroups were not co-resident); the "
+             "affected launch wrote NaN -- results since then are invalid";
+    case ISHAP_DEV_CHAIN_TIMEOUT:
+      return "device-side failure: a small-map chain kernel gave up waiting for another workgroup; the affected launch "
+             "wrote NaN -- results since then are invalid";
+    default: return "device-side failure: unknown status code";
+  }
+}
+int ishap_check_status() {
+  unsigned* p = g_status.load(std::memory_order_acquire);
+  if (!p) return 0;
+  const unsigned code = *(volatile unsigned*)p;
+  if (code == 0u) return 0;
+  *(volatile unsigned*)p = 0u;
+  ishap_set_error(std::string(status_text(code)) + " (code " + std::to_string(code) + ")");
+  return -3;
+}
+int ishap_cu_count() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  cached[dev].store(n, std::memory_order_relaxed);
+  return n;
+}
+
 extern "C" {
 
 const char* ishap_last_error(void) { return g_err.c_str(); }
+
+int ishap_device_status(void) { return ishap_check_status(); }
 
 int ishap_ddpm_step(const float* x, const float* model_out, const float* noise, const float* variance_in,
                     const ishap_step_coefs* k, int N, int C, int HW, float* sample, float* pred_xstart,

@@ -45,7 +45,7 @@ static int gn_bwd_local_op(Exec& e, const GnBwdArgs& g, Tensor& up) {
   a.N = g.N; a.H = g.H; a.W = g.W; a.C = g.C; a.film = g.film; a.act = g.act; a.gmode = g.gmode;
   long long* rec = nullptr;
   ISHAP_SALLOC(rec, e, (size_t)g.N * 32 * GN_REC_STRIDE);       // zeroed with the rest of the statistics arena
-  a.rec = reinterpret_cast<unsigned long long*>(rec);
+  a.rec = exec_is_solo(e) ? reinterpret_cast<unsigned long long*>(rec) : nullptr;     // see gn_local_op
   up.pend = SlabSrc{};
   if (e.dry) return 0;
   return gn_bwd_local_launch(a, e.s);
@@ -249,12 +249,14 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
 
 extern "C" int ishap_unet_backward_input(ishap_unet* u, const void* cot, const float* scale2, float* dx, void* stream) {
   ISHAP_REQUIRE(u && cot && dx, "null argument");
+  ISHAP_TRY(ishap_check_status());
   ISHAP_CHECK_HIP(hipSetDevice(u->device));
   return unet_backward_impl(u, (const half_t*)cot, nullptr, 0, scale2, dx, (hipStream_t)stream, false);
 }
 extern "C" int ishap_unet_backward_from_output(ishap_unet* u, const void* cot_out, int cot_is_f16, const float* scale2,
                                                float* dx, void* stream) {
   ISHAP_REQUIRE(u && cot_out && dx, "null argument");
+  ISHAP_TRY(ishap_check_status());
   ISHAP_CHECK_HIP(hipSetDevice(u->device));
   return unet_backward_impl(u, nullptr, cot_out, cot_is_f16, scale2, dx, (hipStream_t)stream, false);
 }

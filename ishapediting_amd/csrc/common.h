@@ -34,11 +34,37 @@ void ishap_set_error(const std::string& msg);
     }                                                                                      \
   } while (0)
 
+// Device status word: ONE process-wide 32-bit word in pinned, device-mapped host memory.  A kernel that cannot go on
+// correctly (a bounded spin that gave up) stores a non-zero ISHAP_DEV_* code there with a system-scope store and poisons
+// its own outputs; every ABI entry point that enqueues work on a model context reads the word first (a plain host load,
+// no synchronisation) and fails with that code's message, so an earlier launch's failure surfaces at the next call --
+// the asynchronous-error contract of the HIP runtime itself.  ishap_device_status() reads (and clears) it on demand.
+enum { ISHAP_DEV_OK = 0, ISHAP_DEV_GN_RENDEZVOUS = 1, ISHAP_DEV_CHAIN_TIMEOUT = 2 };
+unsigned* ishap_status_word();        // null only if the pinned allocation failed
+int ishap_check_status();             // 0, or -3 with the error string set (the word is cleared once reported)
+int ishap_cu_count();                 // compute units of the current device (cached per device)
+
 #define ISHAP_TRY(expr)        \
   do {                         \
     int _r = (expr);           \
     if (_r != 0) return _r;    \
   } while (0)
+
+// Raise a kernel's dynamic-LDS limit once per (thread, device, kernel symbol).  The cache is thread-local (no shared
+// mutable state, so concurrent callers need no lock) and keyed by the CURRENT device: a process that drives a second GPU,
+// or a worker thread that switches devices, sets the attribute there too instead of launching with the 64 KB default.
+static inline int ishap_set_max_lds(const void* kern, int bytes) {
+  struct Done { const void* k; int dev; int bytes; };
+  static thread_local Done done[192];
+  static thread_local int ndone = 0;
+  int dev = 0;
+  ISHAP_CHECK_HIP(hipGetDevice(&dev));
+  for (int i = 0; i < ndone; ++i)
+    if (done[i].k == kern && done[i].dev == dev && done[i].bytes >= bytes) return 0;
+  ISHAP_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (ndone < 192) done[ndone++] = Done{kern, dev, bytes};
+  return 0;
+}
 
 #define STAT_SCALE_SUM 16777216.f      /* 2^24 */
 #define STAT_SCALE_SQ 1048576.f        /* 2^20 */
@@ -63,6 +89,14 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
   v += dpp_move<0x141>(v);    // row_half_mirror
   v += dpp_move<0x140>(v);    // row_mirror
+  return v;
+}
+
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_move<0xB1>(v));
+  v = fmaxf(v, dpp_move<0x4E>(v));
+  v = fmaxf(v, dpp_move<0x141>(v));
+  v = fmaxf(v, dpp_move<0x140>(v));
   return v;
 }
 

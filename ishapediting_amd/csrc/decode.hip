@@ -240,11 +240,7 @@ int triplane_decode_launch(const DecodeArgs& a, hipStream_t s) {
   ISHAP_REQUIRE(a.npts > 0, "no points");
   ISHAP_REQUIRE(a.coords != nullptr || (a.lin != nullptr && a.res > 0), "either coords or a grid axis");
   const size_t smem = (size_t)4 * 128 * LDH * sizeof(half_t) + (size_t)(64 * LDB + 3 * 128) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    ISHAP_CHECK_HIP(hipFuncSetAttribute((const void*)triplane_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr = true;
-  }
+  ISHAP_TRY(ishap_set_max_lds((const void*)triplane_decode_kernel, (int)smem));
   long long ntiles = (a.npts + 31) / 32;
   int blocks = (int)std::min<long long>((ntiles + 7) / 8, 256);
   hipLaunchKernelGGL(triplane_decode_kernel, dim3(blocks), dim3(512), smem, s, a);

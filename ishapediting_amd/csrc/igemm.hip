@@ -242,13 +242,15 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(IgemmArgs a) {
     const int t = threadIdx.x;
     if (t < 128) {
       const int ch = t >> 1, k = t & 1;
-      float acc = 0.f;
+      // double: f and f*f of an fp16 value are exact, and so is their sum -- an fp32 sum of 16 squares at |mean| >> std
+      // already loses the variance (see igemm_epilogue.h)
+      double acc = 0.0;
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) acc += red[rr][ch][k];
+      for (int rr = 0; rr < 16; ++rr) acc += (double)red[rr][ch][k];
       const int nn = cg * 64 + ch;
       if (nn < a.N)
         atomicAdd(reinterpret_cast<unsigned long long*>(sdst + ((long long)((rbi * 16) / HW) * a.N + nn) * 2 + k),
-                  (unsigned long long)__float2ll_rn(acc * (k ? scale_q : STAT_SCALE_SUM)));
+                  (unsigned long long)__double2ll_rn(acc * (double)(k ? scale_q : STAT_SCALE_SUM)));
     }
   }
 }
@@ -324,11 +326,7 @@ template <int BM, int BN, int BK, int WM, int WN, bool CONV3>
 static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(half_t);
   auto kern = igemm_kernel<BM, BN, BK, WM, WN, CONV3>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    ISHAP_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
+  ISHAP_TRY(ishap_set_max_lds((const void*)kern, (int)smem));
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
   int prof_slot = -1;
   auto fire = [&]() -> int {

@@ -177,11 +177,7 @@ static int launch3(const IgemmArgs& a, hipStream_t s) {
   constexpr size_t smem = (size_t)(NSTW * BN * 64 + NSTX * XI * 32 * 64) * sizeof(half_t);
   static_assert(smem <= 163840, "LDS");
   auto kern = igemm3_kernel<BM, BN, NSTW, NSTX>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    ISHAP_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
+  ISHAP_TRY(ishap_set_max_lds((const void*)kern, (int)smem));
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.ksplit);
   if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(512), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a);
   else hipLaunchKernelGGL(kern, grid, dim3(512), smem, s, a);

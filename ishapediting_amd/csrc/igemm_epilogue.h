@@ -34,11 +34,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
                       (reinterpret_cast<unsigned long long>(out16) & 15) == 0;
   half_t* const tile = reinterpret_cast<half_t*>(lds_f);
   if (staged) __syncthreads();                   // the K loop's LDS tiles are dead from here on
-  float ssum[NT][4], ssq[NT][4];
+  // Forward statistics are gathered about a PIVOT: every lane takes the first value it stores in a channel as that channel's
+  // pivot p and accumulates sum(x - p), sum((x - p)^2) -- small numbers even when the channel sits at |mean| >> std, where
+  // the plain fp32 sums of x and x^2 cancel (128 squares of 100.1 +- 0.1 carry an fp32 error of ~0.1 against a variance
+  // contribution of 1.3: the GroupNorm32 of gd/nn.py:16-18 would come out several per cent off).  The pivots are
+  // reconciled below (a lane row to its largest pivot, then the tile's waves in double), before the fixed-point atomics.
+  float ssum[NT][4], ssq[NT][4], piv[NT][4];
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { ssum[i][c] = 0.f; ssq[i][c] = 0.f; }
+    for (int c = 0; c < 4; ++c) { ssum[i][c] = 0.f; ssq[i][c] = 0.f; piv[i][c] = 0.f; }
   // One loop over the wave's MT x NT fragment tiles per output mode, the mode tested OUTSIDE the loop: with the tests
   // inside, every tile jumped over the other modes' code and the launch paid an instruction-cache miss per jump
   // (~4 us of a 128x128-tile launch, tools/fixed_cost_probe3.sh).
@@ -116,8 +121,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
             else *reinterpret_cast<half4*>(out16 + (long long)row(j) * a.ldo + col(i)) = o;
             // the stored (rounded) values: GroupNorm statistics of the next layer / operand of the backward sums below
             const f32x4 fo = {(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+            if (j == 0) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { ssum[i][c] += fo[c]; ssq[i][c] += fo[c] * fo[c]; }
+              for (int c = 0; c < 4; ++c) piv[i][c] = fo[c];
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) { const float d = fo[c] - piv[i][c]; ssum[i][c] += d; ssq[i][c] = fmaf(d, d, ssq[i][c]); }
+            }
             acc[i][j] = fo;
           }
         }
@@ -166,7 +176,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { ssum[i][c] = 0.f; ssq[i][c] = 0.f; }
+      for (int c = 0; c < 4; ++c) { ssum[i][c] = 0.f; ssq[i][c] = 0.f; piv[i][c] = 0.f; }     // O(1) terms: no pivot
     // GroupNorm-backward sums of this gradient tile (see common.h): channel parameters once per i, pixels over j
     const int n_img = m0 / HW;
     const int cpg = a.N / 32;
@@ -202,11 +212,21 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
   if ((a.stat_out || a.gb_x) && a.ksplit == 1) {
     long long* const sdst = a.gb_x ? a.gb_csums : a.stat_out;
     const float scale_q = a.gb_x ? STAT_SCALE_SUM : STAT_SCALE_SQ;
-    // reduce over the 16 pixel-lanes, stage per-wave channel sums in LDS, one atomic per (channel, stat) per block
+    // reduce over the 16 pixel-lanes, stage per-wave channel sums in LDS, one atomic per (channel, stat) per block.
+    // A lane row first moves to its largest pivot P (e = p - P is exact: both are fp16 values):
+    //   sum(x - P) = sum(x - p) + n e,   sum((x - P)^2) = sum((x - p)^2) + 2 e sum(x - p) + n e^2,   n = MT values per lane
+    const bool pivoted = !a.gb_x;
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+        if (pivoted) {
+          const float P = row16_max(piv[i][c]);
+          const float e = piv[i][c] - P;
+          ssq[i][c] = fmaf(e, fmaf((float)MT, e, 2.f * ssum[i][c]), ssq[i][c]);
+          ssum[i][c] = fmaf((float)MT, e, ssum[i][c]);
+          piv[i][c] = P;
+        }
         ssum[i][c] = row16_sum(ssum[i][c]);
         ssq[i][c] = row16_sum(ssq[i][c]);
       }
@@ -217,8 +237,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int nl = wn * TNW + i * 16 + (lane >> 4) * 4 + c;      // channel within the block tile
-          lds_f[(wm * BN + nl) * 2 + 0] = ssum[i][c];
-          lds_f[(wm * BN + nl) * 2 + 1] = ssq[i][c];
+          lds_f[(wm * BN + nl) * 3 + 0] = ssum[i][c];
+          lds_f[(wm * BN + nl) * 3 + 1] = ssq[i][c];
+          lds_f[(wm * BN + nl) * 3 + 2] = piv[i][c];
         }
     }
     __syncthreads();
@@ -226,9 +247,18 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     if (t < BN * 2) {
       const int nl = t >> 1;
       if (n0 + nl < a.N) {
-        const float v = lds_f[t] + lds_f[BN * 2 + t];                   // the two wm waves
+        // the two wm waves, each about its own pivot P over nW = 16 * MT pixels, brought to pivot 0 in double:
+        //   sum x = s + nW P,   sum x^2 = q + 2 P s + nW P^2
+        constexpr double nW = 16.0 * MT;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const double sw = (double)lds_f[(w * BN + nl) * 3 + 0], qw = (double)lds_f[(w * BN + nl) * 3 + 1];
+          const double P = (double)lds_f[(w * BN + nl) * 3 + 2];
+          v += (t & 1) ? qw + P * (2.0 * sw + nW * P) : sw + nW * P;
+        }
         const int n_img = m0 / HW;                                        // a tile never straddles images (HW % BM == 0)
-        const long long fx = __float2ll_rn(v * ((t & 1) ? scale_q : STAT_SCALE_SUM));
+        const long long fx = __double2ll_rn(v * (double)((t & 1) ? scale_q : STAT_SCALE_SUM));
 #ifdef ABL_STAT_COPIES      // harness probe: spread the same-address atomics over ABL_STAT_COPIES copies of the table
         atomicAdd(reinterpret_cast<unsigned long long*>(sdst + (long long)((m0 / BM_T) % ABL_STAT_COPIES) * a.N * 2 +
                                                         ((long long)n_img * a.N + n0 + nl) * 2 + (t & 1)),

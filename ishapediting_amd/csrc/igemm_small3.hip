@@ -384,11 +384,7 @@ int launch_s3(const IgemmArgs& a, const S3Geom& geo, hipStream_t s) {
   const size_t smem = std::max<size_t>((size_t)S3_SLOTS * geo.slot_bytes + 1024, red);
   ISHAP_REQUIRE(smem <= 160 * 1024, "small-map conv: LDS");
   auto kern = conv3_small_kernel<SPC>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    ISHAP_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  ISHAP_TRY(ishap_set_max_lds((const void*)kern, 160 * 1024));
   dim3 grid(a.M / 64, (a.N + 15) / 16, geo.nslice);
   if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(S3_THREADS), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a, geo);
   else hipLaunchKernelGGL(kern, grid, dim3(S3_THREADS), smem, s, a, geo);

@@ -8,7 +8,7 @@ static inline int gn_rows_per_block(int HW) {
   return r;
 }
 static inline size_t gn_partial_floats(int N, int HW, int C) {
-  return (size_t)N * (HW / gn_rows_per_block(HW)) * C * 2;
+  return (size_t)N * (HW / gn_rows_per_block(HW)) * C * 2 * 2;    // (sum, sum of squares) as doubles = 2 floats each
 }
 // stats[n][32][2] = (mean, rstd); partial is scratch of gn_partial_floats()
 int gn_stats_launch(const half_t* x, float* partial, float* stats, int N, int HW, int C, hipStream_t s);
@@ -65,7 +65,9 @@ int gn_backward_launch(const GnBwdArgs& a, hipStream_t s);
 // (image, group) -- H*W pixels x C/32 channels, staged in LDS -- so statistics, normalisation, FiLM, SiLU, pooling and
 // (backward) the group means are ONE launch with no atomics, and the input may be a pending split-K result (SlabSrc).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int GN_REC_STRIDE = 32;     // 8-byte granules per (image, group) in the rendezvous record: 2 per part, up to 16 parts
+constexpr int GN_REC_STRIDE = 32;     // 8-byte granules per (image, group) in the rendezvous record
+constexpr int GN_REC_PER_PART = 4;    // (hi, lo) fp32 pair for each of a part's two sums: up to 8 parts
+constexpr int GN_SPIN_LIMIT = 1 << 22; // polls before a rendezvous gives up (an error, see ISHAP_DEV_GN_RENDEZVOUS)
 
 struct GnLocalArgs {
   // source A: channels [0, Ca) -- a dense fp16 tensor [N][H*W][Ca] or pending fp32 slices (then `ya` receives the fp16 tensor)
@@ -89,8 +91,11 @@ struct GnLocalArgs {
   // partial sums as data-tagged granules); null = one workgroup per group.  `parts` is set by the launcher.
   unsigned long long* rec = nullptr;
   int parts = 1;
+  unsigned* status = nullptr;    // device status word (set by the launcher)
+  int spin_limit = GN_SPIN_LIMIT;
 };
 bool gn_local_fits(int HW, int C);              // LDS budget of the forward / backward staging
+int gn_local_parts(int N, int HW, int C);       // workgroups per (image, group) the launcher picks when a rendezvous record is given
 int gn_local_launch(const GnLocalArgs& a, hipStream_t s);
 
 struct GnBwdLocalArgs {
@@ -111,6 +116,8 @@ struct GnBwdLocalArgs {
   int film = 0, act = 1, gmode = GB_SAME;
   unsigned long long* rec = nullptr;   // as in GnLocalArgs
   int parts = 1;
+  unsigned* status = nullptr;
+  int spin_limit = GN_SPIN_LIMIT;
 };
 bool gn_bwd_local_fits(int HW, int C, int gmode);
 int gn_bwd_local_launch(const GnBwdLocalArgs& a, hipStream_t s);

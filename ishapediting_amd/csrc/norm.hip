@@ -13,10 +13,15 @@
 // ---------------------------------------------------------------------------------------------
 // statistics
 // ---------------------------------------------------------------------------------------------
-// partial[n][blk][C][2]  (sum, sum of squares) over this block's rows
-__global__ __launch_bounds__(256) void gn_partial_kernel(const half_t* __restrict__ x, float* __restrict__ partial,
+// partial[n][blk][C][2]  (sum, sum of squares) over this block's rows, kept in DOUBLE end to end: with |mean| >> std the
+// one-pass E[x^2] - E[x]^2 needs every bit of the sums (a group at mean 100 / std 0.1 loses several per cent of its
+// variance to fp32 partial sums); products of fp16 values are exact in double.  `partial` is typed float for the
+// workspace bookkeeping (gn_partial_floats counts two floats per double).
+__global__ __launch_bounds__(256) void gn_partial_kernel(const half_t* __restrict__ x, float* __restrict__ partial_f,
                                                          int HW, int C, int rows_per_block) {
-  extern __shared__ float red[];                 // [rpi][C][2]
+  extern __shared__ __attribute__((aligned(16))) char red_raw[];
+  double* red = reinterpret_cast<double*>(red_raw);   // [rpi][C][2]
+  double* partial = reinterpret_cast<double*>(partial_f);
   const int CV = C >> 3;
   const int rpi = 256 / CV > 0 ? 256 / CV : 1;   // rows handled per iteration
   const int tid = threadIdx.x;
@@ -25,15 +30,15 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const half_t* __restric
   const int row0 = blk * rows_per_block;
   const bool active = tid < rpi * CV;
   const int cv = tid % CV, r0 = tid / CV;
-  float s[8], q[8];
+  double s[8], q[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
+  for (int i = 0; i < 8; ++i) { s[i] = 0.0; q[i] = 0.0; }
   if (active) {
     const half_t* base = x + ((long long)n * HW + row0) * C + cv * 8;
     for (int r = r0; r < rows_per_block; r += rpi) {
       half8 v = *reinterpret_cast<const half8*>(base + (long long)r * C);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { float f = (float)v[i]; s[i] += f; q[i] += f * f; }
+      for (int i = 0; i < 8; ++i) { const double f = (double)(float)v[i]; s[i] += f; q[i] += f * f; }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -42,18 +47,19 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const half_t* __restric
     }
   }
   __syncthreads();
-  float* out = partial + ((long long)n * gridDim.x + blk) * C * 2;
+  double* out = partial + ((long long)n * gridDim.x + blk) * C * 2;
   for (int c = tid; c < C * 2; c += 256) {
-    float acc = 0.f;
+    double acc = 0.0;
     for (int r = 0; r < rpi; ++r) acc += red[r * C * 2 + c];
     out[c] = acc;
   }
 }
 
 // stats[n][32][2] = (mean, rstd)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial_f, float* __restrict__ stats,
                                                           int nblk, int C, int HW, float eps) {
   __shared__ double sh[2][256];
+  const double* partial = reinterpret_cast<const double*>(partial_f);
   const int g = blockIdx.x, n = blockIdx.y;
   const int cpg = C / 32;
   const int tid = threadIdx.x;
@@ -61,9 +67,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   const int total = nblk * cpg;
   for (int i = tid; i < total; i += 256) {
     int b = i / cpg, c = g * cpg + i % cpg;
-    const float* p = partial + (((long long)n * nblk + b) * C + c) * 2;
-    s += (double)p[0];
-    q += (double)p[1];
+    const double* p = partial + (((long long)n * nblk + b) * C + c) * 2;
+    s += p[0];
+    q += p[1];
   }
   sh[0][tid] = s; sh[1][tid] = q;
   __syncthreads();
@@ -87,13 +93,9 @@ int gn_stats_launch(const half_t* x, float* partial, float* stats, int N, int HW
   int nblk = HW / rpb;
   int CV = C / 8;
   int rpi = 256 / CV > 0 ? 256 / CV : 1;
-  size_t smem = (size_t)rpi * C * 2 * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    ISHAP_CHECK_HIP(hipFuncSetAttribute((const void*)gn_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    attr = true;
-  }
-  ISHAP_REQUIRE(smem <= 65536, "gn_partial LDS");
+  size_t smem = (size_t)rpi * C * 2 * sizeof(double);
+  ISHAP_REQUIRE(smem <= 160 * 1024, "gn_partial LDS");
+  ISHAP_TRY(ishap_set_max_lds((const void*)gn_partial_kernel, 160 * 1024));
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, N), dim3(256), smem, s, x, partial, HW, C, rpb);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, N), dim3(256), 0, s, partial, stats, nblk, C, HW, 1e-5f);
   ISHAP_CHECK_HIP(hipGetLastError());

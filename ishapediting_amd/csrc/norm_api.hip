@@ -1,0 +1,142 @@
+// GroupNorm32 (+ SiLU) and its input gradient as stand-alone C-ABI calls, with the statistics route selectable.
+// Reference: guided_diffusion/nn.py:16-18,92-99 (GroupNorm32: 32 groups, eps 1e-5, computed on x.float()) followed by
+// nn.SiLU (unet.py:179-183), and what autograd derives for them (drag_utils.py:383).
+// The UNet executor picks a route per map size; these entry points run ANY route on a caller-given tensor so that the
+// reference's own primitive fixtures (golden G3b / G15: group means up to 1000x the group spread) reach every one of them:
+//   1  two-pass statistics (gn_partial / gn_finalize, double) + the full-map apply kernel
+//   2  group-local kernel, one workgroup per (image, group)
+//   3  group-local kernel, several workgroups per (image, group) meeting in the in-launch rendezvous
+//   4  statistics as 64-bit fixed-point per-channel sums gathered in an implicit-GEMM epilogue (an identity 1x1
+//      convolution stands in for the producing layer) + the apply kernel's finalise prologue  -- the route of the 128^2 / 64^2 maps
+//   0  what the executor would pick for this map
+#include "../../include/ishap.h"
+#include "norm.h"
+
+namespace {
+
+struct Carve {
+  char* base;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+struct Scratch {
+  unsigned long long* rec;
+  long long* csums;
+  size_t zero_bytes;       // rec + csums: zeroed per call
+  float* partial;
+  half_t* ident;
+  half_t* copy;
+  size_t total;
+};
+Scratch carve(void* base, int N, int HW, int C) {
+  Carve c{(char*)base};
+  Scratch s;
+  s.rec = c.take<unsigned long long>((size_t)N * 32 * GN_REC_STRIDE);
+  s.csums = c.take<long long>((size_t)N * C * 2);
+  s.zero_bytes = align_up(c.off, 256);
+  s.partial = c.take<float>(gn_partial_floats(N, HW, C) + 64);
+  s.ident = c.take<half_t>((size_t)align_up((size_t)C, 128) * C);
+  s.copy = c.take<half_t>((size_t)N * HW * C);
+  s.total = align_up(c.off, 256);
+  return s;
+}
+
+__global__ void identity_fill_kernel(half_t* w, int C, int rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows * C) w[i] = (i / C == i % C) ? (half_t)1.f : (half_t)0.f;
+}
+
+int resolve_route(int route, int HW, int C, bool backward) {
+  if (route != 0) return route;
+  const bool loc = HW <= 1024 && (backward ? gn_bwd_local_fits(HW, C, GB_SAME) : gn_local_fits(HW, C));
+  return loc ? 3 : 4;
+}
+
+}  // namespace
+
+extern "C" {
+
+long long ishap_group_norm32_scratch_bytes(int N, int HW, int C) {
+  if (N < 1 || HW < 1 || C < 32) return 0;
+  return (long long)carve(nullptr, N, HW, C).total;
+}
+
+int ishap_group_norm32(const void* x_nhwc_f16, const float* gamma, const float* beta, int N, int H, int W, int C, int silu,
+                       int route, void* y_nhwc_f16, float* stats, void* scratch, void* stream) {
+  ISHAP_REQUIRE(x_nhwc_f16 && gamma && beta && y_nhwc_f16 && stats && scratch, "null argument");
+  ISHAP_REQUIRE(N >= 1 && N <= 16 && H >= 1 && W >= 1 && C % 32 == 0, "GroupNorm32 dims");
+  ISHAP_REQUIRE(route >= 0 && route <= 4, "route 0..4");
+  ISHAP_TRY(ishap_check_status());
+  hipStream_t s = (hipStream_t)stream;
+  const int HW = H * W;
+  const Scratch sc = carve(scratch, N, HW, C);
+  ISHAP_CHECK_HIP(hipMemsetAsync(scratch, 0, sc.zero_bytes, s));
+  const half_t* x = (const half_t*)x_nhwc_f16;
+  route = resolve_route(route, HW, C, false);
+  if (route == 2 || route == 3) {
+    GnLocalArgs g;
+    g.xa = x; g.Ca = C; g.out = (half_t*)y_nhwc_f16; g.stats_out = stats; g.gamma = gamma; g.beta = beta;
+    g.N = N; g.H = H; g.W = W; g.C = C; g.film = 0; g.act = silu; g.pool = 0;
+    g.rec = route == 3 ? sc.rec : nullptr;
+    return gn_local_launch(g, s);
+  }
+  GnApplyArgs g;
+  g.x = x; g.out = (half_t*)y_nhwc_f16; g.gamma = gamma; g.beta = beta;
+  g.N = N; g.H = H; g.W = W; g.C = C; g.act = silu;
+  if (route == 1) {
+    ISHAP_TRY(gn_stats_launch(x, sc.partial, stats, N, HW, C, s));
+    g.stats = stats;
+  } else {
+    // producer stand-in: copy = x * I through the implicit-GEMM kernel, whose epilogue gathers the per-channel sums
+    ISHAP_REQUIRE(C % 64 == 0 && ((long long)N * HW) % 64 == 0 && C % 8 == 0, "route 4: C % 64 == 0, N*H*W % 64 == 0");
+    const int rows = (int)align_up((size_t)C, 128);
+    hipLaunchKernelGGL(identity_fill_kernel, dim3((rows * C + 255) / 256), dim3(256), 0, s, sc.ident, C, rows);
+    IgemmArgs a;
+    a.X = x; a.Wt = sc.ident; a.out = sc.copy; a.M = N * HW; a.N = C; a.K = C; a.conv3 = 0; a.Cin = C;
+    a.ldx = C; a.ldw = C; a.ldo = C; a.H = H; a.W = W; a.out_mode = IG_OUT_F16; a.ksplit = 1;
+    a.stat_out = sc.csums;
+    ISHAP_TRY(igemm_launch(a, s));
+    g.x = sc.copy; g.sums = sc.csums; g.stats_out = stats;
+  }
+  return gn_apply_launch(g, s);
+}
+
+int ishap_group_norm32_backward(const void* g_nhwc_f16, const void* x_nhwc_f16, const float* stats, const float* gamma,
+                                const float* beta, int N, int H, int W, int C, int silu, int route, void* dx_nhwc_f16,
+                                void* scratch, void* stream) {
+  ISHAP_REQUIRE(g_nhwc_f16 && x_nhwc_f16 && stats && gamma && beta && dx_nhwc_f16 && scratch, "null argument");
+  ISHAP_REQUIRE(N >= 1 && N <= 16 && H >= 1 && W >= 1 && C % 32 == 0, "GroupNorm32 dims");
+  ISHAP_REQUIRE(route >= 0 && route <= 3, "backward route 0..3");
+  ISHAP_TRY(ishap_check_status());
+  hipStream_t s = (hipStream_t)stream;
+  const int HW = H * W;
+  const Scratch sc = carve(scratch, N, HW, C);
+  ISHAP_CHECK_HIP(hipMemsetAsync(scratch, 0, sc.zero_bytes, s));
+  route = resolve_route(route, HW, C, true);
+  if (route == 4) route = 1;
+  if (route == 2 || route == 3) {
+    GnBwdLocalArgs a;
+    a.g = (const half_t*)g_nhwc_f16; a.x = (const half_t*)x_nhwc_f16; a.dx = (half_t*)dx_nhwc_f16;
+    a.stats = stats; a.gamma = gamma; a.beta = beta; a.N = N; a.H = H; a.W = W; a.C = C; a.film = 0; a.act = silu;
+    a.gmode = GB_SAME;
+    a.rec = route == 3 ? sc.rec : nullptr;
+    return gn_bwd_local_launch(a, s);
+  }
+  GnBwdArgs a;
+  a.g = (const half_t*)g_nhwc_f16; a.x = (const half_t*)x_nhwc_f16; a.dx = (half_t*)dx_nhwc_f16;
+  a.stats = stats; a.gamma = gamma; a.beta = beta; a.N = N; a.H = H; a.W = W; a.C = C; a.film = 0; a.act = silu;
+  a.gmode = GB_SAME; a.csums = sc.csums;
+  return gn_backward_launch(a, s);
+}
+
+/* workgroups per (image, group) the group-local kernels use for this shape on the current device (tests assert that a
+ * case really exercises the in-launch rendezvous) */
+int ishap_group_norm32_parts(int N, int HW, int C) { return gn_local_parts(N, HW, C); }
+
+}  // extern "C"

@@ -124,31 +124,45 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
 
 // Several workgroups share one (image, group): each publishes its two partial sums as data-tagged 8-byte granules
 // {fp32 value, tag} -- ONE naturally aligned agent-scope (sc1, write-through) store each, so a granule is valid by itself and
-// needs no flag, fence or ordering -- and every workgroup polls all 2 * parts granules of its group with agent-scope loads
-// until the tags are there (MI355X_MICROARCH.md, handoff-1to1: ~1 us per hop).  The totals are formed from the parts in
-// part order in double: bitwise reproducible, no atomics.  rec = [parts][2] granules, zeroed before the launch (tag 0 =
-// not yet written).  The launcher only uses parts > 1 when the whole grid is resident at once (<= 256 workgroups of
-// <= 1024 threads); the spin is bounded all the same.
+// needs no flag, fence or ordering -- and every workgroup polls all GN_REC_PER_PART * parts granules of its group with
+// agent-scope loads until the tags are there (MI355X_MICROARCH.md, handoff-1to1: ~1 us per hop).
+// A sum travels as TWO granules, hi = (float)s and lo = (float)(s - hi): the pair carries 48 significant bits, so the
+// variance q/cnt - mean^2 formed from the exchanged totals is as cancellation-safe as the one-workgroup route, which keeps
+// its sums in double (a group with |mean| = 100 std: one fp32 granule per sum lost ~10 % of the variance).
+// The totals are formed from the parts in part order in double: bitwise reproducible, no atomics.
+// rec = [parts][4] granules, zeroed before the launch (tag 0 = not yet written).  The launcher only uses parts > 1 when the
+// whole grid is resident at once; the spin is bounded all the same, and a give-up is an ERROR: it raises the process-wide
+// device status word (common.h) and poisons this group's sums with NaN, so nothing downstream looks plausible.
 __device__ __forceinline__ void group_rendezvous(double& a, double& b, unsigned long long* rec, int part, int parts,
-                                                 double* scratch) {
+                                                 double* scratch, unsigned* status, int spin_limit) {
   if (parts <= 1) return;
   __syncthreads();
-  if (threadIdx.x < 2) {
-    const float v = threadIdx.x == 0 ? (float)a : (float)b;
+  if (threadIdx.x < GN_REC_PER_PART) {
+    const double d = (threadIdx.x & 2) ? b : a;
+    const float hi = (float)d;
+    const float v = (threadIdx.x & 1) ? (float)(d - (double)hi) : hi;
     const unsigned long long granule = (unsigned long long)__float_as_uint(v) | (1ull << 32);
-    __hip_atomic_store(rec + part * 2 + threadIdx.x, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rec + part * GN_REC_PER_PART + threadIdx.x, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if ((int)threadIdx.x < 2 * parts) {
+  if ((int)threadIdx.x < GN_REC_PER_PART * parts) {
     unsigned long long gr = 0;
     int spins = 0;
     do {
       gr = __hip_atomic_load(rec + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } while ((gr >> 32) == 0ull && ++spins < (1 << 22));
-    scratch[threadIdx.x] = (double)__uint_as_float((unsigned)(gr & 0xffffffffull));
+    } while ((gr >> 32) == 0ull && ++spins < spin_limit);
+    double v = (double)__uint_as_float((unsigned)(gr & 0xffffffffull));
+    if ((gr >> 32) == 0ull) {          // a part never arrived: the grid was not co-resident (or a part faulted)
+      __hip_atomic_store(status, (unsigned)ISHAP_DEV_GN_RENDEZVOUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      v = __builtin_nan("");
+    }
+    scratch[threadIdx.x] = v;
   }
   __syncthreads();
   double ta = 0.0, tb = 0.0;
-  for (int p = 0; p < parts; ++p) { ta += scratch[2 * p]; tb += scratch[2 * p + 1]; }
+  for (int p = 0; p < parts; ++p) {    // (hi + lo) is exact in double; parts add in part order
+    ta += scratch[GN_REC_PER_PART * p] + scratch[GN_REC_PER_PART * p + 1];
+    tb += scratch[GN_REC_PER_PART * p + 2] + scratch[GN_REC_PER_PART * p + 3];
+  }
   a = ta;
   b = tb;
   __syncthreads();
@@ -158,7 +172,7 @@ __device__ __forceinline__ void group_rendezvous(double& a, double& b, unsigned 
 template <int VEC, bool FILM, bool ACT, bool POOL>
 __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* scratch = reinterpret_cast<double*>(smem_raw);                 // 32 doubles
+  double* scratch = reinterpret_cast<double*>(smem_raw);                 // 32 doubles (block_sum2: 2 x 16; rendezvous: 4 x parts)
   half_t* st = reinterpret_cast<half_t*>(smem_raw + 256);                // [HW][cpg]
   const int g = blockIdx.x / a.parts, part = blockIdx.x - g * a.parts, n = blockIdx.y;
   const int C = a.C, cpg = C / 32, VPP = cpg / VEC, HW = a.H * a.W;
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
     for (int i = 0; i < VEC; ++i) { s += (double)v[i]; q += (double)v[i] * (double)v[i]; }
   }
   block_sum2(s, q, scratch);
-  group_rendezvous(s, q, a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE, part, a.parts, scratch);
+  group_rendezvous(s, q, a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE, part, a.parts, scratch, a.status, a.spin_limit);
   const double cnt = (double)HW * (double)cpg;
   const double md = s / cnt;
   double vd = q / cnt - md * md;
@@ -345,7 +359,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(GnBwdLocalArgs a) {
     }
   }
   block_sum2(s1, s2, scratch);
-  group_rendezvous(s1, s2, a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE, part, a.parts, scratch);
+  group_rendezvous(s1, s2, a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE, part, a.parts, scratch, a.status, a.spin_limit);
   const double cnt = (double)HW * (double)cpg;
   const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt);
   __syncthreads();
@@ -406,24 +420,28 @@ int pick_parts(int N, int HW, int cpg, int unit, bool have_rec) {
   // with the tagged-granule rendezvous, tools/gn_parts_probe.sh: local-GN kernel time 193 / 198 / 216 / 243 at >= 128 / 256 /
   // 1024 / 2048 elements, 226 / 271 with at most 4 / 2 parts, 203-214 with up to 16 parts)
   int p = 1;
-  static const int max_wgs = [] { const char* e = getenv("ISHAP_GN_MAX_WGS"); return e ? atoi(e) : 256; }();
-  while (p * 2 <= maxp && p * 2 <= GN_REC_STRIDE / 2 && 32 * N * (p * 2) <= max_wgs && HW % (p * 2) == 0 && (HW / (p * 2)) % unit == 0 &&
-         (long long)(HW / (p * 2)) * cpg >= min_el)
+  // co-residency: a workgroup of these kernels (<= 1024 threads, <= 160 KB of LDS) always fits a compute unit by itself, so
+  // a grid of at most one workgroup per CU OF THIS DEVICE (a partitioned MI355X exposes fewer than 256) becomes resident
+  // whatever else is draining; ISHAP_GN_MAX_WGS can only lower that bound
+  static const int env_wgs = [] { const char* e = getenv("ISHAP_GN_MAX_WGS"); return e ? atoi(e) : 0; }();
+  int max_wgs = ishap_cu_count();
+  if (env_wgs > 0 && env_wgs < max_wgs) max_wgs = env_wgs;
+  while (p * 2 <= maxp && p * 2 <= GN_REC_STRIDE / GN_REC_PER_PART && 32 * N * (p * 2) <= max_wgs && HW % (p * 2) == 0 &&
+         (HW / (p * 2)) % unit == 0 && (long long)(HW / (p * 2)) * cpg >= min_el)
     p *= 2;
   return p;
 }
 constexpr size_t LOCAL_LDS_CAP = 160 * 1024 - 256;
+// polls before a rendezvous gives up; ISHAP_GN_SPIN_LIMIT exists so that a test can force the give-up path (1 poll)
+int spin_limit() {
+  static const int v = [] { const char* e = getenv("ISHAP_GN_SPIN_LIMIT"); const int n = e ? atoi(e) : 0; return n > 0 ? n : GN_SPIN_LIMIT; }();
+  return v;
+}
 
 template <typename K>
 int set_lds(K kern, size_t smem) {
-  // per kernel symbol: raise the dynamic LDS limit once
-  static thread_local const void* done[64];
-  static thread_local int ndone = 0;
-  for (int i = 0; i < ndone; ++i) if (done[i] == (const void*)kern) return 0;
-  ISHAP_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LOCAL_LDS_CAP + 256));
-  if (ndone < 64) done[ndone++] = (const void*)kern;
   (void)smem;
-  return 0;
+  return ishap_set_max_lds((const void*)kern, (int)LOCAL_LDS_CAP + 256);
 }
 
 }  // namespace
@@ -431,6 +449,7 @@ int set_lds(K kern, size_t smem) {
 bool gn_local_fits(int HW, int C) {
   return C % 32 == 0 && (size_t)HW * (C / 32) * sizeof(half_t) <= LOCAL_LDS_CAP;
 }
+int gn_local_parts(int N, int HW, int C) { return C % 32 ? 1 : pick_parts(N, HW, C / 32, 1, true); }
 bool gn_bwd_local_fits(int HW, int C, int gmode) {
   return C % 32 == 0 && (size_t)HW * (C / 32) * (gmode != GB_SAME ? sizeof(float) : sizeof(half_t)) <= LOCAL_LDS_CAP;
 }
@@ -443,6 +462,9 @@ int gn_local_launch(const GnLocalArgs& a, hipStream_t s) {
   const int HW = a.H * a.W, cpg = a.C / 32;
   ISHAP_REQUIRE(gn_local_fits(HW, a.C), "group does not fit in LDS");
   GnLocalArgs b = a;
+  b.spin_limit = spin_limit();
+  b.status = ishap_status_word();
+  ISHAP_REQUIRE(b.status != nullptr, "device status word");
   b.parts = pick_parts(a.N, HW, cpg, a.pool ? 2 * a.W : 1, a.rec != nullptr);
   const int PP = HW / b.parts;
   const int VEC = pick_vec(cpg, PP, a.slab.pending());
@@ -484,6 +506,9 @@ int gn_bwd_local_launch(const GnBwdLocalArgs& a, hipStream_t s) {
   const int HW = a.H * a.W, cpg = a.C / 32;
   const bool s32 = a.gmode != GB_SAME;      // 0.25 * fp16 and sums of four fp16 values are kept in fp32 between the passes
   GnBwdLocalArgs b = a;
+  b.spin_limit = spin_limit();
+  b.status = ishap_status_word();
+  ISHAP_REQUIRE(b.status != nullptr, "device status word");
   b.parts = pick_parts(a.N, HW, cpg, 1, a.rec != nullptr);
   const int PP = HW / b.parts;
   const size_t smem = 256 + (size_t)PP * cpg * (s32 ? sizeof(float) : sizeof(half_t));

@@ -200,6 +200,7 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
 // small maps (<= 32 x 32): GroupNorm passes run group-local (norm_local.hip), producers gather no statistics
 int unet_join_tail(ishap_unet* u, hipStream_t s);
 bool small_map(int HW);
+bool exec_is_solo(const Exec& e);   // no other stream of this context has work in flight (in-launch rendezvous allowed)
 bool local_gn(int HW, int C);
 int slab_materialize(Exec& e, Tensor& t);    // add up a pending tensor with the stand-alone reduce kernel (consumers that cannot)
 long long* salloc(Exec& e, size_t count);   // from the stats arena

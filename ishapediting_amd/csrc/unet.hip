@@ -259,6 +259,8 @@ long long* salloc(Exec& e, size_t count) {
   return u->stat_off <= u->stat_cap ? u->stat_base + o : nullptr;
 }
 
+bool exec_is_solo(const Exec& e) { return e.dry || (!e.u->tail_pending && (e.u->side == nullptr || e.s != e.u->side)); }
+
 bool small_map(int HW) {
   static const int on = [] { const char* v = getenv("ISHAP_LOCAL_GN"); return v ? atoi(v) : 1; }();
   return on && HW <= (on == 2 ? 64 : 1024);      // 2: only the 8x8 maps
@@ -349,7 +351,9 @@ static int gn_local_op(Exec& e, Tensor& x, const NormW& nw, half_t* out, half_t*
   g.N = x.N; g.H = x.H; g.W = x.W; g.C = x.C; g.film = film; g.act = act; g.pool = pool;
   long long* rec = nullptr;
   ISHAP_SALLOC(rec, e, (size_t)x.N * 32 * GN_REC_STRIDE);       // zeroed with the statistics arena at the start of the forward
-  g.rec = reinterpret_cast<unsigned long long*>(rec);
+  // several workgroups per group rendezvous inside the launch: only while this launch sequence is the context's only one
+  // (beside an overlapped forward tail two half-resident rendezvous grids could wait on each other's compute units)
+  g.rec = exec_is_solo(e) ? reinterpret_cast<unsigned long long*>(rec) : nullptr;
   if (e.dry) return 0;
   return gn_local_launch(g, e.s);
 }
@@ -805,6 +809,7 @@ int ishap_unet_forward(ishap_unet* u, const float* x, const float* timesteps, in
                        void* inter_feat, int keep_for_backward, void* stream) {
   ISHAP_REQUIRE(u && x && timesteps && out, "null argument");
   ISHAP_REQUIRE(u->n_loaded == (int)u->params.size(), "missing keys: not every state_dict tensor has been loaded");
+  ISHAP_TRY(ishap_check_status());          // an earlier launch's device-side failure surfaces here
   ISHAP_CHECK_HIP(hipSetDevice(u->device));
   return unet_forward_impl(u, x, timesteps, N, feat_layer, out, inter_feat, keep_for_backward, (hipStream_t)stream, false);
 }
@@ -835,6 +840,7 @@ int ishap_unet_block_output(const ishap_unet* u, int group, int index, int* chan
   if (size) *size = b->res_out;
   if (!dst_nchw_f16) return 0;
   ISHAP_REQUIRE(u->have_saved && b->out.p, "block outputs stay resident only after a forward with keep_for_backward=1");
+  ISHAP_TRY(ishap_check_status());
   ISHAP_CHECK_HIP(hipSetDevice(u->device));
   ISHAP_TRY(unet_join_tail(const_cast<ishap_unet*>(u), (hipStream_t)stream));
   return nhwc_f16_to_nchw(b->out.p, dst_nchw_f16, 0, b->out.N, b->out.C, b->out.H * b->out.W, b->out.C, (hipStream_t)stream);

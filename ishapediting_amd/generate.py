@@ -80,10 +80,12 @@ def main(argv=None, overrides=None):
     for idx, triplane in enumerate(samples):
         np.save(f"{args.save_dir}/triplanes/{idx}.npy", triplane)
     os.makedirs(f"{args.save_dir}/objects", exist_ok=True)
-    decoder = MultiTriplane(1, device=image_sample.dev())
-    decoder.net.load_state_dict(dec_sd if dec_sd is not None else th.load(args.decoder_ckpt, map_location="cpu"))
+    from . import visualize
     for idx, triplane in enumerate(samples):
-        decode_to_obj(triplane, decoder, args.shape_resolution, f"{args.save_dir}/objects/{idx}.obj")
+        print(f"Decoding triplane {idx}...")
+        decoder_args = Namespace(input=f"{args.save_dir}/triplanes/{idx}.npy", output=f"{args.save_dir}/objects/{idx}.obj",
+                                 model_path=args.decoder_ckpt, res=args.shape_resolution)
+        visualize.main(args=decoder_args, state_dict=dec_sd)        # generate.py:88-95
     print("Done!")
     print("decode time:", time.time() - t2)
 

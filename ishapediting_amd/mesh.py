@@ -18,7 +18,7 @@ from . import _lib
 
 
 MAX_OBJ_VERTICES = 4_000_000      # text export limit (a 256^3 shape has well under a million surface vertices)
-BACKEND = "device"                # "device" | "third_party"; set explicitly, results never depend on what happens to be installed
+BACKEND = "device"                # "device" | "open3d" | "third_party"; set explicitly, results never depend on what happens to be installed
 METHODS = {"marching_tetrahedra": 0, "marching_cubes": 1}
 
 
@@ -121,15 +121,37 @@ def mesh_chamfer(mesh_a, mesh_b, point_num: int = 20000, seed: int = 0) -> float
     return chamfer_distance(pa, pb, point_num=None)
 
 
+class _Points:
+    """What `np.asarray(mesh.vertices)` / `len(mesh.vertices)` need (main.py:507): a lazy host view of a device array."""
+
+    def __init__(self, fetch):
+        self._fetch = fetch
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._fetch()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __len__(self):
+        return int(self._fetch().shape[0])
+
+
 class OccupancyMesh:
-    """The mesh get_mesh returns when PyMCubes/Open3D are absent: the device volume plus, on first use, its surface
-    (vertices in the reference's convention grid/res*2-1, visualize.py:101) after `smooth_iterations` sweeps."""
+    """The mesh get_mesh returns with the default "device" backend: the device volume plus, on first use, its surface
+    (vertices in the reference's convention grid/res*2-1, visualize.py:101) after `smooth_iterations` sweeps.
+
+    It carries the part of open3d.geometry.TriangleMesh's surface the reference's GUI touches on `drag_stuff.mesh`
+    (main.py:288,314,373,478,507) -- `has_vertex_normals()`, `has_triangle_normals()`, `compute_vertex_normals()`,
+    `np.asarray(mesh.vertex_normals)`, `copy.deepcopy` -- and `to_open3d()`, which builds the real TriangleMesh for
+    `update_mesh` (Open3D is imported only there, when called).  `.vertices` / `.triangles` stay device tensors (the
+    product's own consumers: Chamfer, sampling, OBJ export); `np.asarray` of them works through torch's __array__ only for
+    host tensors, so GUI code goes through `to_open3d()` or `vertices_numpy()`."""
 
     def __init__(self, volume: torch.Tensor, res: int, smooth_iterations: int = 10):
         self.volume = volume
         self.res = res
         self.smooth_iterations = smooth_iterations
         self._mesh = None
+        self._vnormals = None
 
     def _build(self):
         if self._mesh is None:
@@ -149,18 +171,92 @@ class OccupancyMesh:
     def counts(self):
         return surface_counts(self.volume, 0.0)
 
+    # ---- the TriangleMesh surface main.py uses ----
+    def vertices_numpy(self) -> np.ndarray:
+        return self.vertices.detach().cpu().numpy().astype(np.float64)
+
+    def triangles_numpy(self) -> np.ndarray:
+        return self.triangles.detach().cpu().numpy().astype(np.int32)
+
+    def has_vertex_normals(self) -> bool:
+        return self._vnormals is not None
+
+    def has_triangle_normals(self) -> bool:
+        return False
+
+    def compute_vertex_normals(self, normalized: bool = True):
+        """TriangleMesh.compute_vertex_normals: area-weighted sum of the incident triangles' normals, normalised."""
+        self._vnormals = vertex_normals(self.vertices, self.triangles, normalized)
+        return self
+
+    @property
+    def vertex_normals(self):
+        return _Points(lambda: np.zeros((0, 3)) if self._vnormals is None else self._vnormals.detach().cpu().numpy().astype(np.float64))
+
+    def to_open3d(self):
+        """The open3d.geometry.TriangleMesh the reference's get_mesh returns (visualize.py:102-104 + drag_utils.py:300):
+        same vertices / triangles, already smoothed on the device.  Imports Open3D here and nowhere else."""
+        import open3d as o3d
+        m = o3d.geometry.TriangleMesh()
+        m.vertices = o3d.utility.Vector3dVector(self.vertices_numpy())
+        m.triangles = o3d.utility.Vector3iVector(self.triangles_numpy())
+        if self._vnormals is not None:
+            m.vertex_normals = o3d.utility.Vector3dVector(np.asarray(self.vertex_normals))
+        return m
+
     def __deepcopy__(self, memo):
         m = OccupancyMesh(self.volume.clone(), self.res, self.smooth_iterations)
         if self._mesh is not None:
             m._mesh = (self._mesh[0].clone(), self._mesh[1].clone())
+        if self._vnormals is not None:
+            m._vnormals = self._vnormals.clone()
         return m
 
 
+def vertex_normals(verts: torch.Tensor, tris: torch.Tensor, normalized: bool = True) -> torch.Tensor:
+    """Per-vertex normals as Open3D's compute_vertex_normals defines them: the sum over incident triangles of the
+    (unnormalised, i.e. area-weighted) face normal cross(v1 - v0, v2 - v0), then normalised.  Display-side plumbing in
+    torch ops on the device (not on the timed path)."""
+    v = verts.detach().to(torch.float32)
+    t = tris.detach().to(device=v.device, dtype=torch.long)
+    fn = torch.cross(v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 0]], dim=1)
+    out = torch.zeros_like(v)
+    for k in range(3):
+        out.index_add_(0, t[:, k], fn)
+    if normalized:
+        out = out / out.norm(dim=1, keepdim=True).clamp_min(1e-30)
+    return out
+
+
+def mesh_arrays(mesh):
+    """(vertices [V,3] float32, triangles [F,3] int32) as numpy from whatever a caller hands train_triplane(mesh=...):
+    a (vertices, triangles) pair, an OccupancyMesh, or any object with `.vertices` / `.triangles` (an
+    open3d.geometry.TriangleMesh, main.py:447-451) -- read with np.asarray, nothing Open3D-specific."""
+    if isinstance(mesh, OccupancyMesh):
+        return mesh.vertices_numpy().astype(np.float32), mesh.triangles_numpy()
+    if isinstance(mesh, tuple):
+        v, t = mesh
+    else:
+        v, t = mesh.vertices, mesh.triangles
+    if torch.is_tensor(v):
+        v = v.detach().cpu().numpy()
+    if torch.is_tensor(t):
+        t = t.detach().cpu().numpy()
+    return np.asarray(v, dtype=np.float32).reshape(-1, 3), np.asarray(t, dtype=np.int32).reshape(-1, 3)
+
+
 def volume_to_mesh(volume: torch.Tensor, res: int, smooth_iterations: int = 10, backend: str = None):
-    """get_mesh's mesh (drag_utils.py:298-300).  backend None -> the module-level BACKEND."""
+    """get_mesh's mesh (drag_utils.py:298-300).  backend None -> the module-level BACKEND:
+      "device"      OccupancyMesh (surface, smoothing on the device; vertices / triangles stay device tensors)
+      "open3d"      the same device surface handed over as an open3d.geometry.TriangleMesh -- what the reference's GUI
+                    expects from drag_stuff.mesh (main.py:288,314,373,478,507); only the final vertex / triangle arrays
+                    cross PCIe (a few MB, not the 67 MB volume)
+      "third_party" the reference's own PyMCubes + Open3D calls on the host."""
     backend = BACKEND if backend is None else backend
     if backend == "device":
         return OccupancyMesh(volume, res, smooth_iterations)
+    if backend == "open3d":
+        return OccupancyMesh(volume, res, smooth_iterations).to_open3d()
     if backend != "third_party":
         raise ValueError(f"unknown mesh backend {backend!r}")
     import mcubes
@@ -170,7 +266,7 @@ def volume_to_mesh(volume: torch.Tensor, res: int, smooth_iterations: int = 10, 
     mesh = o3d.geometry.TriangleMesh()
     mesh.vertices = o3d.utility.Vector3dVector(vertices)
     mesh.triangles = o3d.utility.Vector3iVector(triangles)
-    return mesh.filter_smooth_simple(number_of_iterations=smooth_iterations)
+    return mesh.filter_smooth_simple(number_of_iterations=smooth_iterations) if smooth_iterations > 0 else mesh
 
 
 def _write_obj(path, verts: torch.Tensor, tris: torch.Tensor):
@@ -182,7 +278,7 @@ def _write_obj(path, verts: torch.Tensor, tris: torch.Tensor):
 
 
 def write_mesh(path, mesh):
-    """o3d.io.write_triangle_mesh (drag_utils.py:470) when Open3D produced the mesh; Wavefront OBJ of the device mesh otherwise."""
+    """o3d.io.write_triangle_mesh (drag_utils.py:470) when the mesh is an Open3D object; Wavefront OBJ of the device mesh otherwise."""
     if isinstance(mesh, OccupancyMesh):
         nv, nt = mesh.counts()
         if nv > MAX_OBJ_VERTICES:
@@ -249,8 +345,9 @@ def sample_surface_points(verts: torch.Tensor, tris: torch.Tensor, n: int, gener
 def sample_occupancy(mesh, mesh_path, center_mesh, points_size, uniform_ratio, device=None, generator=None):
     """drag_utils.py:411-440: `points_size` samples (a `uniform_ratio` share uniform in [-1,1]^3, the rest on the surface
     plus N(0, 0.01) noise) with their occupancy.  BACKEND "third_party": Open3D (RaycastingScene) exactly as the
-    reference; "device" (default): the mesh (an OBJ file, or a (vertices, triangles) pair) is sampled on the device.
-    Returns (None, None) when no mesh is given."""
+    reference; "device" (default): the mesh -- an OBJ file, a (vertices, triangles) pair, an OccupancyMesh or ANY object
+    with `.vertices` / `.triangles` such as the open3d TriangleMesh the GUI passes (main.py:447-451) -- is sampled on
+    the device.  Returns (None, None) when no mesh is given."""
     if mesh is None and mesh_path is None:
         return None, None
     o3d = None
@@ -276,8 +373,8 @@ def sample_occupancy(mesh, mesh_path, center_mesh, points_size, uniform_ratio, d
         occ = scene.compute_occupancy(pts).numpy().reshape(-1, 1).astype(np.float32)
         return pts, occ
     # ---- device route ----
-    if isinstance(mesh, tuple):
-        v_np, t_np = np.asarray(mesh[0], np.float32), np.asarray(mesh[1], np.int32)
+    if mesh is not None:
+        v_np, t_np = mesh_arrays(mesh)
     else:
         v_np, t_np = read_obj(mesh_path)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)

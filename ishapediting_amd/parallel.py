@@ -28,7 +28,14 @@ def gather_volumes(volumes: Sequence[torch.Tensor], n_edits: int, dst: int = 0, 
     like = volumes[0] if volumes else None
     if full_shape is not None:
         full = tuple(int(v) for v in full_shape)
-        dev = like.device
+        # a rank that owns no edit still takes part in the gather: its padding lives on its own device (the current
+        # CUDA device under RCCL, the CPU under gloo)
+        if like is not None:
+            dev = like.device
+        elif dist.get_backend() == "nccl":
+            dev = torch.device("cuda", torch.cuda.current_device())
+        else:
+            dev = torch.device("cpu")
     else:
         shape = torch.tensor(list(like.shape) if like is not None else [0, 0, 0], device=like.device if like is not None else "cpu")
         # every rank owns at least one edit when n_edits >= world; otherwise agree on the shape first

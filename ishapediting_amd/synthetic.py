@@ -39,6 +39,24 @@ def unet_state_dict(cfg: UNetConfig, seed: int = 1234, gain: float = 1.0) -> Dic
     return sd
 
 
+def unet_state_dict_offset(cfg: UNetConfig, seed: int, offset: float = 6.0, gain: float = 0.25) -> Dict[str, torch.Tensor]:
+    """Like unet_state_dict, but every torso conv bias is (a per-GroupNorm-group constant of magnitude ~`offset`, random
+    sign) + N(0, 0.01), and the conv weights are small (`gain`): the activations a GroupNorm reads then sit at a group
+    mean tens of times their spread -- the regime where a one-pass fp32 variance cancels (nn.py:16-18 works in fp32 on
+    x.float()).  Groups follow GroupNorm32's split of the conv's OUTPUT channels into 32 groups."""
+    sd = unet_state_dict(cfg, seed, gain)
+    g = torch.Generator().manual_seed(seed + 7)
+    for name, t in sd.items():
+        if not (name.endswith(".bias") and is_torso_conv(name)) or ".qkv." in name:
+            continue            # qkv feeds the softmax, not a GroupNorm: its bias stays small
+        C = t.shape[0]
+        if C % 32:
+            continue
+        per_group = (torch.rand(32, generator=g) * 0.5 + 0.75) * offset * torch.sign(torch.randn(32, generator=g))
+        sd[name] = (per_group.repeat_interleave(C // 32) + 0.01 * torch.randn(C, generator=g)).float()
+    return sd
+
+
 def round_torso_to_fp16(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Values the fp16 torso would hold (fp16_util.py:14-21), kept as fp32
     storage so an fp32 oracle and the fp16 device path share exact weights."""

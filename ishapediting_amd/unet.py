@@ -163,20 +163,28 @@ class UNetModel:
     def tap_ptr(self) -> int:
         return self._L.ishap_unet_tap_ptr(self._h)
 
-    def copy_tap(self, feat_layer: int, N: int = 1) -> torch.Tensor:
-        """The resident tap of the last forward as an NHWC fp16 tensor [N, S*S, C] (device copy)."""
+    def copy_tap(self, feat_layer: int, N: Optional[int] = None) -> torch.Tensor:
+        """The resident tap of the last forward as an NHWC fp16 tensor [N, S*S, C] (device copy); N is the last forward's
+        batch size (the library copies that many images)."""
         ch, sz = self.tap_shape(feat_layer)
+        last = self._last_shape[0] if self._last_shape is not None else 1
+        if N is not None and N != last:
+            raise ValueError(f"copy_tap: the resident tap holds {last} image(s), not {N}")
+        N = last
         t = torch.empty((N, sz * sz, ch), dtype=torch.float16, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self._L.ishap_unet_copy_tap(self._h, t.data_ptr(), _lib.stream_ptr(self.device)))
         return t
 
-    def block_output(self, group: int, index: int = 0, N: int = 1) -> torch.Tensor:
+    def block_output(self, group: int, index: int = 0) -> torch.Tensor:
         """Output of input_blocks[index] (group 0), middle_block (1) or output_blocks[index] (2) of the last
-        forward(keep_for_backward=True), as fp16 NCHW like the reference's activations."""
+        forward(keep_for_backward=True), as fp16 NCHW like the reference's activations.  The batch size is the kept
+        forward's (the library writes that many images)."""
         ch, sz = C.c_int(), C.c_int()
         _lib.check(self._L.ishap_unet_block_output(self._h, group, index, C.byref(ch), C.byref(sz), None, None))
-        t = torch.empty((N, ch.value, sz.value, sz.value), dtype=torch.float16, device=self.device)
+        if self._last_shape is None:
+            raise RuntimeError("block outputs stay resident only after a forward with keep_for_backward=1")
+        t = torch.empty((self._last_shape[0], ch.value, sz.value, sz.value), dtype=torch.float16, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self._L.ishap_unet_block_output(self._h, group, index, C.byref(ch), C.byref(sz), t.data_ptr(),
                                                        _lib.stream_ptr(self.device)))

@@ -1,0 +1,296 @@
+"""Round-3 parity tests for the numerics holes VERDICT r2 named: GroupNorm with group means far from zero on EVERY
+statistics route (golden G15 / G3b, straight from the reference's GroupNorm32), the bounded rendezvous that now raises,
+and the chained loops against the reference's own fp16-torso runs (golden G14a-c) instead of fp32 ones.
+Needs an MI355X: -m gpu.  Nothing here reads /root/reference."""
+import ctypes as C
+import os
+import subprocess
+import sys
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from ishapediting_amd import _lib, synthetic
+from ishapediting_amd.unet_spec import UNetConfig, build_spec, tiny_config
+from tests.helpers import redraw_generate_noise, small96_args, small96_config
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda", 0)
+
+
+def rel(a, b):
+    a = a.detach().float().cpu()
+    b = torch.as_tensor(b).float()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def nhwc(x_nchw):
+    """[N,C,H,W] -> the library's activation layout [N][H*W][C] fp16 on the device."""
+    n, c, h, w = x_nchw.shape
+    return x_nchw.permute(0, 2, 3, 1).reshape(n, h * w, c).contiguous().half().to(dev())
+
+
+def nchw(t, n, c, h, w):
+    return t.float().cpu().reshape(n, h, w, c).permute(0, 3, 1, 2)
+
+
+def group_norm(x, w, b, silu, route):
+    """ishap_group_norm32 on an NCHW tensor of fp16-exact values -> (y NCHW fp32 on the CPU, stats device tensor)."""
+    L = _lib.lib()
+    n, c, h, ww = x.shape
+    xd = nhwc(x)
+    y = torch.empty_like(xd)
+    stats = torch.empty(n * 64, dtype=torch.float32, device=dev())
+    scratch = torch.empty(int(L.ishap_group_norm32_scratch_bytes(n, h * ww, c)), dtype=torch.uint8, device=dev())
+    wd, bd = w.float().to(dev()), b.float().to(dev())
+    _lib.check(L.ishap_group_norm32(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), n, h, ww, c, int(silu), route, y.data_ptr(),
+                                    stats.data_ptr(), scratch.data_ptr(), _lib.stream_ptr(dev())))
+    torch.cuda.synchronize()
+    return nchw(y, n, c, h, ww), stats, xd
+
+
+def group_norm_backward(ct, xd, stats, w, b, shape, silu, route):
+    L = _lib.lib()
+    n, c, h, ww = shape
+    gd = nhwc(ct)
+    dx = torch.empty_like(gd)
+    scratch = torch.empty(int(L.ishap_group_norm32_scratch_bytes(n, h * ww, c)), dtype=torch.uint8, device=dev())
+    wd, bd = w.float().to(dev()), b.float().to(dev())
+    _lib.check(L.ishap_group_norm32_backward(gd.data_ptr(), xd.data_ptr(), stats.data_ptr(), wd.data_ptr(), bd.data_ptr(), n, h, ww,
+                                             c, int(silu), route, dx.data_ptr(), scratch.data_ptr(), _lib.stream_ptr(dev())))
+    torch.cuda.synchronize()
+    return nchw(dx, n, c, h, ww)
+
+
+# ------------------------------------------------------------------------------------------ GroupNorm32 alone, 1000x
+@pytest.mark.parametrize("route", [1, 2, 3, 4])
+@pytest.mark.parametrize("silu", [0, 1])
+def test_group_norm32_with_group_mean_1000x_its_spread(gold, route, silu):
+    """GroupNorm32 (+ SiLU) of the reference (nn.py:16-18) on a 32x32 map whose groups sit at |mean| = 100 with std 0.1
+    (golden G15), through each statistics route of the library: two-pass (1), group-local with one (2) and with several
+    workgroups per group (3: the in-launch rendezvous; its partial sums used to travel as one fp32 each, which cost ~10 %
+    of the variance here), fixed-point sums from a convolution epilogue (4).  The outputs are fp16 (the torso's storage):
+    tolerance 2e-3 relative L2 and 6e-3 max abs on O(1) values = two fp16 roundings; a 10 % variance error shows as 5e-2."""
+    g = gold("g15_large_group_means")
+    x, w, b = T(g["gn_x"]).float(), T(g["gn_w"]), T(g["gn_b"])
+    want = g["gn_y_silu"] if silu else g["gn_y_plain"]
+    if route == 3:
+        parts = _lib.lib().ishap_group_norm32_parts(1, 32 * 32, 64)
+        assert parts > 1, "this shape must exercise the rendezvous"
+    y, stats, xd = group_norm(x, w, b, silu, route)
+    r, mx = rel(y, want), float((y - T(want)).abs().max())
+    print(f"GroupNorm32 route {route} silu {silu}: rel {r:.2e} max abs {mx:.2e}")
+    assert r < 2e-3 and mx < 6e-3
+    # statistics themselves: mean to fp32 rounding, rstd to 1e-4 relative (the quantity the cancellation destroys)
+    xs = x.reshape(1, 32, -1).double()
+    mean, var = xs.mean(-1), xs.var(-1, unbiased=False)
+    st = stats.cpu().reshape(1, 32, 2).double()
+    np.testing.assert_allclose(st[..., 0].numpy(), mean.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(st[..., 1].numpy(), (1.0 / torch.sqrt(var + 1e-5)).numpy(), rtol=1e-4)
+    if route == 4:
+        return                                       # the backward has no epilogue-sum route of its own at this level
+    want_g = g["gn_gx_silu"] if silu else g["gn_gx_plain"]
+    dx = group_norm_backward(T(g["gn_ct"]).float(), xd, stats, w, b, x.shape, silu, route)
+    rg = rel(dx, want_g)
+    print(f"GroupNorm32 backward route {route} silu {silu}: rel {rg:.2e}")
+    assert rg < 3e-3
+
+
+@pytest.mark.parametrize("route", [1, 2, 3, 4])
+def test_group_norm32_g3b_fixture_reaches_the_device(gold, route):
+    """The round-2 fixture G3b (GroupNorm32 + SiLU, 8x8 map, |mean| = 100, batch 2) was only read by the CPU oracle; here
+    it goes through the library (at 8x8 x 2 channels per group a group is one workgroup even on route 3)."""
+    g = gold("g3b_block_primitives")
+    y, _, _ = group_norm(T(g["gn_x"]).float(), T(g["gn_w"]), T(g["gn_b"]), 1, route)
+    r = rel(y, g["gn_y"])
+    print(f"G3b GroupNorm32 route {route}: rel {r:.2e}")
+    assert r < 2e-3
+
+
+def test_rendezvous_and_one_workgroup_routes_agree_bitwise(gold):
+    """norm_local.hip's header claims both group-local routes give the same values: with the (hi, lo) exchange the totals
+    agree to ~1e-15 relative, so the fp32 (mean, rstd) and every fp16 output are identical."""
+    g = gold("g15_large_group_means")
+    x, w, b = T(g["gn_x"]).float(), T(g["gn_w"]), T(g["gn_b"])
+    y2, s2, _ = group_norm(x, w, b, 1, 2)
+    y3, s3, _ = group_norm(x, w, b, 1, 3)
+    assert torch.equal(s2, s3) and torch.equal(y2, y3)
+
+
+# ------------------------------------------------------------------------------------------ whole model, 40-80x
+def offset64_config():
+    return UNetConfig(image_size=64, in_channels=6, model_channels=64, out_channels=12, num_res_blocks=1,
+                      attention_resolutions="4", channel_mult=(1, 1, 2), num_head_channels=64)
+
+
+def test_model_with_large_group_means_vs_reference_runs(gold):
+    """offset64 model (64^2 maps: GroupNorm statistics as fixed-point sums from the conv epilogues; 32^2 / 16^2: group-local
+    with a rendezvous) whose conv biases put most GroupNorm inputs at a group mean 40-80x the group spread (golden G15
+    lists the measured ratios): output, two taps, input gradients from a tap and from the output, against the
+    reference's fp16-torso run (like for like) and its fp32 run.
+    Tolerances: at ratio R an fp16-stored activation carries a relative error of R * 2^-11 / sqrt(3) ~ 1.7e-2 (R = 60) of
+    the group spread that GroupNorm then scales to O(1) -- in the reference's half torso as in ours, with different
+    roundings -- so two correct fp16 runs differ by a few 1e-2: forward 3e-2, gradients 6e-2 (relative L2); the fp32
+    reference sits at the same distance from both.  The bug this guards against (10 % variance) moves outputs by 5e-2
+    per affected layer and compounds over the 13 ResBlocks."""
+    from ishapediting_amd.unet import UNetModel
+    g = gold("g15_large_group_means")
+    assert float(np.median(g["ratio_median"])) > 20 and float(g["ratio_median"].max()) > 60
+    cfg = offset64_config()
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict_offset(cfg, 141, offset=6.0))
+    m = UNetModel(cfg, dev())
+    m.load_state_dict(sd)
+    x, ts = T(g["x"]).to(dev()), T(g["ts"]).float()
+    k1, k2 = [int(v) for v in g["taps_k"]]
+    errs = {}
+    for k in (k1, k2):
+        out, tap = m(x, ts, feat_layer=k, keep_for_backward=True)
+        errs[f"tap{k}"] = (rel(tap, g[f"f16_tap{k}"].astype(np.float32)), rel(tap, g[f"f32_tap{k}"].astype(np.float32)))
+        if k == k1:
+            ct = T(g[f"tap{k}_ct"])
+            cot = ct[0].permute(1, 2, 0).reshape(1, -1, ct.shape[1]).contiguous().half().to(dev())
+            gx = m.backward_input(cot)
+            errs[f"tap{k}_gx"] = (rel(gx, g[f"f16_tap{k}_gx"]), rel(gx, g[f"f32_tap{k}_gx"]))
+    errs["out"] = (rel(out, g["f16_out"]), rel(out, g["f32_out"]))
+    m(x, ts, feat_layer=k2, keep_for_backward=True, want_inter_feat=False)
+    gx = m.backward_from_output(T(g["out_ct"]).to(dev()))
+    errs["out_gx"] = (rel(gx, g["f16_out_gx"]), rel(gx, g["f32_out_gx"]))
+    ref_gap = {k: rel(T(g[f"f16_{k}"].astype(np.float32)), g[f"f32_{k}"].astype(np.float32))
+               for k in (f"tap{k1}", f"tap{k2}", "out", f"tap{k1}_gx", "out_gx")}
+    for k, (e16, e32) in errs.items():
+        print(f"offset64 {k}: vs reference fp16 torso {e16:.2e}, vs fp32 {e32:.2e}; reference fp16 vs its own fp32 {ref_gap[k]:.2e}")
+    assert int(_lib.lib().ishap_device_status()) == 0
+    for k, (e16, e32) in errs.items():
+        tol = 6e-2 if k.endswith("gx") else 3e-2
+        assert e16 < tol and e32 < tol, (k, e16, e32)
+
+
+# ------------------------------------------------------------------------------------------ the rendezvous gives up loudly
+_GIVE_UP = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from tests.test_gpu_norm import group_norm, T
+from tests.conftest import golden
+from ishapediting_amd import _lib
+g = golden("g15_large_group_means")
+y, stats, _ = group_norm(T(g["gn_x"]).float(), T(g["gn_w"]), T(g["gn_b"]), 1, 3)
+bad = int(torch.isnan(y).any())
+rc = int(_lib.lib().ishap_device_status())
+msg = _lib.lib().ishap_last_error().decode()
+again = int(_lib.lib().ishap_device_status())
+print("RESULT", bad, rc, again, msg)
+"""
+
+
+def test_rendezvous_give_up_raises_instead_of_using_zeros():
+    """A rendezvous whose other parts do not show up used to continue with tag-0 granules (value 0: wrong statistics, no
+    error).  Forced here by one poll per wait (ISHAP_GN_SPIN_LIMIT=1, own process: the limit is read once): the launch
+    poisons its output with NaN, the next status check fails with a message naming the rendezvous, and the word is cleared
+    once reported."""
+    env = dict(os.environ, ISHAP_GN_SPIN_LIMIT="1")
+    r = subprocess.run([sys.executable, "-c", _GIVE_UP % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+    assert line, r.stdout + r.stderr
+    bad, rc, again, msg = line[0].split(" ", 4)[1:]
+    assert int(bad) == 1 and int(rc) == -3 and int(again) == 0 and "rendezvous" in msg, line[0]
+
+
+# ------------------------------------------------------------------------------------------ like-for-like fp16 loops (G14)
+def tiny_args(Tn, w_time, feat_layer):
+    return Namespace(clip_denoised=True, num_samples=1, batch_size=1, use_ddim=False, num_steps=Tn, image_size=16,
+                     num_channels=32, num_res_blocks=1, num_heads=4, num_heads_upsample=-1, num_head_channels=32,
+                     attention_resolutions="8", channel_mult="1,2", dropout=0.1, class_cond=False, shape_resolution=32,
+                     use_checkpoint=False, use_scale_shift_norm=True, resblock_updown=True, use_fp16=True,
+                     use_new_attention_order=False, in_out_channels=6, learn_sigma=True, diffusion_steps=1000,
+                     noise_schedule="linear", timestep_respacing=str(Tn), w_time=w_time, feat_layer=feat_layer,
+                     loss_type="l2", use_kl=False, predict_xstart=False, rescale_timesteps=False,
+                     rescale_learned_sigmas=False, explicit_normalization=False)
+
+
+def test_latent_inversion_vs_reference_fp16_torso_run(gold):
+    """ddpm_inversion (gaussian_diffusion.py:512-532) against the reference run with ITS fp16 torso (golden G14a; inputs
+    and noise are those of G8).  Like for like, so the round-2 allowances for 'fp16 vs fp32' are gone: inverted variance
+    <= 1e-2 (was 3e-2), variance_noise / sample / taps <= 1e-2 (was 2e-2)."""
+    from ishapediting_amd.drag_utils import DragStuff
+    g, h = gold("g8_g9_tiny_loops"), gold("g14a_tiny_loops_fp16")
+    Tn, w_time, feat_layer, r1, B = g["meta"].tolist()
+    ds = DragStuff(dev(), args=tiny_args(Tn, w_time, feat_layer))
+    ds.model.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(tiny_config(1), 101)))
+    captured = []
+    ds.get_mesh = lambda tri_feat=None, img=None, t=0: captured.append(tri_feat)
+    fwd = [n.to(dev()) for n in T(g["inv_fwd_noise"])]
+    ds.latent_inversion(T(g["inv_x0"]).to(dev()), fwd_noise=fwd)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(ds.w.cpu().numpy(), h["inv_latent"], rtol=0, atol=1e-5)
+    r_var = rel(torch.stack(ds.variance), h["inv_variance"])
+    r_vn = rel(torch.stack(ds.variance_noise), h["inv_variance_noise"])
+    r_s = rel(captured[-1], h["inv_sample"])
+    ch, sz = ds.model.tap_shape(feat_layer)
+    r_tap = max(rel(tap.reshape(sz, sz, ch).permute(2, 0, 1).unsqueeze(0).float(), h["inv_inter_feat"][k])
+                for k, tap in enumerate(ds.feature_guidance))
+    ref_gap = rel(T(h["inv_variance"]), g["inv_variance"])
+    print(f"inversion vs fp16-torso reference: variance {r_var:.2e}, variance_noise {r_vn:.2e}, sample {r_s:.2e}, taps {r_tap:.2e}"
+          f" (reference fp16 vs its fp32 variance: {ref_gap:.2e})")
+    assert r_var < 1e-2 and r_vn < 1e-2 and r_s < 1e-2 and r_tap < 1e-2
+
+
+def test_reconstruction_steps_vs_reference_fp16_torso_run(gold):
+    """train_triplane's guided loop, one step at a time from the reference's own fp16-torso latents (golden G14b; inputs
+    of G11).  For every step the fixture holds the reference's fp16-torso result AND its fp32 result from the same input
+    state; their distance is the reference's own one-step precision spread (0.113 at step 0, where t = 999 makes
+    pred_xstart = clamp(157.1 x - 157.1 eps) amplify the torso's rounding 157x before the clip; 4.6e-3, 1.8e-2 and 8e-6
+    at the later steps).  No implementation can be asked to sit closer to either run than they sit to each other, so the
+    bound is stated relative to that spread, not picked after a run: the device result must lie within
+    max(5e-3, 1.5 x spread) of BOTH reference results (5e-3 = the single-step floor of an fp16 torso).  Round 2 asserted a
+    flat 0.25 / 2e-2 against the fp32 run alone."""
+    from ishapediting_amd.drag_utils import DragStuff
+    g, h = gold("g11_reconstruct"), gold("g14b_reconstruct_fp16")
+    Tn = int(g["T"])
+    args = small96_args(Tn)
+    ds = DragStuff(dev(), args=args)
+    ds.model.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(small96_config(), 202)))
+    ds.decoder.net.load_state_dict(synthetic.decoder_state_dict())
+    ds.range, ds.middle = T(g["range"]).to(dev()), T(g["middle"]).to(dev())
+    noise, coords, gts = T(g["noise"]).to(dev()), T(g["coords"]).to(dev()), T(g["gt"]).to(dev())
+    ds.step_noise = lambda i: noise[Tn - 1 - i]
+    prev = T(g["img0"])
+    for k in range(Tn):
+        i = Tn - 1 - k
+        img = ds.reconstruct(None, None, scale=600, img=prev, batch_fn=lambda ii: (coords[Tn - 1 - ii], gts[Tn - 1 - ii]),
+                             steps=[i])
+        torch.cuda.synchronize()
+        loss = float(ds.last_losses[0])
+        r16, r32 = rel(img, h["imgs"][k]), rel(img, h["imgs_fp32_same_input"][k])
+        spread = rel(T(h["imgs"][k]), h["imgs_fp32_same_input"][k])
+        print(f"reconstruct step {k} (t={i}): vs reference fp16 torso {r16:.3e}, vs its fp32 on the same input {r32:.3e}; "
+              f"reference fp16 vs fp32 {spread:.3e}; loss {loss:.6f} vs {float(h['losses'][k]):.6f}")
+        assert abs(loss - float(h["losses"][k])) <= 2e-3 * abs(float(h["losses"][k]))
+        bound = max(5e-3, 1.5 * spread)
+        assert r16 < bound and r32 < bound, (k, r16, r32, spread)
+        prev = T(h["imgs"][k])
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_noise2shape_vs_reference_fp16_torso_run(gold, B):
+    """The generate path against the reference's p_sample_loop with its fp16 torso (golden G14c, the configuration
+    generate.py really runs: use_fp16=True): <= 1e-2 relative L2 over the 5 chained steps (2e-2 against the fp32 run)."""
+    from ishapediting_amd import image_sample
+    g, h = gold("g12_generate"), gold("g14c_generate_fp16")
+    Tn = int(g["T"])
+    init, steps = redraw_generate_noise(g, B)
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(small96_config(), 303))
+    stepd = steps.to(dev())
+    arr = image_sample.noise2shape(small96_args(Tn, batch=B), state_dict=sd, bounds=(g["lower_bound"], g["upper_bound"]),
+                                   noise=init.to(dev()), step_noise=lambda i: stepd[Tn - 1 - i])
+    r16, r32 = rel(T(arr), h[f"b{B}_arr"]), rel(T(arr), g[f"b{B}_arr"])
+    gap = rel(T(h[f"b{B}_arr"]), g[f"b{B}_arr"])
+    print(f"noise2shape batch {B}: vs reference fp16 torso {r16:.2e}, vs fp32 {r32:.2e}; reference fp16 vs fp32 {gap:.2e}")
+    assert r16 < 1e-2

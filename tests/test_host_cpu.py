@@ -81,13 +81,19 @@ def _worker(rank, world, port, n_edits, q):
         out2 = gather_volumes(vols, n_edits, dst=0, full_shape=(4, 4, 4), recv=recv)
         if rank == 0:
             assert all(torch.equal(a, b) for a, b in zip(out, out2)) and out2[0] is recv[0]
+    if n_edits < world:
+        # a rank that owns NO edit must still take part when the shape is passed explicitly (it used to raise
+        # AttributeError on `None.device` while the other ranks waited in dist.gather)
+        out3 = gather_volumes(vols, n_edits, dst=0, full_shape=(4, 4, 4))
+        if rank == 0:
+            assert len(out3) == n_edits and all(torch.equal(a, b) for a, b in zip(out, out3))
     if rank == 0:
         q.put([float(v[0, 0, 0]) for v in out])
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_edits", [2, 3, 4])
+@pytest.mark.parametrize("n_edits", [1, 2, 3, 4])
 def test_gather_volumes_world_size_2_gloo(n_edits):
     import socket
     import torch.multiprocessing as mp
@@ -119,3 +125,38 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from ishapediting_amd.unet_spec import tiny_config
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         UNetModel(tiny_config(1), torch.device("cpu"))
+
+
+def test_visualize_mirrors_the_reference_signatures():
+    """triplane_decoder/visualize.py:36,76,108: same parameter names, order and defaults (SURVEY 8b keeps these callable)."""
+    import inspect
+    from ishapediting_amd import visualize
+    sig = lambda f: [(p.name, p.default) for p in inspect.signature(f).parameters.values()]
+    E = inspect.Parameter.empty
+    assert sig(visualize.create_obj) == [("model", E), ("obj_idx", E), ("res", 128), ("max_batch_size", 50000),
+                                         ("output_path", "output.obj")]
+    assert sig(visualize.create_obj_o3d) == [("model", E), ("obj_idx", E), ("res", 128), ("max_batch_size", 50000)]
+    assert sig(visualize.main)[:2] == [("args", None), ("feature", None)]
+    a = visualize.build_parser().parse_args(["--output", "o.obj"])
+    assert a.res == 128 and a.input is None and a.model_path.endswith(".pt")
+
+
+def test_mesh_arrays_reads_any_object_with_vertices_and_triangles():
+    """train_triplane(mesh=<open3d TriangleMesh>) (main.py:447-451): the device route takes the arrays with np.asarray."""
+    from types import SimpleNamespace
+    from ishapediting_amd.mesh import mesh_arrays
+    m = SimpleNamespace(vertices=[[0.0, 0, 0], [1, 0, 0], [0, 1, 0]], triangles=[[0, 1, 2]])
+    v, t = mesh_arrays(m)
+    assert v.dtype == np.float32 and v.shape == (3, 3) and t.dtype == np.int32 and t.shape == (1, 3)
+    v2, t2 = mesh_arrays((torch.tensor(m.vertices), torch.tensor(m.triangles)))
+    assert np.array_equal(v, v2) and np.array_equal(t, t2)
+
+
+def test_bench_counts_gpus_without_loading_hip(monkeypatch):
+    """bench.py's spawning parent must not initialise the GPU: the count comes from sysfs and *_VISIBLE_DEVICES."""
+    import bench
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    n = bench.visible_gpu_count()
+    assert n is not None and n <= 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0

@@ -157,13 +157,18 @@ def g3_primitives():
     save("g3_primitives", **out)
 
 
-def load_ref_unet(cfg, seed, respacing, gain=1.0):
-    model, diff = ref_model_and_diffusion(cfg, respacing)
-    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, seed, gain))
+def load_ref_unet(cfg, seed, respacing, gain=1.0, fp16=False, sd=None):
+    """fp16=True: the reference's own precision contract (create with use_fp16=True, then convert_to_fp16(), as
+    generate.py:67 / drag_utils.py:51,232 do) -- the torso runs in half on the CPU (torch 2.10 supports it)."""
+    model, diff = ref_model_and_diffusion(cfg, respacing, use_fp16=fp16)
+    if sd is None:
+        sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, seed, gain))
     assert set(sd) == set(model.state_dict()), "unet_spec key table differs from the reference module tree"
     for k, v in model.state_dict().items():
         assert tuple(v.shape) == tuple(sd[k].shape), k
     model.load_state_dict(sd, strict=True)
+    if fp16:
+        model.convert_to_fp16()
     model.eval()
     return model, diff
 
@@ -293,10 +298,10 @@ def g7b_drag_loss_values():
     pass
 
 
-def g8_g9_tiny_loops():
+def g8_g9_tiny_loops(fp16=False, name="g8_g9_tiny_loops"):
     cfg = tiny_config(1)
     T, w_time, feat_layer, r1, B = 6, 3, 1, 2, 2
-    model, diff = load_ref_unet(cfg, 101, str(T))
+    model, diff = load_ref_unet(cfg, 101, str(T), fp16=fp16)
     g = torch.Generator().manual_seed(61)
     out = {}
     # ---- G8: ddpm_inversion (noise via torch.manual_seed) ----
@@ -355,7 +360,11 @@ def g8_g9_tiny_loops():
     out["drag_final"] = finals[-1][1]
     out["drag_stop_time"] = finals[-1][2]
     out["meta"] = np.array([T, w_time, feat_layer, r1, B])
-    save("g8_g9_tiny_loops", **out)
+    if fp16:        # the inputs are those of the fp32 fixture (same seeds): keep only what the fp16 torso changes
+        out = {k: v for k, v in out.items() if k in ("inv_latent", "inv_sample", "inv_variance_noise", "inv_variance",
+                                                     "inv_inter_feat", "loop_final_unguided", "loop_w", "loop_guidance",
+                                                     "drag_final", "drag_stop_time", "drag_progress", "meta")}
+    save(name, **out)
 
 
 def small96_config():
@@ -363,13 +372,13 @@ def small96_config():
                       attention_resolutions="8", channel_mult=(1, 2), num_head_channels=32)
 
 
-def g11_reconstruct():
+def g11_reconstruct(fp16=False, name="g11_reconstruct"):
     """Two steps of train_triplane's guided loop (drag_utils.py:445-463), restated line by line over the
     reference's own model / diffusion / MultiTriplane objects (the method itself needs Open3D for its sampling)."""
     import torch as th
     cfg = small96_config()
     T = 4
-    model, diff = load_ref_unet(cfg, 202, str(T))
+    model, diff = load_ref_unet(cfg, 202, str(T), fp16=fp16)
     dec = MultiTriplane(1, input_dim=3, output_dim=1, device="cpu")
     dec.net.load_state_dict(synthetic.decoder_state_dict())
     dec.eval()
@@ -386,22 +395,35 @@ def g11_reconstruct():
     noises = th.randn(T, 1, 96, 16, 16, generator=g)
     out = {"img0": img, "range": rng, "middle": mid, "coords": coords, "gt": gts, "noise": noises, "T": T}
     scale = 600
-    imgs, losses, grads = [], [], []
-    for k, i in enumerate(range(T - 1, -1, -1)):
-        img = img.detach().requires_grad_(True)
-        outs = diff.p_sample_guidance(model, img, th.tensor([i]), noise=noises[k])
+
+    def one_step(m, d, img_in, k, i):
+        img_in = img_in.detach().clone().requires_grad_(True)
+        outs = d.p_sample_guidance(m, img_in, th.tensor([i]), noise=noises[k])
         predict_x0 = (outs["pred_xstart"] * rng + mid).reshape(3, 32, 16, 16)
         for j in range(3):
             dec.embeddings[j] = predict_x0[[j]]
         prediction = dec(0, coords[k].unsqueeze(0)).squeeze(0)
         loss = -th.nn.BCEWithLogitsLoss()(prediction, gts[k])
         loss.backward()
-        grads1 = img.grad.clone().detach()
+        grads1 = img_in.grad.clone().detach()
         with th.no_grad():
-            img = (outs["sample"] + outs["variance"] * (scale * grads1)).clone().detach()
-        imgs.append(img); losses.append(loss.detach()); grads.append(grads1)
+            new = (outs["sample"] + outs["variance"] * (scale * grads1)).clone().detach()
+        return new, loss.detach(), grads1
+
+    # the fp16 fixture also records, for every step, what the reference's fp32 model makes of the SAME input state: the
+    # distance between the two is the reference's own one-step precision spread, the yardstick of the like-for-like test
+    model32, diff32 = load_ref_unet(cfg, 202, str(T)) if fp16 else (None, None)
+    imgs, losses, grads, imgs32 = [], [], [], []
+    for k, i in enumerate(range(T - 1, -1, -1)):
+        if fp16:
+            imgs32.append(one_step(model32, diff32, img, k, i)[0])
+        img, loss, grads1 = one_step(model, diff, img, k, i)
+        imgs.append(img); losses.append(loss); grads.append(grads1)
     out["imgs"] = th.stack(imgs); out["losses"] = th.stack(losses); out["grads"] = th.stack(grads)
-    save("g11_reconstruct", **out)
+    if fp16:
+        out["imgs_fp32_same_input"] = th.stack(imgs32)
+        out = {k: out[k] for k in ("imgs", "losses", "grads", "T", "imgs_fp32_same_input")}
+    save(name, **out)
 
 
 
@@ -487,7 +509,7 @@ def g4b_block_outputs():
     save("g4b_block_outputs", **out)
 
 
-def g12_generate():
+def g12_generate(fp16=False, name="g12_generate"):
     """The generate path (image_sample.py:173-192): the reference's p_sample_loop with its own RNG draws (noise=None:
     th.randn(*shape) then randn_like per step, gaussian_diffusion.py:629,437), its unnormalize (normalization.py:6-15)
     and the NHWC permute, for batch 1 and 3 on small96_config."""
@@ -495,7 +517,7 @@ def g12_generate():
     from neural_field_diffusion.guided_diffusion.normalization import unnormalize
     cfg = small96_config()
     T = 5
-    model, diff = load_ref_unet(cfg, 303, str(T))
+    model, diff = load_ref_unet(cfg, 303, str(T), fp16=fp16)
     g = torch.Generator().manual_seed(81)
     lower = -(torch.rand(96, generator=g) + 0.5).numpy().astype(np.float32)
     upper = (torch.rand(96, generator=g) + 0.5).numpy().astype(np.float32)
@@ -518,7 +540,9 @@ def g12_generate():
                                                   float(steps[-1, -1, -1, -1, -1])], dtype=np.float64)
             out[f"b{B}_sample"] = sample
             out[f"b{B}_arr"] = arr
-    save("g12_generate", **out)
+    if fp16:
+        out = {k: v for k, v in out.items() if k.endswith("_sample") or k.endswith("_arr") or k == "T"}
+    save(name, **out)
 
 
 def g13_ddim():
@@ -541,6 +565,92 @@ def g13_ddim():
     save("g13_ddim", **out)
 
 
+def g14_fp16_loops():
+    """the chained loops of G8/G9, G11 and G12 re-run by the reference with its own fp16 torso
+    (model.convert_to_fp16(), unet.py:618-624 / fp16_util.py:14-21) on the SAME inputs and seeds, so the device path is
+    compared like for like (fp16 torso vs fp16 torso) and not against an fp32 run."""
+    g8_g9_tiny_loops(fp16=True, name="g14a_tiny_loops_fp16")
+    g11_reconstruct(fp16=True, name="g14b_reconstruct_fp16")
+    g12_generate(fp16=True, name="g14c_generate_fp16")
+
+
+def offset64_config():
+    """64 channels on 64^2 and 32^2 maps, 128 on 16^2 with attention: the 64^2 level runs the full-map GroupNorm route
+    (statistics gathered as 64-bit fixed-point sums in the producing convolution's epilogue), the 32^2 / 16^2 levels the
+    group-local route with several workgroups per (image, group)."""
+    return UNetConfig(image_size=64, in_channels=6, model_channels=64, out_channels=12, num_res_blocks=1,
+                      attention_resolutions="4", channel_mult=(1, 1, 2), num_head_channels=64)
+
+
+def g15_large_group_means():
+    """VERDICT r2 item 1b / ADVICE: GroupNorm inputs whose group mean is far from zero (nn.py:16-18 computes in fp32 on
+    x.float(); a one-pass variance in fp32 cancels).  (i) offset64_config with conv biases that give every GroupNorm
+    group a mean of 30-60 times its spread (synthetic.unet_state_dict_offset): output, two taps and the input gradient
+    from one tap and from the output, from the reference in fp32 and with its fp16 torso.  (ii) GroupNorm32 (+ SiLU)
+    alone on a 32x32 map with |mean| = 100, std 0.1 (1000x): output and the input gradient of sum(y * ct)."""
+    from neural_field_diffusion.guided_diffusion.nn import normalization
+    out = {}
+    cfg = offset64_config()
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict_offset(cfg, 141, offset=6.0))
+    g = torch.Generator().manual_seed(142)
+    x = torch.randn(1, 6, 64, 64, generator=g)
+    ts = torch.tensor([311])
+    n_out = 3 * 2
+    taps_k = (1, n_out - 2)
+    for tag, fp16 in (("f32", False), ("f16", True)):
+        model, _ = load_ref_unet(cfg, 0, "10", fp16=fp16, sd=sd)
+        assert len(model.output_blocks) == n_out
+        rec = {}
+        hooks = []
+        if not fp16:
+            # ratio |group mean| / group std of every GroupNorm input, to document what the fixture exercises
+            def probe(m, a, name):
+                v = a[0].detach().float()
+                N, C = v.shape[:2]
+                gv = v.reshape(N, 32, -1)
+                rec[name] = float((gv.mean(-1).abs() / (gv.std(-1) + 1e-12)).median())
+            for name, mod in model.named_modules():
+                if mod.__class__.__name__ == "GroupNorm32":
+                    hooks.append(mod.register_forward_hook(lambda m, a, o, name=name: probe(m, a, name)))
+        for k in taps_k:
+            xx = x.clone().requires_grad_(True)
+            o, feat = model(xx, ts, feat_layer=k)
+            out[f"{tag}_tap{k}"] = feat.half()          # the device tap is fp16; tolerance 1e-2
+            if k == taps_k[0]:
+                ct = torch.randn(feat.shape, generator=torch.Generator().manual_seed(1400 + k)) * 0.1
+                gx, = torch.autograd.grad((feat.float() * ct).sum(), xx)
+                out[f"tap{k}_ct"] = ct
+                out[f"{tag}_tap{k}_gx"] = gx
+        for h in hooks:
+            h.remove()
+        xx = x.clone().requires_grad_(True)
+        o = model(xx, ts)
+        ct = torch.randn(o.shape, generator=torch.Generator().manual_seed(1499)) * 0.1
+        gx, = torch.autograd.grad((o * ct).sum(), xx)
+        out[f"{tag}_out"] = o
+        out["out_ct"] = ct
+        out[f"{tag}_out_gx"] = gx
+        if not fp16:
+            out["ratio_names"] = np.array(sorted(rec))
+            out["ratio_median"] = np.array([rec[k] for k in sorted(rec)])
+            print("median |mean|/std per GroupNorm input:", {k: round(v, 1) for k, v in rec.items()})
+    out["x"], out["ts"], out["taps_k"] = x, ts, np.array(taps_k)
+    # (ii) GroupNorm32 + SiLU alone, 1000x
+    gn = normalization(64)
+    sdg = _seed_module(gn, 1402)
+    gg = torch.Generator().manual_seed(143)
+    xg = (torch.randn(1, 64, 32, 32, generator=gg) * 0.1 + 100.0 * torch.randn(1, 64, 1, 1, generator=gg).sign()).half().float()
+    ctg = torch.randn(1, 64, 32, 32, generator=gg).half().float()
+    xr = xg.clone().requires_grad_(True)
+    y = torch.nn.functional.silu(gn(xr.float()))
+    gxg, = torch.autograd.grad((y * ctg).sum(), xr)
+    yp = gn(xr.float())
+    gxp, = torch.autograd.grad((yp * ctg).sum(), xr)
+    out["gn_x"], out["gn_ct"], out["gn_w"], out["gn_b"] = xg.half(), ctg.half(), sdg["weight"], sdg["bias"]     # fp16-exact values
+    out["gn_y_silu"], out["gn_gx_silu"], out["gn_y_plain"], out["gn_gx_plain"] = y, gxg, yp, gxp
+    save("g15_large_group_means", **out)
+
+
 def g10_full_keys():
     """Key table + parameter count of the full-size model (structure only, no tensors stored)."""
     cfg = full_config()
@@ -559,7 +669,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = _WHICH
     todo = [g1_schedules, g2_steps, g3_primitives, g3b_block_primitives, g4_tiny_unet, g4b_block_outputs, g6_decoder, g7_drag,
-            g8_g9_tiny_loops, g10_full_keys, g11_reconstruct, g12_generate, g13_ddim]
+            g8_g9_tiny_loops, g10_full_keys, g11_reconstruct, g12_generate, g13_ddim, g14_fp16_loops, g15_large_group_means]
     if which:
         todo = [f for f in todo if f.__name__ in which]
     with torch.no_grad():
