@@ -43,6 +43,7 @@ static int gn_bwd_local_op(Exec& e, const GnBwdArgs& g, Tensor& up) {
   a.g = up.p; a.slab = up.pend; a.x = g.x; a.add = g.add; a.add2 = g.add2; a.dx = g.dx; a.dx2 = g.dx2; a.csplit = g.csplit;
   a.stats = g.stats; a.gamma = g.gamma; a.beta = g.beta; a.emb = g.emb; a.emb_ld = g.emb_ld;
   a.N = g.N; a.H = g.H; a.W = g.W; a.C = g.C; a.film = g.film; a.act = g.act; a.gmode = g.gmode;
+  a.pf = g.pf;
   long long* rec = nullptr;
   ISHAP_SALLOC(rec, e, (size_t)g.N * 32 * GN_REC_STRIDE);       // zeroed with the rest of the statistics arena
   a.rec = exec_is_solo(e) ? reinterpret_cast<unsigned long long*>(rec) : nullptr;     // see gn_local_op
@@ -55,8 +56,9 @@ static bool local_gn_bwd(int HW, int C, int gmode) { return small_map(HW) && gn_
 // `split` > 0: the block input was a skip concatenation [h | skip]; its gradient is written as two dense tensors
 // (dx = first `split` channels, *dx2 = the rest) so no slicing pass is needed afterwards.
 // `add2`: a gradient map of the block input's shape (the skip-connection gradient of an input block) added to the result.
+// `next`: weights of the first convolution the backward pass runs after this block (prefetched by this block's last kernel)
 static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int split = 0, Tensor* dx2 = nullptr,
-                        const half_t* add2 = nullptr) {
+                        const half_t* add2 = nullptr, PrefetchHint next = PrefetchHint{}) {
   ishap_unet* u = e.u;
   const ResSaved& sv = L.sv;
   const Tensor& x = sv.x;
@@ -74,6 +76,7 @@ static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int spli
     ISHAP_TRY(dgrad_op(e, L.c2, dy, dc, L.cout, loc ? nullptr : &g, loc));
     ISHAP_ALLOC(dh1.p, e, h1.numel());
     g.g = dc.p; g.dx = dh1.p;
+    g.pf = pf_bwd(L.c1);
     if (loc) ISHAP_TRY(gn_bwd_local_op(e, g, dc));
     else ISHAP_TRY(gn_bwd_op(e, g));
   }
@@ -105,12 +108,13 @@ static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int spli
   }
   dx.sums = nullptr;
   g1.g = da.p; g1.add = add; g1.dx = dx.p; g1.add2 = add2;
+  g1.pf = next;
   if (loc1) ISHAP_TRY(gn_bwd_local_op(e, g1, da));
   else ISHAP_TRY(gn_bwd_op(e, g1));
   return 0;
 }
 
-static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx) {
+static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx, PrefetchHint next = PrefetchHint{}) {
   ishap_unet* u = e.u;
   const AttnSaved& sv = L.sv;
   const Tensor& x = sv.x;
@@ -139,10 +143,18 @@ static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx) {
     ISHAP_TRY(dgrad_op(e, L.qkv, dqkv, dn, C, loc ? nullptr : &g, loc));
     ISHAP_ALLOC(dx.p, e, x.numel());
     g.g = dn.p; g.add = dy.p; g.dx = dx.p;
+    g.pf = next;
     if (loc) ISHAP_TRY(gn_bwd_local_op(e, g, dn));
     else ISHAP_TRY(gn_bwd_op(e, g));
   }
   return 0;
+}
+
+// the first convolution a layer's backward runs: its weights are what the kernel before it should prefetch
+static PrefetchHint first_bwd_weights(ishap_unet* u, const LayerRef& l) {
+  if (l.kind == 0) return pf_bwd(u->stem);
+  if (l.kind == 1) return pf_bwd(u->res[l.idx].c2);
+  return pf_bwd(u->attn[l.idx].proj);
 }
 
 static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out, int split = 0, Tensor* out2 = nullptr,
@@ -150,15 +162,16 @@ static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out, int split =
   ishap_unet* u = e.u;
   for (int i = (int)b.layers.size() - 1; i >= 0; --i) {
     const LayerRef& l = b.layers[i];
+    const PrefetchHint next = i > 0 ? first_bwd_weights(u, b.layers[i - 1]) : e.next_block_pf;
     Tensor dx;
     if (l.kind == 0) {
       ISHAP_TRY(dgrad_op(e, u->stem, g, dx, u->in_pad));
     } else if (l.kind == 1) {
-      if (i == 0 && split > 0) ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, split, out2));
-      else if (i == 0 && add2) { ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, 0, nullptr, add2)); *add2_done = true; }
-      else ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx));
+      if (i == 0 && split > 0) ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, split, out2, nullptr, next));
+      else if (i == 0 && add2) { ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, 0, nullptr, add2, next)); *add2_done = true; }
+      else ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, 0, nullptr, nullptr, next));
     } else {
-      ISHAP_TRY(attn_backward(e, u->attn[l.idx], g, dx));
+      ISHAP_TRY(attn_backward(e, u->attn[l.idx], g, dx, next));
     }
     g = dx;
   }
@@ -215,6 +228,7 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
     const int Cs = b.skip_ch, Ch = b.cin - Cs;
     ISHAP_REQUIRE(b.layers[0].kind == 1 && Ch % 8 == 0, "an output block starts with a ResBlock on the concatenation");
     Tensor gh, gs;
+    e.next_block_pf = first_bwd_weights(u, (i > 0 ? u->out_blocks[i - 1] : u->mid).layers.back());
     ISHAP_TRY(block_backward(e, b, g, gh, Ch, &gs));       // the first ResBlock writes d/d[h | skip] as two tensors
     skipgrad[n_in - 1 - i] = gs;     // hs.pop() order (unet.py:663)
     g = gh;
@@ -231,8 +245,10 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
     return 0;
   };
   const half_t* pending = nullptr;
+  e.next_block_pf = n_in > 0 ? first_bwd_weights(u, u->in_blocks[n_in - 1].layers.back()) : PrefetchHint{};
   ISHAP_TRY(run(u->mid, n_in > 0 ? skipgrad[n_in - 1].p : nullptr, pending));
   for (int i = n_in - 1; i >= 0; --i) {
+    e.next_block_pf = i > 0 ? first_bwd_weights(u, u->in_blocks[i - 1].layers.back()) : PrefetchHint{};
     if (pending) {                       // fall-back: a separate add
       Tensor sum = g;
       ISHAP_ALLOC(sum.p, e, g.numel());

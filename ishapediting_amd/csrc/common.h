@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <string>
 
 typedef _Float16 half_t;
@@ -99,6 +100,48 @@ __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, dpp_move<0x140>(v));
   return v;
 }
+
+// Weight prefetch hint -- an OPT-IN experiment (ISHAP_PREFETCH=1), measured and rejected in round 3.  Idea: the kernel that
+// runs before a convolution (a GroupNorm pass: latency-bound, the memory system mostly idle) carries a few extra workgroups
+// that touch one dword of every 128-byte line of the convolution's weights, pulling them into the Infinity Cache while the
+// GroupNorm runs (the UNet streams 1.5 GB of once-read weights per guided step through ~270 dependent launches).
+// Result (bench.py, same box, two rounds each): 0.2045 s/edit without, 0.2175 / 0.2335 / 0.2323 with the first 256 KB / 1 MB /
+// 4 MB of each operand prefetched, 0.231 with whole operands.  The convolutions gain only 1-4 % from warm weights (their
+// rings hide an HBM miss almost as well as an L2 hit), while every carrying kernel now ends one HBM round trip after its
+// last prefetch workgroup was dispatched: +2.4 us on each of ~140 GroupNorm launches per step.  A kernel boundary waits for
+// the prefetch, so it cannot run ahead of the consumer the way a persistent loader ring does.
+struct PrefetchHint {
+  const void* p = nullptr;
+  unsigned lines = 0;            // 128-byte lines starting at p
+  __host__ __device__ bool any() const { return lines != 0; }
+};
+static inline PrefetchHint prefetch_hint(const void* p, size_t bytes) {
+  // a prefetch keeps the carrying kernel alive until its loads are back, so it must stay shorter than that kernel:
+  // only the first ISHAP_PREFETCH_KB of an operand are touched (what the consumer's pipeline fill waits for)
+  static const size_t cap = [] { const char* e = getenv("ISHAP_PREFETCH_KB"); return (size_t)(e ? atoi(e) : 1024) * 1024; }();
+  PrefetchHint h;
+  if (bytes > cap) bytes = cap;
+  if (p && bytes >= 128) { h.p = p; h.lines = (unsigned)(bytes / 128); }
+  return h;
+}
+// workgroups of `threads` threads that cover the hint with ~8 loads per thread, at most `cap`
+static inline int prefetch_blocks(const PrefetchHint& h, int threads, int cap = 64) {
+  if (!h.any()) return 0;
+  const long long per = (long long)threads * 8;
+  const long long n = (h.lines + per - 1) / per;
+  return (int)(n < 1 ? 1 : (n > cap ? cap : n));
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ void prefetch_block(const PrefetchHint& h, int blk, int nblk) {
+  const char* base = reinterpret_cast<const char*>(h.p);
+  const unsigned stride = (unsigned)nblk * blockDim.x;
+  unsigned acc = 0;
+#pragma unroll 8
+  for (unsigned i = (unsigned)blk * blockDim.x + threadIdx.x; i < h.lines; i += stride)
+    acc ^= *reinterpret_cast<const unsigned*>(base + (size_t)i * 128);
+  asm volatile("" ::"v"(acc));          // keeps the loads; the wave ends when they have returned
+}
+#endif
 
 // A convolution result that has not been materialised yet: the split-K slices of an implicit-GEMM launch left as fp32
 // partial sums [nslab][rows][ld].  The next kernel on the tensor (a GroupNorm pass, forward or backward -- it has to read

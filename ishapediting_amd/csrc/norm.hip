@@ -115,6 +115,10 @@ __device__ __forceinline__ float rh(float v) { return (float)(half_t)v; }   // r
 //  SPLIT: fp32-grade output for the fp32 head: writes [hi | lo | hi] fp16 channel blocks (3*C wide)
 template <bool FILM, bool ACT, bool POOL, bool SPLIT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
+  if ((int)blockIdx.x >= a.main_blocks) {          // prefetch workgroups: the next convolution's weights (common.h)
+    prefetch_block(a.pf, blockIdx.x - a.main_blocks, gridDim.x - a.main_blocks);
+    return;
+  }
   const int CV = a.C >> 3;
   const int HWo = POOL ? (a.H >> 1) * (a.W >> 1) : a.H * a.W;
   const long long total = (long long)a.N * HWo * CV;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
   // The launcher makes the thread count a multiple of CV, so a thread keeps ONE 8-channel vector for all its pixels:
   // gamma/beta are loaded once, the per-image values (mean, rstd, FiLM) only when the image changes.
   const long long tg = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long nth = (long long)gridDim.x * blockDim.x;
+  const long long nth = (long long)a.main_blocks * blockDim.x;
   const int cv = (int)(tg % CV), c0 = cv * 8;
   const long long pstep = nth / CV, npix = (long long)a.N * HWo;
   float gam[8], bet[8], mu[8], rs[8], sc[8], sh[8];
@@ -255,12 +259,15 @@ int gn_apply_launch(const GnApplyArgs& a, hipStream_t s) {
   while (r256) { const int t = gcd % r256; gcd = r256; r256 = t; }
   const int unit = CV / gcd;
   blocks = blocks < unit ? unit : blocks / unit * unit;
-  dim3 g(blocks), b(256);
-  if (a.split) hipLaunchKernelGGL((gn_apply_kernel<false, true, false, true>), g, b, 0, s, a);
-  else if (a.pool) hipLaunchKernelGGL((gn_apply_kernel<false, true, true, false>), g, b, 0, s, a);
-  else if (a.film) hipLaunchKernelGGL((gn_apply_kernel<true, true, false, false>), g, b, 0, s, a);
-  else if (a.act) hipLaunchKernelGGL((gn_apply_kernel<false, true, false, false>), g, b, 0, s, a);
-  else hipLaunchKernelGGL((gn_apply_kernel<false, false, false, false>), g, b, 0, s, a);
+  static const int pf_on = [] { const char* e = getenv("ISHAP_PREFETCH"); return e ? atoi(e) : 0; }();
+  GnApplyArgs a2 = a;
+  a2.main_blocks = blocks;
+  dim3 g(blocks + (pf_on ? prefetch_blocks(a.pf, 256) : 0)), b(256);
+  if (a.split) hipLaunchKernelGGL((gn_apply_kernel<false, true, false, true>), g, b, 0, s, a2);
+  else if (a.pool) hipLaunchKernelGGL((gn_apply_kernel<false, true, true, false>), g, b, 0, s, a2);
+  else if (a.film) hipLaunchKernelGGL((gn_apply_kernel<true, true, false, false>), g, b, 0, s, a2);
+  else if (a.act) hipLaunchKernelGGL((gn_apply_kernel<false, true, false, false>), g, b, 0, s, a2);
+  else hipLaunchKernelGGL((gn_apply_kernel<false, false, false, false>), g, b, 0, s, a2);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -88,6 +88,10 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnBwdArgs a, int ro
 
 template <bool FILM, bool ACT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
+  if ((int)blockIdx.x >= a.main_blocks) {          // prefetch workgroups: the next convolution's weights (common.h)
+    prefetch_block(a.pf, blockIdx.x - a.main_blocks, gridDim.x - a.main_blocks);
+    return;
+  }
   const int CV = a.C >> 3, HW = a.H * a.W, cpg = a.C / 32;
   const long long total = (long long)a.N * HW * CV;
   // group means of dyh and dyh*xh from the per-channel sums (8 lanes per (image, group))
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
   }
   // thread count is a multiple of CV (launcher): one 8-channel vector per thread, parameters loaded once per image
   const long long tg = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long nth = (long long)gridDim.x * blockDim.x;
+  const long long nth = (long long)a.main_blocks * blockDim.x;
   const int cv = (int)(tg % CV), c0 = cv * 8;
   const long long pstep = nth / CV, npix = (long long)a.N * HW;
   float gam[8], bet[8], mu[8], rs[8], esc[8], esh[8], m1[8], m2[8];
@@ -167,11 +171,15 @@ int gn_backward_launch(const GnBwdArgs& a, hipStream_t s) {
   while (r256) { const int t = gcd % r256; gcd = r256; r256 = t; }
   const int unit = CV / gcd;
   blocks = blocks < unit ? unit : blocks / unit * unit;
+  static const int pf_on = [] { const char* e = getenv("ISHAP_PREFETCH"); return e ? atoi(e) : 0; }();
+  GnBwdArgs a2 = a;
+  a2.main_blocks = blocks;
+  const int grid_apply = blocks + (pf_on ? prefetch_blocks(a.pf, 256) : 0);
 #define GB_LAUNCH(F, A)                                                                                             \
   do {                                                                                                              \
     if (!a.sums_ready)                                                                                              \
       hipLaunchKernelGGL((gn_bwd_partial_kernel<F, A>), dim3(nblk, a.N), dim3(256), smem, s, a, rpb);               \
-    hipLaunchKernelGGL((gn_bwd_apply_kernel<F, A>), dim3(blocks), dim3(256), 0, s, a);                              \
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<F, A>), dim3(grid_apply), dim3(256), 0, s, a2);                         \
   } while (0)
   if (a.film) GB_LAUNCH(true, true);
   else if (a.act) GB_LAUNCH(false, true);

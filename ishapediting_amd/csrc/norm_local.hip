@@ -172,6 +172,11 @@ __device__ __forceinline__ void group_rendezvous(double& a, double& b, unsigned 
 template <int VEC, bool FILM, bool ACT, bool POOL>
 __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if ((int)blockIdx.x >= 32 * a.parts) {           // prefetch workgroups (last in the grid: the GroupNorm ones are dispatched first)
+    const int npf = gridDim.x - 32 * a.parts;
+    prefetch_block(a.pf, (blockIdx.x - 32 * a.parts) + npf * blockIdx.y, npf * gridDim.y);
+    return;
+  }
   double* scratch = reinterpret_cast<double*>(smem_raw);                 // 32 doubles (block_sum2: 2 x 16; rendezvous: 4 x parts)
   half_t* st = reinterpret_cast<half_t*>(smem_raw + 256);                // [HW][cpg]
   const int g = blockIdx.x / a.parts, part = blockIdx.x - g * a.parts, n = blockIdx.y;
@@ -327,6 +332,11 @@ __device__ __forceinline__ void addend(const half_t* g, int gmode, int n, int p,
 template <int VEC, bool FILM, bool ACT, bool STAGE32>
 __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(GnBwdLocalArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if ((int)blockIdx.x >= 32 * a.parts) {
+    const int npf = gridDim.x - 32 * a.parts;
+    prefetch_block(a.pf, (blockIdx.x - 32 * a.parts) + npf * blockIdx.y, npf * gridDim.y);
+    return;
+  }
   double* scratch = reinterpret_cast<double*>(smem_raw);
   half_t* st16 = reinterpret_cast<half_t*>(smem_raw + 256);
   float* st32 = reinterpret_cast<float*>(smem_raw + 256);
@@ -432,6 +442,13 @@ int pick_parts(int N, int HW, int cpg, int unit, bool have_rec) {
   return p;
 }
 constexpr size_t LOCAL_LDS_CAP = 160 * 1024 - 256;
+// prefetch workgroups per image row of the grid (they inherit the launch's LDS request: none when that would cost a CU each)
+int pf_blocks_for(const PrefetchHint& h, int threads, int N, size_t smem) {
+  static const int on = [] { const char* e = getenv("ISHAP_PREFETCH"); return e ? atoi(e) : 0; }();
+  if (!on || !h.any() || smem > 16 * 1024) return 0;
+  const int total = prefetch_blocks(h, threads);
+  return (total + N - 1) / N;
+}
 // polls before a rendezvous gives up; ISHAP_GN_SPIN_LIMIT exists so that a test can force the give-up path (1 poll)
 int spin_limit() {
   static const int v = [] { const char* e = getenv("ISHAP_GN_SPIN_LIMIT"); const int n = e ? atoi(e) : 0; return n > 0 ? n : GN_SPIN_LIMIT; }();
@@ -470,7 +487,7 @@ int gn_local_launch(const GnLocalArgs& a, hipStream_t s) {
   const int VEC = pick_vec(cpg, PP, a.slab.pending());
   const int T = pick_threads(PP * (cpg / VEC));
   const size_t smem = 256 + (size_t)PP * cpg * sizeof(half_t);
-  dim3 grid(32 * b.parts, a.N), blk(T);
+  dim3 grid(32 * b.parts + pf_blocks_for(a.pf, T, a.N, smem), a.N), blk(T);
 #define GL_LAUNCH(V, F, A, P)                                                            \
   do {                                                                                   \
     auto kern = gn_local_kernel<V, F, A, P>;                                             \
@@ -515,7 +532,7 @@ int gn_bwd_local_launch(const GnBwdLocalArgs& a, hipStream_t s) {
   ISHAP_REQUIRE(smem <= LOCAL_LDS_CAP + 256, "group does not fit in LDS");
   const int VEC = pick_vec(cpg, PP, a.slab.pending());
   const int T = pick_threads(PP * (cpg / VEC));
-  dim3 grid(32 * b.parts, a.N), blk(T);
+  dim3 grid(32 * b.parts + pf_blocks_for(a.pf, T, a.N, smem), a.N), blk(T);
 #define GB_LAUNCH(V, F, A, S32)                                                          \
   do {                                                                                   \
     auto kern = gn_bwd_local_kernel<V, F, A, S32>;                                       \

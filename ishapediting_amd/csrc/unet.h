@@ -168,10 +168,22 @@ struct ishap_unet {
   size_t attn_D_floats = 0;
 };
 
+// weights a convolution is about to stream, as a prefetch hint for the kernel that runs before it (common.h)
+static inline PrefetchHint pf_fwd(const ConvW& c) {          // forward operand; the [c2 | skip] concatenation when there is one
+  const size_t rows = ((size_t)c.cout + 127) / 128 * 128;
+  if (c.cat && c.cat_off == 0) return prefetch_hint(c.cat, rows * c.cat_ld * sizeof(half_t));
+  return prefetch_hint(c.w, rows * c.taps * c.kpad * sizeof(half_t));
+}
+static inline PrefetchHint pf_bwd(const ConvW& c) {          // input-gradient operand
+  const size_t rows = ((size_t)((c.cin + 31) / 32 * 32) + 127) / 128 * 128;
+  return prefetch_hint(c.wT, rows * c.taps * c.cout_pad * sizeof(half_t));
+}
+
 struct Exec {
   ishap_unet* u;
   hipStream_t s;
   bool dry;
+  PrefetchHint next_block_pf;   // backward: first weights of the block processed after the current one
   bool keep = false;   // the forward keeps what a following backward re-reads
   float* ws = nullptr;          // split-K / GroupNorm-statistics scratch of this launch sequence (null: the context's)
   float* gn_partial = nullptr;

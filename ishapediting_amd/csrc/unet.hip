@@ -337,8 +337,9 @@ int gn_stats_op(Exec& e, const Tensor& x, float* stats) {
 // GroupNorm (+FiLM) (+SiLU) (+2x2 pool) of `x` into `out` on a small map: one group-local launch that also adds up `x`
 // when it is still pending (and its first half when x is a lazy skip concatenation), see norm_local.hip
 static int gn_local_op(Exec& e, Tensor& x, const NormW& nw, half_t* out, half_t* xpool, float* stats_out, const float* emb,
-                       int emb_ld, int film, int act, int pool) {
+                       int emb_ld, int film, int act, int pool, PrefetchHint pf = PrefetchHint{}) {
   GnLocalArgs g;
+  g.pf = pf;
   if (x.cat_a) {
     g.xa = x.cat_a; g.slab = x.cat_pend; g.ya = x.cat_pend.pending() ? const_cast<half_t*>(x.cat_a) : nullptr;
     g.Ca = x.cat_ca; g.xb = x.cat_b; g.xcopy = x.p;
@@ -375,7 +376,7 @@ static int res_forward(Exec& e, ResL& L, Tensor x, Tensor& y) {
   xs.pend = SlabSrc{}; xs.cat_pend = SlabSrc{};
   if (L.down) { xs = a; ISHAP_ALLOC(xs.p, e, a.numel()); }
   if (loc_in) {
-    ISHAP_TRY(gn_local_op(e, x, L.n1, a.p, L.down ? xs.p : nullptr, st1, nullptr, 0, 0, 1, L.down));
+    ISHAP_TRY(gn_local_op(e, x, L.n1, a.p, L.down ? xs.p : nullptr, st1, nullptr, 0, 0, 1, L.down, pf_fwd(L.c1)));
   } else {
     ISHAP_REQUIRE(!lazy_cat || (x.cat_sa && x.cat_sb), "a lazy concatenation on a large map carries the producers' sums");
     ISHAP_TRY(slab_materialize(e, x));
@@ -385,6 +386,7 @@ static int res_forward(Exec& e, ResL& L, Tensor x, Tensor& y) {
       g.x = x.p; g.out = a.p; g.xpool = L.down ? xs.p : nullptr;
       g.stats = st1; g.sums = x.sums; g.stats_out = x.sums ? st1 : nullptr; g.gamma = L.n1.gamma; g.beta = L.n1.beta;
       g.N = N; g.H = H; g.W = W; g.C = L.cin; g.act = 1; g.pool = L.down;
+      g.pf = pf_fwd(L.c1);
       if (lazy_cat) {
         g.x = x.cat_a; g.x2 = x.cat_b; g.sums = x.cat_sa; g.sums2 = x.cat_sb; g.csplit = x.cat_ca; g.xcopy = x.p;
         g.stats_out = st1;
@@ -401,7 +403,7 @@ static int res_forward(Exec& e, ResL& L, Tensor x, Tensor& y) {
   c.pend = SlabSrc{};
   ISHAP_ALLOC(c.p, e, h1.numel());
   if (loc_out) {
-    ISHAP_TRY(gn_local_op(e, h1, L.n2, c.p, nullptr, st2, u->film_cur + L.emb_off, u->film_cur_ld, 1, 1, 0));
+    ISHAP_TRY(gn_local_op(e, h1, L.n2, c.p, nullptr, st2, u->film_cur + L.emb_off, u->film_cur_ld, 1, 1, 0, pf_fwd(L.c2)));
   } else {
     if (!h1.sums) ISHAP_TRY(gn_stats_op(e, h1, st2));
     if (!e.dry) {
@@ -409,6 +411,7 @@ static int res_forward(Exec& e, ResL& L, Tensor x, Tensor& y) {
       g.x = h1.p; g.out = c.p; g.stats = st2; g.sums = h1.sums; g.stats_out = h1.sums ? st2 : nullptr; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
       g.emb = u->film_cur + L.emb_off; g.emb_ld = u->film_cur_ld;
       g.N = N; g.H = Ho; g.W = Wo; g.C = L.cout; g.film = 1; g.act = 1;
+      g.pf = pf_fwd(L.c2);
       ISHAP_TRY(gn_apply_launch(g, e.s));
     }
   }
@@ -451,7 +454,7 @@ static int attn_forward(Exec& e, AttnL& L, Tensor x, Tensor& y) {
   nrm.pend = SlabSrc{};
   ISHAP_ALLOC(nrm.p, e, x.numel());
   if (local_gn(T, C)) {
-    ISHAP_TRY(gn_local_op(e, x, L.n, nrm.p, nullptr, st, nullptr, 0, 0, 0, 0));
+    ISHAP_TRY(gn_local_op(e, x, L.n, nrm.p, nullptr, st, nullptr, 0, 0, 0, 0, pf_fwd(L.qkv)));
   } else {
     ISHAP_TRY(slab_materialize(e, x));
     if (!x.sums) ISHAP_TRY(gn_stats_op(e, x, st));
@@ -459,6 +462,7 @@ static int attn_forward(Exec& e, AttnL& L, Tensor x, Tensor& y) {
       GnApplyArgs g;
       g.x = x.p; g.out = nrm.p; g.stats = st; g.sums = x.sums; g.stats_out = x.sums ? st : nullptr; g.gamma = L.n.gamma; g.beta = L.n.beta;
       g.N = N; g.H = x.H; g.W = x.W; g.C = C; g.act = 0;
+      g.pf = pf_fwd(L.qkv);
       ISHAP_TRY(gn_apply_launch(g, e.s));
     }
   }
@@ -645,6 +649,7 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     g.x = h.p; g.out = hsplit; g.stats = u->head_stats; g.sums = h.sums; g.stats_out = h.sums ? u->head_stats : nullptr;
     g.gamma = u->head_norm.gamma; g.beta = u->head_norm.beta;
     g.N = N; g.H = S; g.W = S; g.C = h.C; g.act = 1; g.split = 1;
+    g.pf = pf_fwd(u->head);
     ISHAP_TRY(gn_apply_launch(g, e.s));
   }
   ISHAP_TRY(conv_op(e, hsplit, N, S, S, 3 * h.C, u->head.w, u->head.kpad, 9, cfg.out_channels, u->head.bias, nullptr, 0, out,
