@@ -38,6 +38,7 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  IG_STAMP(0, wave_all == 0);
   const int team = HALVES == 2 ? wave_all / (4 + IG2_LOADERS) : 0;
   const int wave8 = wave_all - team * (4 + IG2_LOADERS);
   half_t* lds = reinterpret_cast<half_t*>(smem_raw) + team * (NST * STAGE);
@@ -180,6 +181,7 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  IG_STAMP(1, wave_all == 0);
   // ---- prologue: NST-1 stages in flight ----
   if (loader) {
 #pragma unroll
@@ -270,6 +272,7 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
     using std::integral_constant;
     __builtin_amdgcn_s_barrier();                // step 0 has landed
     asm volatile("" ::: "memory");
+    IG_STAMP(2, wave_all == 0);
     if (nk > 0) read_half(0, 0, xa, wa);
     for (int k = 0; k < nk_loop; ++k) {
       const bool act = k < nk;                   // the shorter half (odd step count) idles through the last barrier
@@ -291,6 +294,7 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
     }
   }
 
+  IG_STAMP(3, wave_all == 0);
   if (HALVES == 2) {
     // team 1 hands its accumulators to team 0 through (its own, now idle) ring memory
     f32x4* red = reinterpret_cast<f32x4*>(reinterpret_cast<half_t*>(smem_raw) + NST * STAGE);
@@ -309,6 +313,7 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
         for (int j = 0; j < MT; ++j) acc[i][j] += red[((i * MT + j) * 4 + wave) * 64 + lane];
     }
   }
+  IG_STAMP(4, wave_all == 0);
 #ifdef ABL_NOEPI
   if (a.alpha == 12345.f)                        // harness probe: the launch without its epilogue (never true)
 #endif

@@ -8,6 +8,225 @@
 #include "gn_bwd_terms.h"
 #include <type_traits>
 
+// Diagnostic build only (tools/bench_igemm.hip -DIG_STAMPS): s_memtime stamps of one wave per workgroup into a buffer of
+// their own (cdna_hip_programming.md 7, In-kernel stamps).  In the library the macro expands to nothing.
+#ifdef IG_STAMPS
+extern __device__ unsigned long long* g_ig_stamps;      // [workgroup][16]
+#define IG_STAMP(slot, cond)                                                                                   \
+  do {                                                                                                         \
+    if (cond) {                                                                                                \
+      unsigned long long t_;                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      if ((threadIdx.x & 63) == 0)                                                                             \
+        g_ig_stamps[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16 + (slot)] = t_; \
+    }                                                                                                          \
+  } while (0)
+#else
+#define IG_STAMP(slot, cond) do {} while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// Staged epilogue of the LDS-DMA kernels (round 3).  The round-2 form did everything on the four MFMA waves in the
+// fragment layout: scale / bias / residual / convert / statistics for MT x NT tiles of 4 values each, ~60 instructions
+// per tile behind run-time selects, then row sums by DPP chains -- 10 300 cycles of a 128x128-tile launch and 4 400 of a
+// 64x64 one (s_memtime stamps, tools/bench_igemm.hip -DIG_STAMPS), on one wave per SIMD while the loader waves idled.
+// Now the MFMA waves only park their raw fp32 accumulators in LDS (the ring is dead by then), and EVERY wave of the
+// workgroup -- loaders and the second team included -- finishes the tile row-wise: a thread owns one 8-channel chunk of a
+// few rows, so bias / FiLM-free epilogue operands are loaded once per thread, the residual and the output are whole
+// 16-byte row segments (coalesced both ways).  Values are formed in the same order as before (alpha * acc, + bias,
+// + bias2, + residual, one rounding to fp16), so outputs are bit-identical to the fragment-layout path.
+// Statistics: forward launches (sum x, sum x^2 of the stored fp16 values = GroupNorm statistics of the next layer,
+// gd/nn.py:16-18) re-read the rounded tile from LDS by column, a thread per channel pair; input-gradient launches
+// (sum dyh, sum dyh*xhat, gn_bwd_terms.h) add their rows' terms in registers and meet by butterfly.  Either way the
+// workgroup's totals go out as 64-bit fixed point (integer atomics commute: bitwise reproducible).
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT, int NT, int TMW, int TNW, int BN, int T>
+__device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 (&acc)[NT][MT], int m0, int n0, int wm, int wn,
+                                                      int lane, int batch, float* lds_f, bool active) {
+  constexpr int BM_T = 2 * TMW;
+  constexpr int LDF = BN + 4;                      // fp32 tile pitch: conflict-free ds_write_b128 of the fragments and row reads
+  constexpr int LDH = BN + 8;                      // fp16 tile pitch (halfs)
+  constexpr int CPRW = BN / 8;                     // 8-channel chunks per tile row
+  constexpr int ITEMS = BM_T * CPRW;               // (row, chunk) items of the tile
+  constexpr int RPT = (ITEMS + T - 1) / T;         // items per thread (rows RSTEP apart, same chunk)
+  constexpr int RSTEP = T / CPRW;
+  constexpr int NW = T / 64;
+  constexpr int PAIRS = BN / 2;                    // statistics pass: a thread owns a channel pair over RPP rows
+  constexpr int PARTS = (T / PAIRS) < (BM_T / 8) ? (T / PAIRS) : (BM_T / 8);
+  constexpr int RPP = BM_T / PARTS;
+  static_assert(T % CPRW == 0 && (ITEMS % T == 0 || ITEMS < T) && BM_T % PARTS == 0, "thread <-> tile mappings");
+  float* const tileF = lds_f;                                               // [BM_T][LDF] raw accumulators
+  half_t* const tileH = reinterpret_cast<half_t*>(lds_f + BM_T * LDF);      // [BM_T][LDH] the stored (rounded) values
+  float* const slots = reinterpret_cast<float*>(tileH + BM_T * LDH);        // partial sums: [PARTS][PAIRS][4] or [NW][BN][2]
+  const int t = threadIdx.x;
+  const bool stamp_wave = active && wm == 0 && wn == 0;
+  (void)stamp_wave;
+  IG_STAMP(5, stamp_wave);
+  __syncthreads();                                 // the K loop's LDS tiles are dead from here on
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        *reinterpret_cast<f32x4*>(tileF + (wm * TMW + j * 16 + (lane & 15)) * LDF + wn * TNW + i * 16 + (lane >> 4) * 4) = acc[i][j];
+  }
+  // this thread's chunk: epilogue operands once per thread, issued before the barrier so that their latency overlaps it
+  const int chunk = t % CPRW, row_first = t / CPRW;
+  const int n = n0 + chunk * 8;
+  const bool has = row_first < BM_T && n < a.N;    // N % 8 == 0: a chunk is inside or outside as a whole
+  const float alpha = a.alpha;
+  const int HW = a.H * a.W;
+  half_t* const out16 = (half_t*)a.out + (long long)batch * a.bso;
+  f32x4 b1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, b2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  half8 rr[RPT];
+  const bool want_fwd = a.stat_out != nullptr, want_gb = a.gb_x != nullptr;
+  if (has) {
+    if (a.bias) { b1[0] = *reinterpret_cast<const f32x4*>(a.bias + n); b1[1] = *reinterpret_cast<const f32x4*>(a.bias + n + 4); }
+    if (a.bias2) { b2[0] = *reinterpret_cast<const f32x4*>(a.bias2 + n); b2[1] = *reinterpret_cast<const f32x4*>(a.bias2 + n + 4); }
+    if (a.res) {
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int m = m0 + row_first + k * RSTEP;
+        long long rrow = m;
+        if (a.res_ups) {
+          const int img = m / HW, p = m - img * HW, py = p / a.W, px = p - py * a.W;
+          rrow = (long long)img * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1);
+        }
+        rr[k] = *reinterpret_cast<const half8*>(a.res + rrow * a.ldr + n);
+      }
+    }
+  }
+  // GroupNorm-backward operands of this chunk (input-gradient launches only)
+  float g_mu[8], g_rs[8], g_gam[8], g_bet[8], g_esc[8], g_esh[8];
+  half8 gx[RPT];
+  if (want_gb && has) {
+    const int n_img = m0 / HW, cpg = a.N / 32;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int g = (n + c) / cpg;
+      g_mu[c] = a.gb_stats[(n_img * 32 + g) * 2];
+      g_rs[c] = a.gb_stats[(n_img * 32 + g) * 2 + 1];
+      g_gam[c] = a.gb_gamma[n + c];
+      g_bet[c] = a.gb_beta[n + c];
+      g_esc[c] = a.gb_film ? a.gb_emb[(long long)n_img * a.gb_emb_ld + n + c] : 0.f;
+      g_esh[c] = a.gb_film ? a.gb_emb[(long long)n_img * a.gb_emb_ld + a.N + n + c] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+      gx[k] = *reinterpret_cast<const half8*>(a.gb_x + (long long)(m0 + row_first + k * RSTEP) * a.N + n);
+  }
+  IG_STAMP(6, stamp_wave);
+  __syncthreads();
+  float gs1[8], gs2[8];                            // input-gradient launches: sum dyh, sum dyh*xhat of this thread's rows (O(1) terms)
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { gs1[c] = 0.f; gs2[c] = 0.f; }
+  if (has) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int row = row_first + k * RSTEP;
+      const float* src = tileF + row * LDF + chunk * 8;
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+      v0 *= alpha; v1 *= alpha;                    // alpha * acc (+ bias) (+ bias2) (+ residual), in this order
+      if (a.bias) { v0 += b1[0]; v1 += b1[1]; }
+      if (a.bias2) { v0 += b2[0]; v1 += b2[1]; }
+      if (a.res) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { v0[c] += (float)rr[k][c]; v1[c] += (float)rr[k][4 + c]; }
+      }
+      half8 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { o[c] = (half_t)v0[c]; o[4 + c] = (half_t)v1[c]; }
+#ifdef ABL_EPI_NOSTORE
+      if (alpha == 12345.f)
+#endif
+      *reinterpret_cast<half8*>(out16 + (long long)(m0 + row) * a.ldo + n) = o;
+      if (want_fwd) {
+        *reinterpret_cast<half8*>(tileH + row * LDH + chunk * 8) = o;    // the statistics pass reads the stored values by column
+      } else if (want_gb) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float dyh, xhat;
+          gn_bwd_term((float)o[c], (float)gx[k][c], g_mu[c], g_rs[c], g_gam[c], g_bet[c], g_esc[c], g_esh[c], a.gb_film != 0,
+                      a.gb_act != 0, dyh, xhat);
+          gs1[c] += dyh;
+          gs2[c] = fmaf(dyh, xhat, gs2[c]);
+        }
+      }
+    }
+  }
+  IG_STAMP(7, stamp_wave);
+  if (!(want_fwd || want_gb)) { IG_STAMP(10, stamp_wave); return; }      // block-uniform (kernel arguments)
+  const int n_img = m0 / HW;                                              // a tile never straddles images (HW % BM == 0)
+  if (want_fwd) {
+    // Per-channel sum and sum of squares of the stored values about a PIVOT P = the channel's value in the tile's first row
+    // (the same for every thread, so partial sums simply add): sum(x - P), sum((x - P)^2) stay small when the channel sits
+    // at |mean| >> std, where fp32 sums of x^2 cancel (128 squares of 100.1 +- 0.1: error ~0.1 against a variance
+    // contribution of 1.3 -- GroupNorm32, gd/nn.py:16-18, would come out several per cent off).
+    __syncthreads();
+    if (t < PARTS * PAIRS) {
+      const int pair = t % PAIRS, part = t / PAIRS;
+      const half2v pv = *reinterpret_cast<const half2v*>(tileH + pair * 2);
+      const float P0 = (float)pv[0], P1 = (float)pv[1];
+      float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < RPP; ++r) {
+        const half2v x = *reinterpret_cast<const half2v*>(tileH + (part * RPP + r) * LDH + pair * 2);
+        const float d0 = (float)x[0] - P0, d1 = (float)x[1] - P1;
+        s0 += d0; q0 = fmaf(d0, d0, q0);
+        s1 += d1; q1 = fmaf(d1, d1, q1);
+      }
+      *reinterpret_cast<f32x4*>(slots + (part * PAIRS + pair) * 4) = (f32x4){s0, q0, s1, q1};
+    }
+    IG_STAMP(8, stamp_wave);
+    __syncthreads();
+    IG_STAMP(9, stamp_wave);
+    if (t < BN * 2) {
+      const int nl = t >> 1, k = t & 1;
+      if (n0 + nl < a.N) {
+        // parts add in double (fixed order); then to pivot 0:  sum x = S + n P,  sum x^2 = Q + P (2 S + n P)
+        double S = 0.0, Q = 0.0;
+#pragma unroll
+        for (int part = 0; part < PARTS; ++part) {
+          const f32x4 r = *reinterpret_cast<const f32x4*>(slots + (part * PAIRS + (nl >> 1)) * 4);
+          S += (double)r[(nl & 1) * 2];
+          Q += (double)r[(nl & 1) * 2 + 1];
+        }
+        const double P = (double)(float)tileH[nl], nn = (double)BM_T;
+        const double v = k ? Q + P * (2.0 * S + nn * P) : S + nn * P;
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stat_out + ((long long)n_img * a.N + n0 + nl) * 2 + k),
+                  (unsigned long long)__double2ll_rn(v * (double)(k ? STAT_SCALE_SQ : STAT_SCALE_SUM)));
+      }
+    }
+  } else {
+    // the lanes of a wave that share a chunk (lane, lane + CPRW, ...) add by butterfly, one slot per (wave, channel, term)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+      for (int o = CPRW; o < 64; o <<= 1) { gs1[c] += __shfl_xor(gs1[c], o); gs2[c] += __shfl_xor(gs2[c], o); }
+    }
+    IG_STAMP(8, stamp_wave);
+    if (lane < CPRW) {
+      float* dst = slots + ((t >> 6) * BN + lane * 8) * 2;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { dst[c * 2] = gs1[c]; dst[c * 2 + 1] = gs2[c]; }
+    }
+    __syncthreads();
+    if (t < BN * 2) {
+      const int nl = t >> 1, k = t & 1;
+      if (n0 + nl < a.N) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += (double)slots[(w * BN + nl) * 2 + k];
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.gb_csums + ((long long)n_img * a.N + n0 + nl) * 2 + k),
+                  (unsigned long long)__double2ll_rn(v * (double)STAT_SCALE_SUM));
+      }
+    }
+  }
+  IG_STAMP(10, stamp_wave);
+}
+
 // STAGE_THREADS > 0 (the LDS-DMA kernels; = threads of the workgroup, all of which call this function): fp16 outputs
 // of an unsplit launch are collected in LDS and leave as full 16-byte-per-lane row segments written by every wave,
 // loader waves included.  The fragment layout's own stores are 8 bytes per lane over 16 rows: issue-bound, ~9 us of
@@ -30,10 +249,22 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
   constexpr int BM_T = 2 * TMW;                  // rows of the workgroup tile
   constexpr int LDT = BN + 8;                    // staged-tile row pitch in halfs (conflict-free 8-byte fragment writes)
   half_t* const out16 = (half_t*)a.out + (long long)batch * a.bso;
-  const bool staged = STAGE_THREADS > 0 && out_mode == IG_OUT_F16 && a.ksplit == 1 && (a.N & 7) == 0 && (a.ldo & 7) == 0 &&
-                      (reinterpret_cast<unsigned long long>(out16) & 15) == 0;
+  if constexpr (STAGE_THREADS > 0) {
+    // wave-uniform (kernel arguments only): dense fp16 outputs of an unsplit launch take the staged, all-waves form above
+    const bool aligned16 = ((reinterpret_cast<unsigned long long>(out16) | reinterpret_cast<unsigned long long>(resp)) & 15) == 0;
+    if (out_mode == IG_OUT_F16 && a.ksplit == 1 && (a.N & 7) == 0 && (a.ldo & 7) == 0 && (!resp || (a.ldr & 7) == 0) && aligned16 &&
+        (!a.gb_x || (a.N & 31) == 0)) {
+      igemm_epilogue_staged<MT, NT, TMW, TNW, BN, STAGE_THREADS>(a, acc, m0, n0, wm, wn, lane, batch, lds_f, active);
+      return;
+    }
+  }
+  constexpr bool staged = false;                 // the fragment-layout path below: split-K slices, fp32 / NCHW outputs, odd shapes
   half_t* const tile = reinterpret_cast<half_t*>(lds_f);
+  const bool stamp_wave = active && wm == 0 && wn == 0;
+  (void)stamp_wave;
+  IG_STAMP(5, stamp_wave);
   if (staged) __syncthreads();                   // the K loop's LDS tiles are dead from here on
+  IG_STAMP(6, stamp_wave);
   // Forward statistics are gathered about a PIVOT: every lane takes the first value it stores in a channel as that channel's
   // pivot p and accumulates sum(x - p), sum((x - p)^2) -- small numbers even when the channel sits at |mean| >> std, where
   // the plain fp32 sums of x and x^2 cancel (128 squares of 100.1 +- 0.1 carry an fp32 error of ~0.1 against a variance
@@ -158,6 +389,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
       }
     }
   }
+  IG_STAMP(7, stamp_wave);
   if (staged) {
     __syncthreads();
     constexpr int CPRW = BN / 8;                 // 16-byte chunks per tile row
@@ -172,6 +404,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         *reinterpret_cast<half8*>(out16 + (long long)(m0 + row) * a.ldo + n) = *reinterpret_cast<const half8*>(tile + row * LDT + ch * 8);
     }
   }
+  IG_STAMP(8, stamp_wave);
   if (a.gb_x && a.ksplit == 1 && active) {
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -230,6 +463,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         ssum[i][c] = row16_sum(ssum[i][c]);
         ssq[i][c] = row16_sum(ssq[i][c]);
       }
+    IG_STAMP(9, stamp_wave);
     __syncthreads();                       // the K-loop's LDS tiles are dead from here on
     if (active && (lane & 15) == 0) {
 #pragma unroll
@@ -269,4 +503,5 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
       }
     }
   }
+  IG_STAMP(10, stamp_wave);
 }

@@ -9,6 +9,10 @@
 #include "../ishapediting_amd/csrc/igemm_skinny.hip"
 #include "../ishapediting_amd/csrc/igemm_small3.hip"
 hipEvent_t g_igemm_prof_start = nullptr, g_igemm_prof_stop = nullptr;
+#ifdef IG_STAMPS
+__device__ unsigned long long* g_ig_stamps;
+#include <algorithm>
+#endif
 void ishap_set_error(const std::string& m) { fprintf(stderr, "ERR %s\n", m.c_str()); }
 
 __global__ void empty_kernel(int* p) { if (p) *p = 0; }
@@ -26,6 +30,12 @@ int main(int argc, char** argv) {
   int stats = argc > 8 ? atoi(argv[8]) : 0;      // 1: accumulate the per-channel GroupNorm statistics in the epilogue
   int nbuf = argc > 9 ? atoi(argv[9]) : 1;       // weight copies cycled through (> 256 MB in total = HBM-cold weights, as in the network)
   int M = H * H, K = ksize * ksize * Cin;
+#ifdef IG_STAMPS
+  const int nwg_st = 8192;                         // before ANY launch: the stamped kernels write through this pointer
+  unsigned long long* sb; hipMalloc(&sb, (size_t)nwg_st * 16 * 8); hipMemset(sb, 0, (size_t)nwg_st * 16 * 8);
+  hipMemcpyToSymbol(HIP_SYMBOL(g_ig_stamps), &sb, sizeof(sb));
+  if (M / 64 * ((Cout + 63) / 64) * ksplit > nwg_st) { printf("too many workgroups for the stamp buffer\n"); return 1; }
+#endif
   half_t *X, *W, *O; float* ws;
   const size_t wel = (size_t)((Cout + 127) / 128 * 128) * K;
   hipMalloc(&X, (size_t)M * Cin * 2); hipMalloc(&W, wel * 2 * nbuf); hipMalloc(&O, (size_t)M * Cout * 2);
@@ -113,6 +123,39 @@ int main(int argc, char** argv) {
       hipFree(buf);
     }
   }
+#ifdef IG_STAMPS
+  {
+    // in-kernel timeline: per workgroup, s_memtime at fixed points of one wave; median over workgroups of the differences
+    const int nwg = nwg_st;
+    hipDeviceSynchronize();
+    hipMemset(sb, 0, (size_t)nwg * 16 * 8);
+    for (int i = 0; i < 3; ++i) run();
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)nwg * 16);
+    hipMemcpy(h.data(), sb, h.size() * 8, hipMemcpyDeviceToHost);
+    const char* names[11] = {"entry", "setup done", "step 0 landed (fill)", "K loop done", "team merge done", "epilogue entry",
+                             "acc parked in LDS, operands issued", "rows finished + stored", "statistics pass / butterfly", "barrier", "final sums + atomics issued"};
+    std::vector<double> d[11];
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (int w = 0; w < nwg; ++w) {
+      const unsigned long long* r = &h[(size_t)w * 16];
+      if (!r[0]) continue;
+      tmin = std::min(tmin, r[0]);
+      for (int k = 1; k < 11; ++k) if (r[k] && r[k] >= r[k - 1]) d[k].push_back((double)(r[k] - r[k - 1]));
+      for (int k = 0; k < 11; ++k) tmax = std::max(tmax, r[k]);
+    }
+    printf("in-kernel timeline (shader cycles, median over workgroups; 100 cycles ~ 0.042-0.05 us):\n");
+    double tot = 0;
+    for (int k = 1; k < 11; ++k) {
+      if (d[k].empty()) continue;
+      std::sort(d[k].begin(), d[k].end());
+      const double m = d[k][d[k].size() / 2];
+      tot += m;
+      printf("  %-28s +%7.0f   (p10 %7.0f  p90 %7.0f)\n", names[k], m, d[k][d[k].size() / 10], d[k][d[k].size() * 9 / 10]);
+    }
+    printf("  sum of medians %.0f cycles; first entry -> last stamp of any workgroup %llu cycles\n", tot, tmax - tmin);
+  }
+#endif
   hipEventRecord(e0, 0);
   for (int i = 0; i < it; ++i) run();
   hipEventRecord(e1, 0);
