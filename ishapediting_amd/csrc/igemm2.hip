@@ -101,10 +101,17 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
     xsc[i] = (pch ^ ((row >> 1) & 7)) * 8;     // source chunk (halfs) for this physical slot
     const int m = m0 + row;
     if (CONV3) {
-      xn[i] = m / HW;
-      const int p = m - xn[i] * HW;
-      xy[i] = p / a.W;
-      xx[i] = p - xy[i] * a.W;
+      if (a.hw_shift >= 0) {                     // power-of-two maps (every map of the UNet): shifts, block-uniform branch
+        xn[i] = m >> a.hw_shift;
+        const int p = m & (HW - 1);
+        xy[i] = p >> a.w_shift;
+        xx[i] = p & (a.W - 1);
+      } else {
+        xn[i] = m / HW;
+        const int p = m - xn[i] * HW;
+        xy[i] = p / a.W;
+        xx[i] = p - xy[i] * a.W;
+      }
       xp[i] = g_zero_line;
       xstep[i] = 0;
     } else {
@@ -329,8 +336,13 @@ static int launch2(const IgemmArgs& a, hipStream_t s) {
   auto kern = igemm2_kernel<BM, BN, NST, CONV3, HALVES>;
   ISHAP_TRY(ishap_set_max_lds((const void*)kern, (int)smem));
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
-  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3((256 + 64 * IG2_LOADERS) * HALVES), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a);
-  else hipLaunchKernelGGL(kern, grid, dim3((256 + 64 * IG2_LOADERS) * HALVES), smem, s, a);
+  IgemmArgs b = a;
+  auto lg2 = [](int v) { int k = 0; while ((1 << k) < v) ++k; return (1 << k) == v ? k : -1; };
+  b.w_shift = a.W > 0 ? lg2(a.W) : -1;
+  b.hw_shift = (a.W > 0 && a.H > 0) ? lg2(a.H * a.W) : -1;
+  if (b.w_shift < 0 || b.hw_shift < 0) b.w_shift = b.hw_shift = -1;
+  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3((256 + 64 * IG2_LOADERS) * HALVES), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, b);
+  else hipLaunchKernelGGL(kern, grid, dim3((256 + 64 * IG2_LOADERS) * HALVES), smem, s, b);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -91,7 +91,9 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
         const int m = m0 + row_first + k * RSTEP;
         long long rrow = m;
         if (a.res_ups) {
-          const int img = m / HW, p = m - img * HW, py = p / a.W, px = p - py * a.W;
+          int img, py, px;
+          if (a.hw_shift >= 0) { img = m >> a.hw_shift; const int p = m & (HW - 1); py = p >> a.w_shift; px = p & (a.W - 1); }
+          else { img = m / HW; const int p = m - img * HW; py = p / a.W; px = p - py * a.W; }
           rrow = (long long)img * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1);
         }
         rr[k] = *reinterpret_cast<const half8*>(a.res + rrow * a.ldr + n);
@@ -158,7 +160,7 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
   }
   IG_STAMP(7, stamp_wave);
   if (!(want_fwd || want_gb)) { IG_STAMP(10, stamp_wave); return; }      // block-uniform (kernel arguments)
-  const int n_img = m0 / HW;                                              // a tile never straddles images (HW % BM == 0)
+  const int n_img = a.hw_shift >= 0 ? (m0 >> a.hw_shift) : m0 / HW;     // a tile never straddles images (HW % BM == 0)
   if (want_fwd) {
     // Per-channel sum and sum of squares of the stored values about a PIVOT P = the channel's value in the tile's first row
     // (the same for every thread, so partial sums simply add): sum(x - P), sum((x - P)^2) stay small when the channel sits

@@ -185,6 +185,17 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
   const int nunits = PP * VPP, c0g = g * cpg;
   const int Cb = C - a.Ca;
   const bool pend = a.slab.pending();
+  // affine / FiLM operands of this thread's FIRST unit, fetched now: their round trip then overlaps the statistics pass and
+  // the rendezvous instead of standing between them and the output (a thread rarely has a second unit on these maps)
+  const int c_first = c0g + ((int)threadIdx.x % VPP) * VEC;
+  float pg[VEC], pb[VEC], psc[VEC], psh[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    pg[i] = a.gamma[c_first + i];
+    pb[i] = a.beta[c_first + i];
+    psc[i] = FILM ? a.emb[(long long)n * a.emb_ld + c_first + i] : 0.f;
+    psh[i] = FILM ? a.emb[(long long)n * a.emb_ld + C + c_first + i] : 0.f;
+  }
   double s = 0.0, q = 0.0;
   for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
     const int pl = u / VPP, cv = u - pl * VPP, c = c0g + cv * VEC;
@@ -241,12 +252,14 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
   __syncthreads();                                                     // staging complete (block_sum2 synchronised after the loop as well)
 
   auto activate = [&](const float* x, int c, float* o) {
+    const bool first = c == c_first;               // the prefetched operands (else: this thread's later units, from memory)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      float y = rh((x[i] - mean) * rstd * a.gamma[c + i] + a.beta[c + i]);
+      const float gm = first ? pg[i] : a.gamma[c + i], bt = first ? pb[i] : a.beta[c + i];
+      float y = rh((x[i] - mean) * rstd * gm + bt);
       if (FILM) {
-        const float sc = rh(1.f + rh(a.emb[(long long)n * a.emb_ld + c + i]));
-        const float sh = rh(a.emb[(long long)n * a.emb_ld + C + c + i]);
+        const float sc = rh(1.f + rh(first ? psc[i] : a.emb[(long long)n * a.emb_ld + c + i]));
+        const float sh = rh(first ? psh[i] : a.emb[(long long)n * a.emb_ld + C + c + i]);
         y = rh(rh(y * sc) + sh);
       }
       if (ACT) y = rh(silu_f(y));

