@@ -167,14 +167,16 @@ __global__ __launch_bounds__(512) void igemm3_kernel(IgemmArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
   }
-  igemm_epilogue<MT, NT, TMW, TNW, BN>(a, acc, m0, n0, wm, wn, lane, 0, ks_id, reinterpret_cast<float*>(smem_raw), !loader);
+  igemm_epilogue<MT, NT, TMW, TNW, BN, 512>(a, acc, m0, n0, wm, wn, lane, 0, ks_id, reinterpret_cast<float*>(smem_raw), !loader);
 #endif
 }
 
 template <int BM, int BN, int NSTW, int NSTX>
 static int launch3(const IgemmArgs& a, hipStream_t s) {
   constexpr int XI = (BM == 128) ? 5 : 3;
-  constexpr size_t smem = (size_t)(NSTW * BN * 64 + NSTX * XI * 32 * 64) * sizeof(half_t);
+  constexpr size_t ring = (size_t)(NSTW * BN * 64 + NSTX * XI * 32 * 64) * sizeof(half_t);
+  constexpr size_t epi = (size_t)BM * (BN + 4) * 4 + (size_t)BM * (BN + 8) * 2 + 16384;      // staged epilogue: fp32 tile + fp16 tile + partial sums
+  constexpr size_t smem = ring > epi ? ring : epi;
   static_assert(smem <= 163840, "LDS");
   auto kern = igemm3_kernel<BM, BN, NSTW, NSTX>;
   ISHAP_TRY(ishap_set_max_lds((const void*)kern, (int)smem));
