@@ -13,6 +13,20 @@
 #include "norm.h"
 #include "gn_bwd_terms.h"
 
+#ifdef GN_STAMPS          // diagnostic build (tools/persist_chain.hip -DGN_STAMPS): s_memtime of thread 0 at the phase boundaries
+extern __device__ unsigned long long* g_gn_stamps;      // [workgroup][8]
+#define GN_STAMP(k)                                                                                    \
+  do {                                                                                                 \
+    if (threadIdx.x == 0) {                                                                            \
+      unsigned long long t_;                                                                           \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+      g_gn_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (k)] = t_;                       \
+    }                                                                                                  \
+  } while (0)
+#else
+#define GN_STAMP(k) do {} while (0)
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -129,6 +143,8 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
 // A sum travels as TWO granules, hi = (float)s and lo = (float)(s - hi): the pair carries 48 significant bits, so the
 // variance q/cnt - mean^2 formed from the exchanged totals is as cancellation-safe as the one-workgroup route, which keeps
 // its sums in double (a group with |mean| = 100 std: one fp32 granule per sum lost ~10 % of the variance).
+// (Alternative measured in round 3: sums about a common pivot every part derives from the group's first element, one fp32
+// granule per sum -- the extra uniform loads of the pivot cost more than the two granules they save: 13 100 vs 11 850 cycles.)
 // The totals are formed from the parts in part order in double: bitwise reproducible, no atomics.
 // rec = [parts][4] granules, zeroed before the launch (tag 0 = not yet written).  The launcher only uses parts > 1 when the
 // whole grid is resident at once; the spin is bounded all the same, and a give-up is an ERROR: it raises the process-wide
@@ -184,6 +200,7 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
   const int PP = HW / a.parts, p0 = part * PP;                           // this workgroup's pixels [p0, p0 + PP)
   const int nunits = PP * VPP, c0g = g * cpg;
   const int Cb = C - a.Ca;
+  GN_STAMP(0);
   const bool pend = a.slab.pending();
   // affine / FiLM operands of this thread's FIRST unit, fetched now: their round trip then overlaps the statistics pass and
   // the rendezvous instead of standing between them and the output (a thread rarely has a second unit on these maps)
@@ -204,14 +221,18 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
     float v[VEC];
     if (c < a.Ca) {
       if (pend) {
-        slab_sum<VEC>(a.slab, row, a.Ca, c, v);
+        // bias / residual are fetched BEFORE the slices are waited for: one memory round trip instead of three in a row
+        // (the kernel is latency-bound, tools/persist_chain.hip -DGN_STAMPS)
+        float bv[VEC], b2v[VEC], r[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { bv[i] = 0.f; b2v[i] = 0.f; r[i] = 0.f; }
         if (a.slab.bias) {
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) v[i] += a.slab.bias[c + i];
+          for (int i = 0; i < VEC; ++i) bv[i] = a.slab.bias[c + i];
         }
         if (a.slab.bias2) {
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) v[i] += a.slab.bias2[c + i];
+          for (int i = 0; i < VEC; ++i) b2v[i] = a.slab.bias2[c + i];
         }
         if (a.slab.res) {
           long long rrow = row;
@@ -219,8 +240,18 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
             const int py = p / a.W, px = p - py * a.W;
             rrow = (long long)n * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1);
           }
-          float r[VEC];
           ld_half<VEC>(a.slab.res + rrow * a.slab.ldr + c, r);
+        }
+        slab_sum<VEC>(a.slab, row, a.Ca, c, v);
+        if (a.slab.bias) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v[i] += bv[i];
+        }
+        if (a.slab.bias2) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v[i] += b2v[i];
+        }
+        if (a.slab.res) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) v[i] += r[i];
         }
@@ -238,8 +269,11 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { s += (double)v[i]; q += (double)v[i] * (double)v[i]; }
   }
+  GN_STAMP(1);
   block_sum2(s, q, scratch);
+  GN_STAMP(2);
   group_rendezvous(s, q, a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE, part, a.parts, scratch, a.status, a.spin_limit);
+  GN_STAMP(3);
   const double cnt = (double)HW * (double)cpg;
   const double md = s / cnt;
   double vd = q / cnt - md * md;
@@ -274,6 +308,7 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
       activate(x, c, o);
       st_half<VEC>(a.out + ((long long)n * HW + p0 + pl) * C + c, o);
     }
+    GN_STAMP(4);
   } else {
     // a part is a whole number of row pairs (launcher), so its 2x2 cells are its own
     const int Wo = a.W >> 1, HWo = HW >> 2, PPo = PP >> 2, po0 = p0 >> 2;

@@ -28,6 +28,9 @@ hipEvent_t g_igemm_prof_start = nullptr, g_igemm_prof_stop = nullptr;
 #ifdef C8_STAMPS
 __device__ unsigned long long* g_c8_stamps;
 #endif
+#ifdef GN_STAMPS
+__device__ unsigned long long* g_gn_stamps;
+#endif
 void ishap_set_error(const std::string& m) { fprintf(stderr, "ERR %s\n", m.c_str()); }
 static unsigned* g_status_host = nullptr;
 unsigned* ishap_status_word() {
@@ -346,8 +349,37 @@ int main(int argc, char** argv) {
     g.gamma = dg; g.beta = db; g.N = 1; g.H = 8; g.W = 8; g.C = C; g.act = 1;
     if (gn_local_launch(g, s)) exit(1);
   };
+#ifdef GN_STAMPS
+  unsigned long long* dstg; CK(hipMalloc(&dstg, 512 * 8 * 8)); CK(hipMemset(dstg, 0, 512 * 8 * 8));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gn_stamps), &dstg, sizeof(dstg)));
+#endif
   for (int i = 0; i < 3; ++i) run_launches();
   CK(hipStreamSynchronize(s));
+#ifdef GN_STAMPS
+  {
+    // the last GroupNorm launch of run_launches is the final materialise (parts = 1); re-run ONE mid-chain GroupNorm for the stamps
+    CK(hipMemset(dstg, 0, 512 * 8 * 8));
+    CK(hipMemsetAsync(drec, 0, (size_t)L * 32 * GN_REC_STRIDE * 8, s));
+    SlabSrc pend; pend.ws = dslab; pend.nslab = 4; pend.zstride = (long long)HWP * C; pend.bias = dbias; pend.res = dXref; pend.ldr = C;
+    GnLocalArgs g;
+    g.xa = dXref + (size_t)1 * HWP * C; g.slab = pend; g.ya = dXref + (size_t)1 * HWP * C; g.Ca = C; g.out = dA; g.stats_out = dstats;
+    g.gamma = dg; g.beta = db; g.N = 1; g.H = 8; g.W = 8; g.C = C; g.act = 1; g.rec = drec;
+    if (gn_local_launch(g, s)) exit(1);
+    CK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h(512 * 8);
+    CK(hipMemcpy(h.data(), dstg, h.size() * 8, hipMemcpyDeviceToHost));
+    const char* nm[4] = {"slices summed (+bias, residual), fp16 stored, staged in LDS", "workgroup sums (block_sum2)", "rendezvous with the group's other parts",
+                         "normalise + SiLU + store"};
+    printf("  gn_local_kernel on a pending 8x8 x 1024 map (4 slices), phases (shader cycles, median over workgroups):\n");
+    for (int k = 0; k < 4; ++k) {
+      std::vector<double> d;
+      for (int w = 0; w < 512; ++w) if (h[w * 8 + k] && h[w * 8 + k + 1] > h[w * 8 + k]) d.push_back((double)(h[w * 8 + k + 1] - h[w * 8 + k]));
+      if (d.empty()) continue;
+      std::sort(d.begin(), d.end());
+      printf("    %-62s %7.0f   (p10 %7.0f  p90 %7.0f)  [%zu workgroups]\n", nm[k], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10], d.size());
+    }
+  }
+#endif
   float best_a = 1e9;
   for (int rep = 0; rep < 10; ++rep) {
     CK(hipEventRecord(e0, s));
