@@ -42,9 +42,17 @@ extern __device__ unsigned long long* g_ig_stamps;      // [workgroup][16]
 // (sum dyh, sum dyh*xhat, gn_bwd_terms.h) add their rows' terms in registers and meet by butterfly.  Either way the
 // workgroup's totals go out as 64-bit fixed point (integer atomics commute: bitwise reproducible).
 // ---------------------------------------------------------------------------------------------------------------
+// block-uniform (kernel arguments only): dense fp16 outputs of an unsplit launch take the staged, all-waves epilogue
+__device__ __forceinline__ bool igemm_epilogue_is_staged(const IgemmArgs& a, int batch) {
+  const half_t* out16 = (const half_t*)a.out + (long long)batch * a.bso;
+  const bool aligned16 = ((reinterpret_cast<unsigned long long>(out16) | reinterpret_cast<unsigned long long>(a.res)) & 15) == 0;
+  return a.out_mode == IG_OUT_F16 && a.ksplit == 1 && (a.N & 7) == 0 && (a.ldo & 7) == 0 && (!a.res || (a.ldr & 7) == 0) && aligned16 &&
+         (!a.gb_x || (a.N & 31) == 0);
+}
+
 template <int MT, int NT, int TMW, int TNW, int BN, int T>
 __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 (&acc)[NT][MT], int m0, int n0, int wm, int wn,
-                                                      int lane, int batch, float* lds_f, bool active) {
+                                                      int lane, int batch, float* lds_f, bool active, int team2) {
   constexpr int BM_T = 2 * TMW;
   constexpr int LDF = BN + 4;                      // fp32 tile pitch: conflict-free ds_write_b128 of the fragments and row reads
   constexpr int LDH = BN + 8;                      // fp16 tile pitch (halfs)
@@ -57,8 +65,9 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
   constexpr int PARTS = (T / PAIRS) < (BM_T / 8) ? (T / PAIRS) : (BM_T / 8);
   constexpr int RPP = BM_T / PARTS;
   static_assert(T % CPRW == 0 && (ITEMS % T == 0 || ITEMS < T) && BM_T % PARTS == 0, "thread <-> tile mappings");
-  float* const tileF = lds_f;                                               // [BM_T][LDF] raw accumulators
-  half_t* const tileH = reinterpret_cast<half_t*>(lds_f + BM_T * LDF);      // [BM_T][LDH] the stored (rounded) values
+  const bool two = team2 >= 0;                                              // block-uniform
+  float* const tileF = lds_f;                                               // [BM_T][LDF] raw accumulators (two teams: team 1's tile follows)
+  half_t* const tileH = reinterpret_cast<half_t*>(lds_f + (two ? 2 : 1) * BM_T * LDF);   // [BM_T][LDH] the stored (rounded) values
   float* const slots = reinterpret_cast<float*>(tileH + BM_T * LDH);        // partial sums: [PARTS][PAIRS][4] or [NW][BN][2]
   const int t = threadIdx.x;
   const bool stamp_wave = active && wm == 0 && wn == 0;
@@ -66,11 +75,12 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
   IG_STAMP(5, stamp_wave);
   __syncthreads();                                 // the K loop's LDS tiles are dead from here on
   if (active) {
+    float* const mine = tileF + (two ? team2 * BM_T * LDF : 0);
 #pragma unroll
     for (int j = 0; j < MT; ++j)
 #pragma unroll
       for (int i = 0; i < NT; ++i)
-        *reinterpret_cast<f32x4*>(tileF + (wm * TMW + j * 16 + (lane & 15)) * LDF + wn * TNW + i * 16 + (lane >> 4) * 4) = acc[i][j];
+        *reinterpret_cast<f32x4*>(mine + (wm * TMW + j * 16 + (lane & 15)) * LDF + wn * TNW + i * 16 + (lane >> 4) * 4) = acc[i][j];
   }
   // this thread's chunk: epilogue operands once per thread, issued before the barrier so that their latency overlaps it
   const int chunk = t % CPRW, row_first = t / CPRW;
@@ -130,6 +140,10 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
       const int row = row_first + k * RSTEP;
       const float* src = tileF + row * LDF + chunk * 8;
       f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+      if (two) {                                   // team 0 + team 1, the order of the old merge pass
+        v0 += *reinterpret_cast<const f32x4*>(src + BM_T * LDF);
+        v1 += *reinterpret_cast<const f32x4*>(src + BM_T * LDF + 4);
+      }
       v0 *= alpha; v1 *= alpha;                    // alpha * acc (+ bias) (+ bias2) (+ residual), in this order
       if (a.bias) { v0 += b1[0]; v1 += b1[1]; }
       if (a.bias2) { v0 += b2[0]; v1 += b2[1]; }
@@ -234,9 +248,12 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
 // loader waves included.  The fragment layout's own stores are 8 bytes per lane over 16 rows: issue-bound, ~9 us of
 // a 128^2-map launch against ~2 us this way (tools/fixed_cost_probe2.sh).  Values and their order of evaluation are
 // unchanged, so results are bit-identical to the direct path.
+// `team2` >= 0 (two-team kernels on the staged path only): this wave belongs to team `team2`, and BOTH teams hold partial
+// accumulators that the staged epilogue adds up (team 0 + team 1) while it finishes the rows -- the separate merge pass
+// through LDS (two barriers, 1 100 cycles of a 64x64 launch) is gone.  -1: `acc` is complete in the waves flagged `active`.
 template <int MT, int NT, int TMW, int TNW, int BN, int STAGE_THREADS = 0>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[NT][MT], int m0, int n0, int wm, int wn,
-                                               int lane, int batch, int ks_id, float* lds_f, bool active = true) {
+                                               int lane, int batch, int ks_id, float* lds_f, bool active = true, int team2 = -1) {
   // `active` = false: a loader wave of a producer/consumer kernel -- it owns no outputs but must take part in the
   // workgroup barriers of the statistics reduction below
   // fields used inside the unrolled tile loops, read once: left as `a.field` the compiler kept {alpha, out_mode, stat_out}
@@ -252,11 +269,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
   constexpr int LDT = BN + 8;                    // staged-tile row pitch in halfs (conflict-free 8-byte fragment writes)
   half_t* const out16 = (half_t*)a.out + (long long)batch * a.bso;
   if constexpr (STAGE_THREADS > 0) {
-    // wave-uniform (kernel arguments only): dense fp16 outputs of an unsplit launch take the staged, all-waves form above
-    const bool aligned16 = ((reinterpret_cast<unsigned long long>(out16) | reinterpret_cast<unsigned long long>(resp)) & 15) == 0;
-    if (out_mode == IG_OUT_F16 && a.ksplit == 1 && (a.N & 7) == 0 && (a.ldo & 7) == 0 && (!resp || (a.ldr & 7) == 0) && aligned16 &&
-        (!a.gb_x || (a.N & 31) == 0)) {
-      igemm_epilogue_staged<MT, NT, TMW, TNW, BN, STAGE_THREADS>(a, acc, m0, n0, wm, wn, lane, batch, lds_f, active);
+    if (igemm_epilogue_is_staged(a, batch)) {
+      igemm_epilogue_staged<MT, NT, TMW, TNW, BN, STAGE_THREADS>(a, acc, m0, n0, wm, wn, lane, batch, lds_f, active, team2);
       return;
     }
   }
