@@ -169,14 +169,18 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
 #ifndef ABL_NOLOAD
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
+#ifndef ABL_NOX
       if (i % LSPLIT == lpart)
         __builtin_amdgcn_global_load_lds(xp[i], (lds_void*)(sx + (wave * XI + i) * RPI * BK), 16, 0, 0);
+#endif
       xp[i] += xstep[i];
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
+#ifndef ABL_NOW
       if (i % LSPLIT == lpart)
         __builtin_amdgcn_global_load_lds(wp[i], (lds_void*)(sw + (wave * WI + i) * RPI * BK), 16, 0, 0);
+#endif
       wp[i] += BK;
     }
 #endif
