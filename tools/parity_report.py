@@ -36,10 +36,22 @@ def surface_report(vol_gpu, vol_cpu, va, res, dev, extract_surface, mesh_chamfer
     return out
 
 
-def shape_like_report(dec_sd, dev, res, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices):
-    """The same decode + surface comparison on a SHAPE-LIKE level set: a smooth, low-amplitude triplane latent makes the
-    random-weight decoder a smooth function of position (the edit's own latent comes from a random-weight UNet and gives a
-    volume-filling noise surface)."""
+def surface_area(mesh):
+    v, t = mesh
+    t = t.long()
+    return float(0.5 * torch.cross(v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 0]], dim=1).norm(dim=1).sum())
+
+
+def shape_like_report(dec_sd, dev, res, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices, edit_dev=None, edit_cpu=None,
+                      point_num=500000, smooth=0.005, amp=0.0005):
+    """The decode + surface comparison on a SHAPE-LIKE level set.  A smooth, low-amplitude triplane latent makes the
+    random-weight decoder a smooth function of position; the EDIT's own results (the final latents of the device run and
+    of the oracle run: sampling + guided iterations with the same seeds, weights and handles) ride on it as a small
+    perturbation, so the two surfaces differ by exactly what the edit path's numerics differ by -- the random-weight UNet
+    alone gives a volume-filling noise surface on which any sampled Chamfer sits on its sampling floor.
+    Chamfer is calc_chamfer's (meshProcess.py:18-35): `point_num` points drawn uniformly by area on each mesh, the two
+    mean squared nearest-neighbour distances added; its sampling floor for a surface of area A is ~ 2 A / (pi N) per
+    direction pair, so on this surface (A ~ 47) N = 500 000 puts the floor below the 1e-4 target (20 000, the reference's default, sits at 1e-3)."""
     from ishapediting_amd.triplane_decoder import MultiTriplane, decode_volume
     from oracle import ref_cpu as O
     S = 128
@@ -48,13 +60,16 @@ def shape_like_report(dec_sd, dev, res, extract_surface, mesh_chamfer, chamfer_d
     lat = torch.zeros(1, 96, S, S)
     for c in range(96):                                  # a few low-frequency modes per channel
         a, b, p, q = torch.randn(4, generator=g)
-        lat[0, c] = 0.02 * (a * torch.cos(1.5 * xx + p) + b * torch.cos(1.5 * yy + q))
+        lat[0, c] = smooth * (a * torch.cos(1.5 * xx + p) + b * torch.cos(1.5 * yy + q))
+    # amp: the edit's latent (|x| <= 1) rides on the smooth field at a tenth of its amplitude
+    lat_dev = lat + (amp * edit_dev.float().cpu() if edit_dev is not None else 0)
+    lat_cpu = lat + (amp * edit_cpu.float().cpu() if edit_cpu is not None else 0)
     dec = MultiTriplane(1, device=dev)
     dec.net.load_state_dict(dec_sd)
-    vg = decode_volume(dec, lat.to(dev), 1.0, 0.0, res)
+    vg = decode_volume(dec, lat_dev.to(dev), 1.0, 0.0, res)
     torch.cuda.synchronize()
-    vc = O.decode_volume(dec_sd, lat, 1.0, 0.0, res)
-    level = float(vc.median())                           # cut the smooth field where it splits the volume in two
+    vc = O.decode_volume(dec_sd, lat_cpu, 1.0, 0.0, res)
+    level = float(vc.median())                           # cut the field where it splits the volume in two
     meshes, out = [], {}
     for name, vol in (("device", vg), ("oracle", vc.to(dev))):
         v, t = extract_surface(vol, level, method="marching_cubes")
@@ -63,13 +78,20 @@ def shape_like_report(dec_sd, dev, res, extract_surface, mesh_chamfer, chamfer_d
         out[f"triangles_{name}_volume"] = int(t.shape[0])
     va = mc_vertices(vg.cpu(), level) / res * 2 - 1
     vb = mc_vertices(vc, level) / res * 2 - 1
+    area = surface_area(meshes[1])
     out.update({
+        "what": f"decode of (smooth triplane of amplitude {smooth} + {amp} x the edit's final latent), device edit vs oracle edit" if edit_dev is not None
+                else "decode of a smooth triplane",
         "res": res, "level": level, "logit_max_abs_err": float((vg.cpu() - vc).abs().max()), "logit_rms": float(vc.pow(2).mean().sqrt()),
         "sign_flips_about_level": int(((vg.cpu() > level) != (vc > level)).sum()),
         "checker_vertex_count_device_volume": int(va.shape[0]), "checker_vertex_count_oracle_volume": int(vb.shape[0]),
+        "surface_area": area,
         "chamfer_all_vertices": chamfer_distance(va.to(dev), vb.to(dev), None),
         "chamfer_area_uniform_20k": mesh_chamfer(meshes[0], meshes[1], 20000),
         "chamfer_area_uniform_20k_floor": mesh_chamfer(meshes[1], (meshes[1][0].clone(), meshes[1][1].clone()), 20000, seed=1),
+        f"chamfer_area_uniform_{point_num // 1000}k": mesh_chamfer(meshes[0], meshes[1], point_num),
+        f"chamfer_area_uniform_{point_num // 1000}k_floor": mesh_chamfer(meshes[1], (meshes[1][0].clone(), meshes[1][1].clone()), point_num, seed=1),
+        f"chamfer_floor_estimate_2A_over_piN_{point_num // 1000}k": 2.0 * area / (3.141592653589793 * point_num),
     })
     return out
 
@@ -79,7 +101,7 @@ def main():
     ap.add_argument("--T", type=int, default=12)
     ap.add_argument("--W", type=int, default=4)
     ap.add_argument("--res", type=int, default=96)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "round2_parity.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "round3_parity.json"))
     a = ap.parse_args()
     from ishapediting_amd import synthetic
     from ishapediting_amd.drag_utils import DragStuff, get_args
@@ -141,7 +163,8 @@ def main():
         "chamfer_20k_samples": chamfer_distance(va.to(dev), vb.to(dev), 20000) if min(va.shape[0], vb.shape[0]) > 0 else None,
         "chamfer_20k_sampling_floor": chamfer_distance(vb.to(dev), vb.clone().to(dev), 20000, seed=1),
         **surface_report(vol_gpu, vol_cpu, va, a.res, dev, extract_surface, mesh_chamfer),
-        "shape_like_decode": shape_like_report(dec_sd, dev, 128, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices),
+        "shape_like_edit": shape_like_report(dec_sd, dev, 128, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices,
+                                             edit_dev=lat_gpu, edit_cpu=final),
         "oracle_drag_losses": losses, "device_drag_losses": [float(l) for l in ds.last_losses],
         "seconds_device": round(t_gpu, 2), "seconds_oracle_cpu": round(t_cpu, 1),
     }
