@@ -166,31 +166,39 @@ class DragKernels:
 
 def synthesize_latent(model, diffusion, args=None, t1=None, t2=0, inter_latent_idx=None, inter_feat_idx=None, img=None,
                       calc_grad=False, **kwargs):
-    """drag_utils.py:61-131 (no caller in the reference; kept for the call surface, no-grad branch)."""
+    """drag_utils.py:61-131 (no caller in the reference; kept for the call surface).  calc_grad=True keeps the autograd
+    graph from the returned tensors back to `img` (a fresh leaf when `img` is None, :86-87; pass a tensor with
+    requires_grad=True otherwise, as there) through differentiable.UNetCall, and records `noise` / `variance` at the
+    inter_feat_idx steps (:104-105); calc_grad=False runs the same loop under no_grad (:115-128)."""
     if args is None:
         args = get_args()
-    if calc_grad:
-        raise NotImplementedError("calc_grad=True relied on autograd through the sampler; use DragStuff.training")
     shape = (args.batch_size, 96, args.image_size, args.image_size)
     if img is None:
         img = th.randn(shape, device=next(model.parameters()).device)
+        if calc_grad:
+            img.requires_grad_(True)
     assert img.shape == shape
     if t1 is None:
         t1 = args.num_steps
     elif t1 == 0:
         return {"img": img[:args.num_samples], "inter_latent": [], "inter_feat": [], "pred_xstart": [], "model_output": None}
-    inter_latent, inter_feat, predict_x0, model_output = [], [], [], None
-    for i in range(t1 - 1, t2 - 1, -1):
-        out = diffusion.p_sample_guidance(model, img, i, **kwargs)
-        img = out["sample"]
-        if inter_feat_idx is not None and i in inter_feat_idx:
-            inter_feat.append(out["inter_feat"])
-        if inter_latent_idx is not None and i in inter_latent_idx:
-            inter_latent.append(img)
-            predict_x0.append(out["pred_xstart"])
-        model_output = out["model_output"]
+    sample_fun = diffusion.ddim_sample if getattr(args, "use_ddim", False) else diffusion.p_sample_guidance
+    inter_latent, inter_feat, predict_x0, model_output, variance, noise = [], [], [], None, [], []
+    with (th.enable_grad() if calc_grad else th.no_grad()):
+        for i in range(t1 - 1, t2 - 1, -1):
+            out = sample_fun(model, img, i, **kwargs)
+            img = out["sample"]
+            if inter_feat_idx is not None and i in inter_feat_idx:
+                inter_feat.append(out["inter_feat"])
+                if calc_grad:
+                    noise.append(out["noise"].cpu())
+                    variance.append(out["variance"].cpu())
+            if inter_latent_idx is not None and i in inter_latent_idx:
+                inter_latent.append(img)
+                predict_x0.append(out["pred_xstart"])
+            model_output = out["model_output"]
     return {"img": img[:args.num_samples], "inter_latent": inter_latent, "inter_feat": inter_feat,
-            "pred_xstart": predict_x0, "model_output": model_output, "variance": [], "noise": []}
+            "pred_xstart": predict_x0, "model_output": model_output, "variance": variance, "noise": noise}
 
 
 class DragStuff:

@@ -139,6 +139,30 @@ class SpacedDiffusion:
     def _prep(x):
         return x.detach().to(dtype=torch.float32).contiguous()
 
+    def _guidance_step_autograd(self, model, x, ti, noise, variance, variance_noise, clip_denoised, feat_layer):
+        """p_sample_guidance with the graph kept (gaussian_diffusion.py:232-331 for LEARNED_RANGE + EPSILON, :489-510): what
+        the reference's autograd records when `x.requires_grad` (synthesize_latent(calc_grad=True), drag_utils.py:86-87).
+        The model call is differentiable.UNetCall (re-forward + the library's input-gradient passes); the step arithmetic
+        is a handful of elementwise torch ops on the device -- the same fp32 formulas ishap_ddpm_step evaluates."""
+        from .differentiable import unet_call
+        f32 = lambda a: float(np.float32(a[ti]))                   # noqa: E731
+        Cc = x.shape[1]
+        mo, inter = unet_call(model, x, [self.timestep_map[ti]] * x.shape[0], feat_layer)
+        eps, v = torch.split(mo, Cc, dim=1)
+        frac = (v + 1) / 2
+        var = torch.exp(frac * f32(self._log_betas) + (1 - frac) * f32(self.posterior_log_variance_clipped))
+        x0 = f32(self.sqrt_recip_alphas_cumprod) * x - f32(self.sqrt_recipm1_alphas_cumprod) * eps
+        if clip_denoised:
+            x0 = x0.clamp(-1, 1)
+        mean = f32(self.posterior_mean_coef1) * x0 + f32(self.posterior_mean_coef2) * x
+        if variance_noise is not None:
+            return {"sample": mean + variance_noise, "inter_feat": inter, "variance": var}
+        noise = noise if noise is not None else torch.randn_like(x)
+        used = var if variance is None else variance
+        sample = mean + (0.0 if ti == 0 else 1.0) * torch.sqrt(used) * noise
+        return {"sample": sample, "pred_xstart": x0, "inter_feat": inter, "model_output": eps, "noise": noise,
+                "variance": used, "mean": mean}
+
     # ------------------------------------------------------------------ reference surface
     def p_sample_guidance(self, model, x, t, noise=None, variance=None, variance_noise=None, clip_denoised=True,
                           denoised_fn=None, cond_fn=None, model_kwargs=None, feat_layer=-1, keep_for_backward=False,
@@ -149,6 +173,10 @@ class SpacedDiffusion:
         them, and the step arithmetic waits for it.  Results are identical with and without it."""
         assert denoised_fn is None and cond_fn is None, "not used on the path"
         ti = self._t_index(t)
+        if torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled() and hasattr(model, "backward_from_output"):
+            assert not model_kwargs and between is None
+            return self._guidance_step_autograd(model, x.to(torch.float32), ti, noise, variance, variance_noise, clip_denoised,
+                                                feat_layer)
         x = self._prep(x)
         kw = dict(model_kwargs or {})
         if hasattr(model, "tap_ptr"):

@@ -457,3 +457,75 @@ def test_prepared_timesteps_are_bit_identical_to_the_in_forward_embedding():
     model.prepare_timesteps([3.0])
     with pytest.raises(RuntimeError, match="preceding forward"):
         model.backward_input(cot)
+
+
+# ------------------------------------------------------------------------------------------ synthesize_latent(calc_grad=True)
+def test_synthesize_latent_calc_grad_matches_oracle_autograd():
+    """drag_utils.py:61-131 with calc_grad=True: three sampler steps with the graph kept, then the gradient of a scalar of
+    the final latent, one intermediate tap and one pred_xstart w.r.t. the initial latent -- against the oracle's own
+    autograd through the same three steps (same fp16-rounded weights, same injected noise).
+    clip_denoised=False: values 1e-2, gradient 1e-2 relative L2 (measured 2e-3).
+    clip_denoised=True (the default): clamp(-1, 1) on pred_xstart has a 0/1 derivative, and with random weights most of
+    pred_xstart sits outside [-1, 1], so fp16 rounding flips the mask of the elements near the bounds: the oracle's OWN
+    fp16-torso run differs from its fp32 run by 0.18-0.25 there.  The device gradient must be within 1.5x that spread of the
+    fp32 oracle (like-for-like bound; values still 1e-2).
+    The no-grad branch returns the same values and no graph."""
+    from oracle import ref_cpu as O
+    from ishapediting_amd.drag_utils import synthesize_latent
+    from ishapediting_amd.gaussian_diffusion import create_gaussian_diffusion
+    from ishapediting_amd.unet import UNetModel
+    cfg, Tn, fl = small96_config(), 6, 1
+    args = small96_args(Tn)
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 511))
+    m = UNetModel(cfg, dev())
+    m.load_state_dict(sd)
+    diff = create_gaussian_diffusion(steps=1000, timestep_respacing=str(Tn))
+    nets = [O.UNetOracle(build_spec(cfg), sd, fp16=False), O.UNetOracle(build_spec(cfg), sd, fp16=True)]
+    od = O.DiffusionOracle(O.Tables(str(Tn)))
+    g = torch.Generator().manual_seed(512)
+    x0 = torch.randn(1, 96, 16, 16, generator=g)
+    noise = torch.randn(1, 96, 16, 16, generator=g)
+    c_img = torch.randn(1, 96, 16, 16, generator=g)
+    c_x0 = torch.randn(1, 96, 16, 16, generator=g)
+    c_tap = None
+
+    def oracle_run(net, clip):
+        nonlocal c_tap
+        xr = x0.clone().requires_grad_(True)
+        img, taps, preds = xr, [], []
+        for i in range(Tn - 1, Tn - 4, -1):
+            o = od.p_sample_guidance(net, img, i, noise=noise, feat_layer=fl, clip_denoised=clip)
+            img = o["sample"]
+            if i == Tn - 2:
+                taps.append(o["inter_feat"])
+                preds.append(o["pred_xstart"])
+        if c_tap is None:
+            c_tap = torch.randn(taps[0].shape, generator=g) * 0.1
+        (gr,) = torch.autograd.grad((img * c_img).sum() + (taps[0].float() * c_tap).sum() + (preds[0] * c_x0).sum(), xr)
+        return img.detach(), taps[0].detach(), preds[0].detach(), gr
+
+    for clip in (False, True):
+        img, tap, pred, ref_g = oracle_run(nets[0], clip)
+        spread = rel(oracle_run(nets[1], clip)[3], ref_g)
+        xd = x0.to(dev()).requires_grad_(True)
+        r = synthesize_latent(m, diff, args, t1=Tn, t2=Tn - 3, inter_latent_idx=[Tn - 2], inter_feat_idx=[Tn - 2], img=xd,
+                              calc_grad=True, noise=noise.to(dev()), feat_layer=fl, clip_denoised=clip)
+        assert r["img"].requires_grad and len(r["inter_feat"]) == 1 and len(r["noise"]) == 1 and len(r["variance"]) == 1
+        assert rel(r["img"], img) < 1e-2 and rel(r["inter_feat"][0], tap) < 1e-2 and rel(r["pred_xstart"][0], pred) < 1e-2
+        loss = (r["img"] * c_img.to(dev())).sum() + (r["inter_feat"][0].float() * c_tap.to(dev())).sum() \
+            + (r["pred_xstart"][0] * c_x0.to(dev())).sum()
+        (gx,) = torch.autograd.grad(loss, xd)
+        r_g = rel(gx, ref_g)
+        print(f"synthesize_latent(calc_grad=True, clip={clip}): gradient rel {r_g:.2e}; oracle fp16-vs-fp32 spread {spread:.2e}")
+        assert r_g < (max(1e-2, 1.5 * spread) if clip else 1e-2), (clip, r_g, spread)
+
+        r0 = synthesize_latent(m, diff, args, t1=Tn, t2=Tn - 3, inter_latent_idx=[Tn - 2], inter_feat_idx=[Tn - 2],
+                               img=x0.to(dev()), calc_grad=False, noise=noise.to(dev()), feat_layer=fl, clip_denoised=clip)
+        assert not r0["img"].requires_grad and r0["noise"] == [] and r0["variance"] == []
+        # kernel step arithmetic (fused multiply-adds) vs the same formulas as separate torch ops: rounding-level differences
+        # in 27 x - 27 eps, carried through two more UNet calls
+        assert rel(r0["img"], r["img"].detach().cpu()) < 2e-3
+        assert rel(r0["inter_feat"][0], r["inter_feat"][0].detach().cpu()) < 2e-3
+    # a leaf created inside (img=None) carries the graph too
+    r1 = synthesize_latent(m, diff, args, t1=1, calc_grad=True, feat_layer=fl)
+    assert r1["img"].requires_grad
