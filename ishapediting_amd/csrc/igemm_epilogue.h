@@ -211,7 +211,12 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
         }
         const double P = (double)(float)tileH[nl], nn = (double)BM_T;
         const double v = k ? Q + P * (2.0 * S + nn * P) : S + nn * P;
+#ifdef ABL_STAT_COPIES      // harness probe (tools/stat_probe2.sh): spread the same-address atomics over copies of the table
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stat_out + (long long)((m0 / BM_T) % ABL_STAT_COPIES) * a.N * 2 +
+                                                        ((long long)n_img * a.N + n0 + nl) * 2 + k),
+#else
         atomicAdd(reinterpret_cast<unsigned long long*>(a.stat_out + ((long long)n_img * a.N + n0 + nl) * 2 + k),
+#endif
                   (unsigned long long)__double2ll_rn(v * (double)(k ? STAT_SCALE_SQ : STAT_SCALE_SUM)));
       }
     }
