@@ -93,6 +93,46 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// The same for a double (its two 32-bit halves move together), then the four row sums meet through v_readlane: the sum over
+// the 64 lanes of a wave, bitwise the same value in every lane, in ~20 instructions -- a __shfl_xor butterfly on doubles is
+// 24 ds_bpermute round trips in a dependent chain (~900 cycles of the latency-bound GroupNorm kernels).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_move_f64<0xB1>(v);
+  v += dpp_move_f64<0x4E>(v);
+  v += dpp_move_f64<0x141>(v);
+  v += dpp_move_f64<0x140>(v);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+// sum over aligned groups of 8 lanes (quad swaps + half-row mirror), 64-bit integer and float forms
+template <int CTRL>
+__device__ __forceinline__ long long dpp_move_i64(long long v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(v & 0xffffffffll), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xF, 0xF, true);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ long long lanes8_sum(long long v) {
+  v += dpp_move_i64<0xB1>(v);
+  v += dpp_move_i64<0x4E>(v);
+  v += dpp_move_i64<0x141>(v);
+  return v;
+}
+__device__ __forceinline__ float lanes8_sum(float v) {
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  return v;
+}
+
 __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, dpp_move<0xB1>(v));
   v = fmaxf(v, dpp_move<0x4E>(v));

@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
         si += sp[0];
         qi += sp[1];
       }
-#pragma unroll
-      for (int o = 1; o < 8; o <<= 1) { si += __shfl_xor(si, o); qi += __shfl_xor(qi, o); }
+      si = lanes8_sum(si);                          // DPP, not ds_bpermute: this prologue stands in front of every load
+      qi = lanes8_sum(qi);
       if (part == 0) {
         const double md = (double)si * (1.0 / (double)STAT_SCALE_SUM) / (double)cnt;
         double vd = (double)qi * (1.0 / (double)STAT_SCALE_SQ) / (double)cnt - md * md;

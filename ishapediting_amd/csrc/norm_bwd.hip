@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
         s1 += (float)a.csums[((long long)n * a.C + c) * 2] * (1.f / STAT_SCALE_SUM);
         s2 += (float)a.csums[((long long)n * a.C + c) * 2 + 1] * (1.f / STAT_SCALE_SUM);
       }
-#pragma unroll
-      for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      s1 = lanes8_sum(s1);
+      s2 = lanes8_sum(s2);
       if (part == 0) { sh_m[(n * 32 + g) * 2] = s1 / cnt; sh_m[(n * 32 + g) * 2 + 1] = s2 / cnt; }
     }
     __syncthreads();

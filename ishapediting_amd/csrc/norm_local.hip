@@ -126,14 +126,18 @@ __device__ __forceinline__ float rh(float v) { return (float)(half_t)v; }
 
 // block-wide sums of two doubles (every thread gets them); `scratch` = 2 * 16 doubles of LDS
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  a = wave_sum_f64(a);                   // DPP + v_readlane (common.h): the butterfly of 64-bit __shfl_xor cost ~400 cycles more
+  b = wave_sum_f64(b);
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  __syncthreads();
+  // (no barrier in front: `scratch` is written here for the first time in both kernels)
   if ((threadIdx.x & 63) == 0) { scratch[wave] = a; scratch[16 + wave] = b; }
   __syncthreads();
   a = 0.0; b = 0.0;
-  for (int w = 0; w < nw; ++w) { a += scratch[w]; b += scratch[16 + w]; }      // fixed order
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {         // fixed order; all 32 reads in flight (slots >= nw are stale and not added)
+    const double pa = scratch[w], pb = scratch[16 + w];
+    if (w < nw) { a += pa; b += pb; }
+  }
 }
 
 // Several workgroups share one (image, group): each publishes its two partial sums as data-tagged 8-byte granules
@@ -144,7 +148,9 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
 // variance q/cnt - mean^2 formed from the exchanged totals is as cancellation-safe as the one-workgroup route, which keeps
 // its sums in double (a group with |mean| = 100 std: one fp32 granule per sum lost ~10 % of the variance).
 // (Alternative measured in round 3: sums about a common pivot every part derives from the group's first element, one fp32
-// granule per sum -- the extra uniform loads of the pivot cost more than the two granules they save: 13 100 vs 11 850 cycles.)
+// granule per sum -- the extra uniform loads of the pivot cost more than the two granules they save: 13 100 vs 11 850 cycles.
+// Also measured: block sum + rendezvous merged into one routine where wave 0 alone adds the wave partials, publishes, polls
+// and adds the parts by v_readlane (two barriers instead of five): 204 + 5 676 cycles against 1 456 + 3 332 -- slower.)
 // The totals are formed from the parts in part order in double: bitwise reproducible, no atomics.
 // rec = [parts][4] granules, zeroed before the launch (tag 0 = not yet written).  The launcher only uses parts > 1 when the
 // whole grid is resident at once; the spin is bounded all the same, and a give-up is an ERROR: it raises the process-wide
