@@ -218,6 +218,7 @@ struct IgemmArgs {
   long long bsx = 0, bsw = 0, bso = 0;   // per-batch strides (elements)
   int nbatch = 1;
   int H = 0, W = 0;              // OUTPUT spatial size (conv3)
+  int nx_shift = -1, ny_shift = -1;  // log2 of the grid's x / y extent when both are powers of two (set by the LDS-DMA launcher): tile remap by shifts
   int w_shift = -1, hw_shift = -1;   // log2(W), log2(H*W) when both are powers of two (set by the launcher): the kernels then
                                      // split a pixel index with shifts instead of ~50-instruction integer divisions
   int ups = 0;                   // conv3 source map is (H/2, W/2): nearest-neighbour upsample on the fly

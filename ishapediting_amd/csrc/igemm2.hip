@@ -57,9 +57,15 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
     const int lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
     const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, pos = lin >> 3;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-    tile_n = swz % ny;
-    tile_m = (swz / ny) % nx;
-    tile_z = swz / (ny * nx);
+    if (a.ny_shift >= 0) {               // power-of-two grid (nearly every launch): no integer divisions in the prologue
+      tile_n = swz & (ny - 1);
+      tile_m = (swz >> a.ny_shift) & (nx - 1);
+      tile_z = swz >> (a.ny_shift + a.nx_shift);
+    } else {
+      tile_n = swz % ny;
+      tile_m = (swz / ny) % nx;
+      tile_z = swz / (ny * nx);
+    }
   }
 #ifdef ABL_SAMEX
   const int m0 = (tile_m & 1) * BM;      // every block reads the same two pixel tiles (L2-hot probe; wrong results)
@@ -67,12 +73,12 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
   const int m0 = tile_m * BM;
 #endif
   const int n0 = tile_n * BN;
-  const int batch = tile_z / a.ksplit;
-  const int ks_id = tile_z % a.ksplit;
+  const int batch = a.ksplit == 1 ? tile_z : tile_z / a.ksplit;
+  const int ks_id = a.ksplit == 1 ? 0 : tile_z % a.ksplit;
   const half_t* X = a.X + (long long)batch * a.bsx;
   const half_t* Wt = a.Wt + (long long)batch * a.bsw;
   const int KS = a.K / BK;
-  const int per = (KS + a.ksplit - 1) / a.ksplit;
+  const int per = a.ksplit == 1 ? KS : (KS + a.ksplit - 1) / a.ksplit;
   int ks0 = ks_id * per;
   int ks1 = min(KS, ks0 + per);
   int nk_loop = ks1 - ks0;                       // barrier count: identical for every wave of the workgroup
@@ -349,6 +355,9 @@ static int launch2(const IgemmArgs& a, hipStream_t s) {
   b.w_shift = a.W > 0 ? lg2(a.W) : -1;
   b.hw_shift = (a.W > 0 && a.H > 0) ? lg2(a.H * a.W) : -1;
   if (b.w_shift < 0 || b.hw_shift < 0) b.w_shift = b.hw_shift = -1;
+  b.nx_shift = lg2((int)grid.x);
+  b.ny_shift = lg2((int)grid.y);
+  if (b.nx_shift < 0 || b.ny_shift < 0) b.nx_shift = b.ny_shift = -1;
   if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3((256 + 64 * IG2_LOADERS) * HALVES), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, b);
   else hipLaunchKernelGGL(kern, grid, dim3((256 + 64 * IG2_LOADERS) * HALVES), smem, s, b);
   ISHAP_CHECK_HIP(hipGetLastError());
