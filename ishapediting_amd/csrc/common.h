@@ -198,6 +198,23 @@ struct SlabSrc {
   __host__ __device__ bool pending() const { return nslab > 0; }
 };
 
+// The arguments an LDS-DMA convolution kernel needs before it can issue its first load, as its FIRST kernel parameter: 14
+// dwords of plain scalars, which the build's -amdgpu-kernarg-preload-count=14 has the command processor place in SGPRs at
+// dispatch.  A kernel otherwise starts by waiting ~430 cycles (0.19 us, tools/kernarg_probe.hip) for the s_load of its
+// argument block; the rest of IgemmArgs (epilogue operands, second source, batch strides) arrives under the ring fill.
+struct IgemmHot {
+  const half_t* X;
+  const half_t* Wt;
+  int K, Cin, ldx, ldw, H, W, ksplit, nwg;
+  unsigned packed;             // w_shift | hw_shift << 6 | nx_shift << 12 | ny_shift << 18 (6-bit two's complement, -1 = none) | ups << 24
+  __host__ __device__ static int sx6(unsigned v) { return (int)(v & 0x3f) - (int)((v & 0x20) << 1); }
+  __host__ __device__ int w_shift() const { return sx6(packed); }
+  __host__ __device__ int hw_shift() const { return sx6(packed >> 6); }
+  __host__ __device__ int nx_shift() const { return sx6(packed >> 12); }
+  __host__ __device__ int ny_shift() const { return sx6(packed >> 18); }
+  __host__ __device__ bool ups() const { return (packed >> 24) & 1u; }
+};
+
 struct IgemmArgs {
   const half_t* X = nullptr;   // activations
   const half_t* Wt = nullptr;  // [Npad][K] (K contiguous), rows >= N are zero

@@ -21,7 +21,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 // and meeting once in LDS at the end -- split-K by two without partial tiles in HBM or a reduce launch.  It gives a CU
 // that holds a single workgroup (grids of <= 256 tiles) the DMA/MFMA overlap two co-resident workgroups would have.
 template <int BM, int BN, int NST, bool CONV3, int HALVES = 1>
-__global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kernel(IgemmArgs a) {
+__global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kernel(const void* hX, const void* hWt, int hK, int hCin, int hldx, int hldw, int hH, int hW,
+                                                                                   int hksplit, int hnwg, unsigned hpacked, IgemmArgs a) {
+  // plain leading scalars (14 dwords): only those are preloaded into SGPRs (a by-value struct is not); see IgemmHot
+  // (void pointers: the profiler's demangler does not know _Float16 and would list the kernels by their mangled names)
+  const IgemmHot h{(const half_t*)hX, (const half_t*)hWt, hK, hCin, hldx, hldw, hH, hW, hksplit, hnwg, hpacked};
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only builtins; the host pass only needs the launch stub
   constexpr int BK = 64;
   constexpr int CPR = 8;                 // 16-byte chunks per tile row
@@ -52,15 +56,16 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
   // halos overlap, and both n-tiles of the same rows then share an L2.  Pure speed: any placement is correct.
   int tile_m, tile_n, tile_z;
   {
-    const int nx = gridDim.x, ny = gridDim.y;
-    const int nwg = nx * ny * gridDim.z;
+    // grid extents: from the preloaded arguments when they are powers of two (gridDim.* is a load from the hidden arguments)
+    const int nx = h.ny_shift() >= 0 ? (1 << h.nx_shift()) : (int)gridDim.x, ny = h.ny_shift() >= 0 ? (1 << h.ny_shift()) : (int)gridDim.y;
+    const int nwg = h.nwg;
     const int lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
     const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, pos = lin >> 3;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-    if (a.ny_shift >= 0) {               // power-of-two grid (nearly every launch): no integer divisions in the prologue
+    if (h.ny_shift() >= 0) {             // power-of-two grid (nearly every launch): no integer divisions in the prologue
       tile_n = swz & (ny - 1);
-      tile_m = (swz >> a.ny_shift) & (nx - 1);
-      tile_z = swz >> (a.ny_shift + a.nx_shift);
+      tile_m = (swz >> h.ny_shift()) & (nx - 1);
+      tile_z = swz >> (h.ny_shift() + h.nx_shift());
     } else {
       tile_n = swz % ny;
       tile_m = (swz / ny) % nx;
@@ -73,12 +78,16 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
   const int m0 = tile_m * BM;
 #endif
   const int n0 = tile_n * BN;
-  const int batch = a.ksplit == 1 ? tile_z : tile_z / a.ksplit;
-  const int ks_id = a.ksplit == 1 ? 0 : tile_z % a.ksplit;
-  const half_t* X = a.X + (long long)batch * a.bsx;
-  const half_t* Wt = a.Wt + (long long)batch * a.bsw;
-  const int KS = a.K / BK;
-  const int per = a.ksplit == 1 ? KS : (KS + a.ksplit - 1) / a.ksplit;
+  const int batch = h.ksplit == 1 ? tile_z : tile_z / h.ksplit;
+  const int ks_id = h.ksplit == 1 ? 0 : tile_z % h.ksplit;
+  const half_t* X = h.X;
+  const half_t* Wt = h.Wt;
+  if (batch != 0) {                      // batch strides live in the argument block proper (not preloaded): first batch needs none
+    X += (long long)batch * a.bsx;
+    Wt += (long long)batch * a.bsw;
+  }
+  const int KS = h.K / BK;
+  const int per = h.ksplit == 1 ? KS : (KS + h.ksplit - 1) / h.ksplit;
   int ks0 = ks_id * per;
   int ks1 = min(KS, ks0 + per);
   int nk_loop = ks1 - ks0;                       // barrier count: identical for every wave of the workgroup
@@ -89,13 +98,13 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
     ks1 = min(ks1, ks0 + half_n);
   }
   const int nk = max(0, ks1 - ks0);
-  const int HW = a.H * a.W;
+  const int HW = h.H * h.W;
 
   // ---- loader state: instruction i of this wave covers tile rows (wave*XI + i)*8 .. +7.  K order is tap-outer,
   //      channel-inner (k = tap*Cin + c, linear in the K-step).  Source pointers are incremental: they advance by BK
   //      halfs per K-step and are recomputed only when the 3x3 tap changes (measured: the chunk-outer order that
   //      re-reads an activation line on consecutive steps is not faster -- the DMA rate, not L2 locality, bounds it). ----
-  const int steps_per_tap = CONV3 ? a.Cin / BK : KS;
+  const int steps_per_tap = CONV3 ? h.Cin / BK : KS;
   const int lrow = lane >> 3;            // row within the instruction
   const int pch = lane & 7;              // physical chunk this lane fills
   int xn[XI], xy[XI], xx[XI], xsc[XI];
@@ -107,22 +116,22 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
     xsc[i] = (pch ^ ((row >> 1) & 7)) * 8;     // source chunk (halfs) for this physical slot
     const int m = m0 + row;
     if (CONV3) {
-      if (a.hw_shift >= 0) {                     // power-of-two maps (every map of the UNet): shifts, block-uniform branch
-        xn[i] = m >> a.hw_shift;
+      if (h.hw_shift() >= 0) {                   // power-of-two maps (every map of the UNet): shifts, block-uniform branch
+        xn[i] = m >> h.hw_shift();
         const int p = m & (HW - 1);
-        xy[i] = p >> a.w_shift;
-        xx[i] = p & (a.W - 1);
+        xy[i] = p >> h.w_shift();
+        xx[i] = p & (h.W - 1);
       } else {
         xn[i] = m / HW;
         const int p = m - xn[i] * HW;
-        xy[i] = p / a.W;
-        xx[i] = p - xy[i] * a.W;
+        xy[i] = p / h.W;
+        xx[i] = p - xy[i] * h.W;
       }
       xp[i] = g_zero_line;
       xstep[i] = 0;
     } else {
       xn[i] = m; xy[i] = 0; xx[i] = 0;
-      xp[i] = X + (long long)m * a.ldx + (long long)ks0 * BK + xsc[i];
+      xp[i] = X + (long long)m * h.ldx + (long long)ks0 * BK + xsc[i];
       xstep[i] = BK;
     }
   }
@@ -130,7 +139,7 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
     const int row = (wave * WI + i) * RPI + lrow;
-    wp[i] = Wt + (long long)(n0 + row) * a.ldw + (long long)ks0 * BK + (pch ^ ((row >> 1) & 7)) * 8;
+    wp[i] = Wt + (long long)(n0 + row) * h.ldw + (long long)ks0 * BK + (pch ^ ((row >> 1) & 7)) * 8;
   }
   int tap_left = 0;                      // K-steps left before the tap changes (conv)
   int next_ks = ks0;
@@ -141,7 +150,7 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
       tap_left = KS - next_ks;
 #pragma unroll
       for (int i = 0; i < XI; ++i) {
-        const long long m = (long long)xn[i] * HW + xy[i] * a.W + xx[i];
+        const long long m = (long long)xn[i] * HW + xy[i] * h.W + xx[i];
         xp[i] = a.X2 + m * a.ldx2 + c0 + xsc[i];
         xstep[i] = BK;
       }
@@ -154,11 +163,11 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int yy = xy[i] + dy, xc = xx[i] + dx;
-      const bool ok = yy >= 0 && yy < a.H && xc >= 0 && xc < a.W;
+      const bool ok = yy >= 0 && yy < h.H && xc >= 0 && xc < h.W;
       const int yc = ok ? yy : 0, xq = ok ? xc : 0;
-      const long long pix = a.ups ? ((long long)xn[i] * (HW >> 2) + (yc >> 1) * (a.W >> 1) + (xq >> 1))
-                                  : ((long long)xn[i] * HW + yc * a.W + xq);
-      const half_t* src = X + pix * a.ldx + c0 + xsc[i];
+      const long long pix = h.ups() ? ((long long)xn[i] * (HW >> 2) + (yc >> 1) * (h.W >> 1) + (xq >> 1))
+                                    : ((long long)xn[i] * HW + yc * h.W + xq);
+      const half_t* src = X + pix * h.ldx + c0 + xsc[i];
       xp[i] = ok ? src : (const half_t*)g_zero_line;
       xstep[i] = ok ? BK : 0;
     }
@@ -358,8 +367,15 @@ static int launch2(const IgemmArgs& a, hipStream_t s) {
   b.nx_shift = lg2((int)grid.x);
   b.ny_shift = lg2((int)grid.y);
   if (b.nx_shift < 0 || b.ny_shift < 0) b.nx_shift = b.ny_shift = -1;
-  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3((256 + 64 * IG2_LOADERS) * HALVES), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, b);
-  else hipLaunchKernelGGL(kern, grid, dim3((256 + 64 * IG2_LOADERS) * HALVES), smem, s, b);
+  IgemmHot h;
+  h.X = b.X; h.Wt = b.Wt; h.K = b.K; h.Cin = b.Cin; h.ldx = b.ldx; h.ldw = b.ldw; h.H = b.H; h.W = b.W; h.ksplit = b.ksplit;
+  h.nwg = (int)(grid.x * grid.y * grid.z);
+  h.packed = (unsigned)(b.w_shift & 0x3f) | (unsigned)(b.hw_shift & 0x3f) << 6 | (unsigned)(b.nx_shift & 0x3f) << 12 |
+             (unsigned)(b.ny_shift & 0x3f) << 18 | (b.ups ? 1u << 24 : 0u);
+  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3((256 + 64 * IG2_LOADERS) * HALVES), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0,
+                                                (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, b);
+  else hipLaunchKernelGGL(kern, grid, dim3((256 + 64 * IG2_LOADERS) * HALVES), smem, s,
+                          (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, b);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
