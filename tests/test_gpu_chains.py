@@ -529,3 +529,60 @@ def test_synthesize_latent_calc_grad_matches_oracle_autograd():
     # a leaf created inside (img=None) carries the graph too
     r1 = synthesize_latent(m, diff, args, t1=1, calc_grad=True, feat_layer=fl)
     assert r1["img"].requires_grad
+
+
+# ------------------------------------------------------------------------------------------ runtime switches
+_SWITCH_WORKER = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from ishapediting_amd import synthetic
+from ishapediting_amd.unet import UNetModel
+from ishapediting_amd.unet_spec import UNetConfig, build_spec
+cfg = UNetConfig(image_size=32, in_channels=6, model_channels=64, out_channels=12, num_res_blocks=1,
+                 attention_resolutions="16,8", channel_mult=(1, 2, 4), num_head_channels=64)
+dev = torch.device("cuda", 0)
+m = UNetModel(cfg, dev)
+m.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 91)))
+g = torch.Generator().manual_seed(21)
+x = torch.randn(1, 6, 32, 32, generator=g).to(dev)
+k = len(build_spec(cfg).output_blocks) - 2
+ch, sz = m.tap_shape(k)
+cot = (torch.randn(1, sz * sz, ch, generator=g) * 0.1).half().to(dev)
+out, tap = m(x, [617.0], feat_layer=k, keep_for_backward=True)
+gx = m.backward_input(cot)
+torch.cuda.synchronize()
+np.savez({out!r}, out=out.cpu().numpy(), tap=tap.float().cpu().numpy(), gx=gx.cpu().numpy())
+"""
+
+
+def test_runtime_switches_keep_the_results(tmp_path):
+    """Every A/B switch DESIGN.md section 3 lists selects another kernel or grid for the same arithmetic: the mid-size
+    configuration (forward output, a tap, the input gradient) under each switch, in a process of its own (the switches are
+    read once per process), against the default build's results.  Same values up to summation order: relative L2 <= 2e-3
+    forward, 5e-3 gradient (fp16 maps; the default-vs-oracle distance of these quantities is 1e-3 / 3e-3); switches that
+    only move work between grids of the same kernel must not change a bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {"default": {}, "ISHAP_IGEMM3=1": {"ISHAP_IGEMM3": "1"}, "ISHAP_HALVES=1": {"ISHAP_HALVES": "1"},
+            "ISHAP_LOCAL_GN=0": {"ISHAP_LOCAL_GN": "0"}, "ISHAP_SKINNY=0": {"ISHAP_SKINNY": "0"},
+            "ISHAP_SMALL3=0": {"ISHAP_SMALL3": "0"}, "ISHAP_GN_PARTS=1": {"ISHAP_GN_PARTS": "1"},
+            "ISHAP_PREFETCH=1": {"ISHAP_PREFETCH": "1"}}
+    res = {}
+    for name, env in runs.items():
+        path = str(tmp_path / (name.replace("=", "_") + ".npz"))
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", _SWITCH_WORKER.format(root=root, out=path)], env=e, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        res[name] = np.load(path)
+    ref = res["default"]
+    for name, got in res.items():
+        if name == "default":
+            continue
+        r_out, r_tap, r_gx = rel(T(got["out"]), ref["out"]), rel(T(got["tap"]), ref["tap"]), rel(T(got["gx"]), ref["gx"])
+        print(f"{name:18s} out {r_out:.1e} tap {r_tap:.1e} grad {r_gx:.1e}")
+        assert r_out < 2e-3 and r_tap < 2e-3 and r_gx < 5e-3, (name, r_out, r_tap, r_gx)
+        if name == "ISHAP_PREFETCH=1":           # extra workgroups that only touch weights: bitwise the same results
+            assert r_out == 0.0 and r_tap == 0.0 and r_gx == 0.0
