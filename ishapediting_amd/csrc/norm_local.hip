@@ -400,6 +400,11 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(GnBwdLocalArgs a) {
   const int nunits = PP * VPP, c0g = g * cpg;
   const float mu = a.stats[(n * 32 + g) * 2], rs = a.stats[(n * 32 + g) * 2 + 1];
   double s1 = 0.0, s2 = 0.0;
+  // A thread's FIRST unit (its only one on these maps, with rare exceptions) keeps dyh / xh in registers across the
+  // reduction and fetches its addends before it: the pass after the rendezvous then needs no memory round trip of its own.
+  float f_dyh[VEC], f_xh[VEC], f_ad[VEC], f_a2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { f_dyh[i] = 0.f; f_xh[i] = 0.f; f_ad[i] = 0.f; f_a2[i] = 0.f; }
   for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
     const int pl = u / VPP, cv = u - pl * VPP, c = c0g + cv * VEC;
     const int p = p0 + pl;
@@ -420,7 +425,13 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(GnBwdLocalArgs a) {
                   FILM, ACT, dyh, xh);
       s1 += (double)dyh;
       s2 += (double)dyh * (double)xh;
+      if (u == (int)threadIdx.x) { f_dyh[i] = dyh; f_xh[i] = xh; }
     }
+  }
+  if ((int)threadIdx.x < nunits) {
+    const int pl = threadIdx.x / VPP, c = c0g + (threadIdx.x - pl * VPP) * VEC, p = p0 + pl;
+    if (a.add) addend<VEC>(a.add, a.gmode, n, p, a.H, a.W, C, c, f_ad);
+    if (a.add2) ld_half<VEC>(a.add2 + ((long long)n * HW + p) * C + c, f_a2);
   }
   block_sum2(s1, s2, scratch);
   group_rendezvous(s1, s2, a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE, part, a.parts, scratch, a.status, a.spin_limit);
@@ -432,6 +443,19 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(GnBwdLocalArgs a) {
     const int p = p0 + pl;
     const long long pix = (long long)n * HW + p;
     float up[VEC], xv[VEC], ad[VEC], a2[VEC], o[VEC];
+    if (u == (int)threadIdx.x) {                   // the first unit: everything is in registers already
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float v = rs * (f_dyh[i] - m1 - f_xh[i] * m2);
+        if (a.add) v += f_ad[i];
+        if (a.add2) v = rh(v) + f_a2[i];                                 // same rounding as a separate fp16 add of the two maps
+        o[i] = v;
+      }
+      if (a.csplit == 0) st_half<VEC>(a.dx + pix * C + c, o);
+      else if (c < a.csplit) st_half<VEC>(a.dx + pix * a.csplit + c, o);
+      else st_half<VEC>(a.dx2 + pix * (C - a.csplit) + (c - a.csplit), o);
+      continue;
+    }
     if (STAGE32) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) up[i] = st32[pl * cpg + cv * VEC + i];
