@@ -192,20 +192,22 @@ __device__ __forceinline__ void group_rendezvous(double& a, double& b, unsigned 
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int VEC, bool FILM, bool ACT, bool POOL>
-__global__ __launch_bounds__(1024) void gn_local_kernel(GnLocalArgs a) {
+__global__ __launch_bounds__(1024) void gn_local_kernel(int h_parts, int h_C, int h_HW, int h_Ca, GnLocalArgs a) {
+  // h_*: copies of a.parts, a.C, a.H * a.W, a.Ca as leading scalar parameters -- preloaded into SGPRs at dispatch (common.h,
+  // IgemmHot), so that the index arithmetic (three integer divisions) runs UNDER the s_load of the argument block, not after it
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if ((int)blockIdx.x >= 32 * a.parts) {           // prefetch workgroups (last in the grid: the GroupNorm ones are dispatched first)
-    const int npf = gridDim.x - 32 * a.parts;
-    prefetch_block(a.pf, (blockIdx.x - 32 * a.parts) + npf * blockIdx.y, npf * gridDim.y);
+  if ((int)blockIdx.x >= 32 * h_parts) {           // prefetch workgroups (last in the grid: the GroupNorm ones are dispatched first)
+    const int npf = gridDim.x - 32 * h_parts;
+    prefetch_block(a.pf, (blockIdx.x - 32 * h_parts) + npf * blockIdx.y, npf * gridDim.y);
     return;
   }
   double* scratch = reinterpret_cast<double*>(smem_raw);                 // 32 doubles (block_sum2: 2 x 16; rendezvous: 4 x parts)
   half_t* st = reinterpret_cast<half_t*>(smem_raw + 256);                // [HW][cpg]
-  const int g = blockIdx.x / a.parts, part = blockIdx.x - g * a.parts, n = blockIdx.y;
-  const int C = a.C, cpg = C / 32, VPP = cpg / VEC, HW = a.H * a.W;
-  const int PP = HW / a.parts, p0 = part * PP;                           // this workgroup's pixels [p0, p0 + PP)
+  const int g = blockIdx.x / h_parts, part = blockIdx.x - g * h_parts, n = blockIdx.y;
+  const int C = h_C, cpg = C / 32, VPP = cpg / VEC, HW = h_HW;
+  const int PP = HW / h_parts, p0 = part * PP;                           // this workgroup's pixels [p0, p0 + PP)
   const int nunits = PP * VPP, c0g = g * cpg;
-  const int Cb = C - a.Ca;
+  const int Cb = C - h_Ca;
   GN_STAMP(0);
   const bool pend = a.slab.pending();
   // affine / FiLM operands of this thread's FIRST unit, fetched now: their round trip then overlaps the statistics pass and
@@ -384,19 +386,20 @@ __device__ __forceinline__ void addend(const half_t* g, int gmode, int n, int p,
 
 // STAGE32: the staged upstream values are fp32 (GB_UNPOOL / GB_SUM4: a quarter or a sum of four fp16 values is not an fp16 value)
 template <int VEC, bool FILM, bool ACT, bool STAGE32>
-__global__ __launch_bounds__(1024) void gn_bwd_local_kernel(GnBwdLocalArgs a) {
+__global__ __launch_bounds__(1024) void gn_bwd_local_kernel(int h_parts, int h_C, int h_HW, GnBwdLocalArgs a) {
+  // h_*: preloaded copies of a.parts, a.C, a.H * a.W (see gn_local_kernel)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if ((int)blockIdx.x >= 32 * a.parts) {
-    const int npf = gridDim.x - 32 * a.parts;
-    prefetch_block(a.pf, (blockIdx.x - 32 * a.parts) + npf * blockIdx.y, npf * gridDim.y);
+  if ((int)blockIdx.x >= 32 * h_parts) {
+    const int npf = gridDim.x - 32 * h_parts;
+    prefetch_block(a.pf, (blockIdx.x - 32 * h_parts) + npf * blockIdx.y, npf * gridDim.y);
     return;
   }
   double* scratch = reinterpret_cast<double*>(smem_raw);
   half_t* st16 = reinterpret_cast<half_t*>(smem_raw + 256);
   float* st32 = reinterpret_cast<float*>(smem_raw + 256);
-  const int g = blockIdx.x / a.parts, part = blockIdx.x - g * a.parts, n = blockIdx.y;
-  const int C = a.C, cpg = C / 32, VPP = cpg / VEC, HW = a.H * a.W;
-  const int PP = HW / a.parts, p0 = part * PP;
+  const int g = blockIdx.x / h_parts, part = blockIdx.x - g * h_parts, n = blockIdx.y;
+  const int C = h_C, cpg = C / 32, VPP = cpg / VEC, HW = h_HW;
+  const int PP = HW / h_parts, p0 = part * PP;
   const int nunits = PP * VPP, c0g = g * cpg;
   const float mu = a.stats[(n * 32 + g) * 2], rs = a.stats[(n * 32 + g) * 2 + 1];
   double s1 = 0.0, s2 = 0.0;
@@ -570,7 +573,7 @@ int gn_local_launch(const GnLocalArgs& a, hipStream_t s) {
   do {                                                                                   \
     auto kern = gn_local_kernel<V, F, A, P>;                                             \
     ISHAP_TRY(set_lds(kern, smem));                                                      \
-    hipLaunchKernelGGL(kern, grid, blk, smem, s, b);                                     \
+    hipLaunchKernelGGL(kern, grid, blk, smem, s, b.parts, b.C, b.H * b.W, b.Ca, b);      \
   } while (0)
 #define GL_VARIANT(V)                                                                    \
   do {                                                                                   \
@@ -615,7 +618,7 @@ int gn_bwd_local_launch(const GnBwdLocalArgs& a, hipStream_t s) {
   do {                                                                                   \
     auto kern = gn_bwd_local_kernel<V, F, A, S32>;                                       \
     ISHAP_TRY(set_lds(kern, smem));                                                      \
-    hipLaunchKernelGGL(kern, grid, blk, smem, s, b);                                     \
+    hipLaunchKernelGGL(kern, grid, blk, smem, s, b.parts, b.C, b.H * b.W, b);            \
   } while (0)
 #define GB_VARIANT(V)                                                                    \
   do {                                                                                   \
