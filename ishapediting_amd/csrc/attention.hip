@@ -67,7 +67,10 @@ __device__ __forceinline__ half4 lds_read_tr4(const half_t* p) {
 // four-wave workgroup per CU (T = 1024, 8 heads: 128 workgroups) every global -> LDS -> MFMA round trip of a tile was
 // exposed; two waves per SIMD on interleaved tiles hide them (T = 1024: 19.9 -> ~11 us).
 template <int D>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const void* h_qkv, void* h_out, float* h_lse, int h_T, int h_C, AttnArgs a0) {
+  // leading scalar parameters are preloaded into SGPRs at dispatch (common.h, IgemmHot); the block `a0` arrives by s_load
+  AttnArgs a = a0;
+  a.qkv = reinterpret_cast<const half_t*>(h_qkv); a.out = reinterpret_cast<half_t*>(h_out); a.lse = h_lse; a.T = h_T; a.C = h_C;
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
   constexpr int VS = D + 16;                 // V row stride: 160-byte rows keep the transposed reads conflict-free
   __shared__ __attribute__((aligned(16))) half_t sK2[2][64 * RS];
@@ -422,7 +425,12 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, int 
 // blockIdx.z = 2 n + role: role 0 = dQ of 64 queries, role 1 = dK/dV of 64 keys (independent of each other, see above)
 // Each workgroup is two teams of four waves on alternating tiles (own staging buffers, shared barriers), merged at the end.
 template <int D>
-__global__ __launch_bounds__(512) void attn_bwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const void* h_qkv, const void* h_out, const void* h_dout, void* h_dqkv, float* h_lse,
+                                                       float* h_Dbuf, int h_T, int h_C, AttnArgs a0) {
+  AttnArgs a = a0;                           // preloaded leading parameters, as in attn_fwd_kernel
+  a.qkv = reinterpret_cast<const half_t*>(h_qkv); a.out = const_cast<half_t*>(reinterpret_cast<const half_t*>(h_out));
+  a.dout = reinterpret_cast<const half_t*>(h_dout); a.dqkv = reinterpret_cast<half_t*>(h_dqkv); a.lse = h_lse; a.Dbuf = h_Dbuf;
+  a.T = h_T; a.C = h_C;
   constexpr int RS = D + 8, DS = D / 16;
   __shared__ __attribute__((aligned(16))) half_t s0[2][64 * RS];
   __shared__ __attribute__((aligned(16))) half_t s1[2][64 * RS];
@@ -442,8 +450,8 @@ static int check_attn(const AttnArgs& a) {
 int attn_forward_launch(const AttnArgs& a, hipStream_t s) {
   ISHAP_TRY(check_attn(a));
   dim3 g(a.T / 64, a.heads, a.N);
-  if (a.d == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, g, dim3(512), 0, s, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<32>, g, dim3(512), 0, s, a);
+  if (a.d == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, g, dim3(512), 0, s, (const void*)a.qkv, (void*)a.out, a.lse, a.T, a.C, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<32>, g, dim3(512), 0, s, (const void*)a.qkv, (void*)a.out, a.lse, a.T, a.C, a);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -452,8 +460,8 @@ int attn_backward_launch(const AttnArgs& a, hipStream_t s) {
   ISHAP_TRY(check_attn(a));
   dim3 g(a.T / 64, a.heads, a.N * 2);
   const dim3 blk(a.T > 64 ? 512 : 256);      // one tile: the second team would have nothing to do
-  if (a.d == 64) hipLaunchKernelGGL(attn_bwd_kernel<64>, g, blk, 0, s, a);
-  else hipLaunchKernelGGL(attn_bwd_kernel<32>, g, blk, 0, s, a);
+  if (a.d == 64) hipLaunchKernelGGL(attn_bwd_kernel<64>, g, blk, 0, s, (const void*)a.qkv, (const void*)a.out, (const void*)a.dout, (void*)a.dqkv, a.lse, a.Dbuf, a.T, a.C, a);
+  else hipLaunchKernelGGL(attn_bwd_kernel<32>, g, blk, 0, s, (const void*)a.qkv, (const void*)a.out, (const void*)a.dout, (void*)a.dqkv, a.lse, a.Dbuf, a.T, a.C, a);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -19,7 +19,12 @@ constexpr int SK_WAVES = 16;
 __device__ __attribute__((aligned(128))) half_t g_zero_line_sk[64];   // zero-initialised: what padded taps read
 
 template <int MT, bool CONV3>
-__global__ __launch_bounds__(SK_WAVES * 64) void igemm_skinny_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(SK_WAVES * 64) void igemm_skinny_kernel(const void* hX, const void* hWt, int hK, int hCin, int hldx, int hldw,
+                                                                     int hH, int hW, int hN, IgemmArgs a0) {
+  // leading scalar parameters are preloaded into SGPRs at dispatch (common.h, IgemmHot): the fragment loads need nothing else
+  IgemmArgs a = a0;
+  a.X = reinterpret_cast<const half_t*>(hX); a.Wt = reinterpret_cast<const half_t*>(hWt);
+  a.K = hK; a.Cin = hCin; a.ldx = hldx; a.ldw = hldw; a.H = hH; a.W = hW; a.N = hN;
   __shared__ f32x4 red[SK_WAVES][MT][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -176,11 +181,15 @@ template <int MT>
 int launch_skinny(const IgemmArgs& a, hipStream_t s) {
   dim3 grid(a.M / (16 * MT), (a.N + 15) / 16);
   if (a.conv3) {
-    if (g_igemm_prof_start) hipExtLaunchKernelGGL((igemm_skinny_kernel<MT, true>), grid, dim3(SK_WAVES * 64), 0, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a);
-    else hipLaunchKernelGGL((igemm_skinny_kernel<MT, true>), grid, dim3(SK_WAVES * 64), 0, s, a);
+    if (g_igemm_prof_start) hipExtLaunchKernelGGL((igemm_skinny_kernel<MT, true>), grid, dim3(SK_WAVES * 64), 0, s, g_igemm_prof_start, g_igemm_prof_stop, 0,
+                                                   (const void*)a.X, (const void*)a.Wt, a.K, a.Cin, a.ldx, a.ldw, a.H, a.W, a.N, a);
+    else hipLaunchKernelGGL((igemm_skinny_kernel<MT, true>), grid, dim3(SK_WAVES * 64), 0, s, (const void*)a.X, (const void*)a.Wt, a.K, a.Cin, a.ldx,
+                            a.ldw, a.H, a.W, a.N, a);
   } else {
-    if (g_igemm_prof_start) hipExtLaunchKernelGGL((igemm_skinny_kernel<MT, false>), grid, dim3(SK_WAVES * 64), 0, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a);
-    else hipLaunchKernelGGL((igemm_skinny_kernel<MT, false>), grid, dim3(SK_WAVES * 64), 0, s, a);
+    if (g_igemm_prof_start) hipExtLaunchKernelGGL((igemm_skinny_kernel<MT, false>), grid, dim3(SK_WAVES * 64), 0, s, g_igemm_prof_start, g_igemm_prof_stop, 0,
+                                                   (const void*)a.X, (const void*)a.Wt, a.K, a.Cin, a.ldx, a.ldw, a.H, a.W, a.N, a);
+    else hipLaunchKernelGGL((igemm_skinny_kernel<MT, false>), grid, dim3(SK_WAVES * 64), 0, s, (const void*)a.X, (const void*)a.Wt, a.K, a.Cin, a.ldx,
+                            a.ldw, a.H, a.W, a.N, a);
   }
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;

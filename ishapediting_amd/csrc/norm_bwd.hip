@@ -87,23 +87,24 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnBwdArgs a, int ro
 }
 
 template <bool FILM, bool ACT>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
-  if ((int)blockIdx.x >= a.main_blocks) {          // prefetch workgroups: the next convolution's weights (common.h)
-    prefetch_block(a.pf, blockIdx.x - a.main_blocks, gridDim.x - a.main_blocks);
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const long long* h_csums, int h_main_blocks, int h_C, int h_H, int h_W, int h_N, GnBwdArgs a) {
+  // h_*: preloaded copies of h_csums, h_main_blocks, h_C, h_H, h_W, h_N (see gn_apply_kernel)
+  if ((int)blockIdx.x >= h_main_blocks) {          // prefetch workgroups: the next convolution's weights (common.h)
+    prefetch_block(a.pf, blockIdx.x - h_main_blocks, gridDim.x - h_main_blocks);
     return;
   }
-  const int CV = a.C >> 3, HW = a.H * a.W, cpg = a.C / 32;
-  const long long total = (long long)a.N * HW * CV;
+  const int CV = h_C >> 3, HW = h_H * h_W, cpg = h_C / 32;
+  const long long total = (long long)h_N * HW * CV;
   // group means of dyh and dyh*xh from the per-channel sums (8 lanes per (image, group))
   __shared__ float sh_m[16 * 32 * 2];
   {
     const float cnt = (float)HW * (float)cpg;
-    for (int idx = threadIdx.x; idx < a.N * 32 * 8; idx += 256) {
+    for (int idx = threadIdx.x; idx < h_N * 32 * 8; idx += 256) {
       const int part = idx & 7, g = (idx >> 3) & 31, n = idx >> 8;
       float s1 = 0.f, s2 = 0.f;
       for (int c = g * cpg + part; c < (g + 1) * cpg; c += 8) {
-        s1 += (float)a.csums[((long long)n * a.C + c) * 2] * (1.f / STAT_SCALE_SUM);
-        s2 += (float)a.csums[((long long)n * a.C + c) * 2 + 1] * (1.f / STAT_SCALE_SUM);
+        s1 += (float)h_csums[((long long)n * h_C + c) * 2] * (1.f / STAT_SCALE_SUM);
+        s2 += (float)h_csums[((long long)n * h_C + c) * 2 + 1] * (1.f / STAT_SCALE_SUM);
       }
       s1 = lanes8_sum(s1);
       s2 = lanes8_sum(s2);
@@ -113,16 +114,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
   }
   // thread count is a multiple of CV (launcher): one 8-channel vector per thread, parameters loaded once per image
   const long long tg = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long nth = (long long)a.main_blocks * blockDim.x;
+  const long long nth = (long long)h_main_blocks * blockDim.x;
   const int cv = (int)(tg % CV), c0 = cv * 8;
-  const long long pstep = nth / CV, npix = (long long)a.N * HW;
+  const long long pstep = nth / CV, npix = (long long)h_N * HW;
   float gam[8], bet[8], mu[8], rs[8], esc[8], esh[8], m1[8], m2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { gam[i] = a.gamma[c0 + i]; bet[i] = (FILM || ACT) ? a.beta[c0 + i] : 0.f; esc[i] = 0.f; esh[i] = 0.f; }
   int cur_n = -1;
   for (long long pix = tg / CV; pix < npix; pix += pstep) {
     const int n = (int)(pix / HW), p = (int)(pix % HW);
-    const int y = p / a.W, x = p % a.W;
+    const int y = p / h_W, x = p % h_W;
     if (n != cur_n) {
       cur_n = n;
 #pragma unroll
@@ -132,28 +133,28 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
         rs[i] = a.stats[(n * 32 + g) * 2 + 1];
         m1[i] = sh_m[(n * 32 + g) * 2];
         m2[i] = sh_m[(n * 32 + g) * 2 + 1];
-        if (FILM) { esc[i] = a.emb[(long long)n * a.emb_ld + c]; esh[i] = a.emb[(long long)n * a.emb_ld + a.C + c]; }
+        if (FILM) { esc[i] = a.emb[(long long)n * a.emb_ld + c]; esh[i] = a.emb[(long long)n * a.emb_ld + h_C + c]; }
       }
     }
     float up[8], ad[8];
-    load_upstream(a.g, a.gmode, n, y, x, a.H, a.W, a.C, c0, up);
-    const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.C + c0);
-    if (a.add) load_upstream(a.add, a.gmode, n, y, x, a.H, a.W, a.C, c0, ad);
+    load_upstream(a.g, a.gmode, n, y, x, h_H, h_W, h_C, c0, up);
+    const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * h_C + c0);
+    if (a.add) load_upstream(a.add, a.gmode, n, y, x, h_H, h_W, h_C, c0, ad);
     half8 a2 = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (a.add2) a2 = *reinterpret_cast<const half8*>(a.add2 + pix * a.C + c0);
+    if (a.add2) a2 = *reinterpret_cast<const half8*>(a.add2 + pix * h_C + c0);
     half8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float dyh, xh;
       gn_bwd_term(up[i], (float)xv[i], mu[i], rs[i], gam[i], bet[i], esc[i], esh[i], FILM, ACT, dyh, xh);
-      float v = rs[i] * (dyh - m1[i] - xh * m2[i]);
+      float v = gn_bwd_dx(rs[i], dyh, xh, m1[i], m2[i]);
       if (a.add) v += ad[i];
       if (a.add2) v = (float)(half_t)v + (float)a2[i];      // same rounding as a separate fp16 add of the two gradient maps
       o[i] = (half_t)v;
     }
-    if (a.csplit == 0) *reinterpret_cast<half8*>(a.dx + pix * a.C + c0) = o;
+    if (a.csplit == 0) *reinterpret_cast<half8*>(a.dx + pix * h_C + c0) = o;
     else if (c0 < a.csplit) *reinterpret_cast<half8*>(a.dx + pix * a.csplit + c0) = o;
-    else *reinterpret_cast<half8*>(a.dx2 + pix * (a.C - a.csplit) + (c0 - a.csplit)) = o;
+    else *reinterpret_cast<half8*>(a.dx2 + pix * (h_C - a.csplit) + (c0 - a.csplit)) = o;
   }
 }
 
@@ -179,7 +180,8 @@ int gn_backward_launch(const GnBwdArgs& a, hipStream_t s) {
   do {                                                                                                              \
     if (!a.sums_ready)                                                                                              \
       hipLaunchKernelGGL((gn_bwd_partial_kernel<F, A>), dim3(nblk, a.N), dim3(256), smem, s, a, rpb);               \
-    hipLaunchKernelGGL((gn_bwd_apply_kernel<F, A>), dim3(grid_apply), dim3(256), 0, s, a2);                         \
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<F, A>), dim3(grid_apply), dim3(256), 0, s, (const long long*)a2.csums,   \
+                       a2.main_blocks, a2.C, a2.H, a2.W, a2.N, a2);                                               \
   } while (0)
   if (a.film) GB_LAUNCH(true, true);
   else if (a.act) GB_LAUNCH(false, true);

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(int h_parts, int h_C
     if (u == (int)threadIdx.x) {                   // the first unit: everything is in registers already
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        float v = rs * (f_dyh[i] - m1 - f_xh[i] * m2);
+        float v = gn_bwd_dx(rs, f_dyh[i], f_xh[i], m1, m2);
         if (a.add) v += f_ad[i];
         if (a.add2) v = rh(v) + f_a2[i];                                 // same rounding as a separate fp16 add of the two maps
         o[i] = v;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(int h_parts, int h_C
       gn_bwd_term(up[i], xv[i], mu, rs, a.gamma[c + i], (FILM || ACT) ? a.beta[c + i] : 0.f,
                   FILM ? a.emb[(long long)n * a.emb_ld + c + i] : 0.f, FILM ? a.emb[(long long)n * a.emb_ld + C + c + i] : 0.f,
                   FILM, ACT, dyh, xh);
-      float v = rs * (dyh - m1 - xh * m2);
+      float v = gn_bwd_dx(rs, dyh, xh, m1, m2);
       if (a.add) v += ad[i];
       if (a.add2) v = rh(v) + a2[i];                                   // same rounding as a separate fp16 add of the two maps
       o[i] = v;
