@@ -114,30 +114,32 @@ __device__ __forceinline__ float rh(float v) { return (float)(half_t)v; }   // r
 //  POOL: output pixel = mean of the 2x2 activated input pixels; also writes pooled raw x to xpool
 //  SPLIT: fp32-grade output for the fp32 head: writes [hi | lo | hi] fp16 channel blocks (3*C wide)
 template <bool FILM, bool ACT, bool POOL, bool SPLIT>
-__global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
-  if ((int)blockIdx.x >= a.main_blocks) {          // prefetch workgroups: the next convolution's weights (common.h)
-    prefetch_block(a.pf, blockIdx.x - a.main_blocks, gridDim.x - a.main_blocks);
+__global__ __launch_bounds__(256) void gn_apply_kernel(int h_main_blocks, int h_C, int h_H, int h_W, int h_N, GnApplyArgs a) {
+  // h_*: copies of h_main_blocks, h_C, h_H, h_W, h_N as leading scalar parameters, preloaded into SGPRs at dispatch
+  // (common.h, IgemmHot): the index arithmetic runs under the s_load of `a`
+  if ((int)blockIdx.x >= h_main_blocks) {          // prefetch workgroups: the next convolution's weights (common.h)
+    prefetch_block(a.pf, blockIdx.x - h_main_blocks, gridDim.x - h_main_blocks);
     return;
   }
-  const int CV = a.C >> 3;
-  const int HWo = POOL ? (a.H >> 1) * (a.W >> 1) : a.H * a.W;
-  const long long total = (long long)a.N * HWo * CV;
-  const int cpg = a.C / 32;
+  const int CV = h_C >> 3;
+  const int HWo = POOL ? (h_H >> 1) * (h_W >> 1) : h_H * h_W;
+  const long long total = (long long)h_N * HWo * CV;
+  const int cpg = h_C / 32;
   // statistics: either finalised already (a.stats) or finalised here from the producer's per-channel sums:
   // 8 lanes per (image, group) add up the group's channels, then mean / rstd (gd/nn.py:16-18, eps 1e-5)
   __shared__ float sh_stats[16 * 32 * 2];
   const float* stats = a.stats;
   if (a.sums) {
-    const float cnt = (float)(a.H * a.W) * (float)cpg;
-    for (int idx = threadIdx.x; idx < a.N * 32 * 8; idx += 256) {
+    const float cnt = (float)(h_H * h_W) * (float)cpg;
+    for (int idx = threadIdx.x; idx < h_N * 32 * 8; idx += 256) {
       const int part = idx & 7, g = (idx >> 3) & 31, n = idx >> 8;
       // exact integer adds of the fixed-point channel sums, then mean / variance in double: the one-pass
       // E[x^2] - E[x]^2 cancels badly in fp32 once |mean| >> std (gn_finalize_kernel does the same arithmetic)
       long long si = 0, qi = 0;
       for (int c = g * cpg + part; c < (g + 1) * cpg; c += 8) {
-        const long long* sp = a.sums + ((long long)n * a.C + c) * 2;
+        const long long* sp = a.sums + ((long long)n * h_C + c) * 2;
         if (a.x2) sp = c < a.csplit ? a.sums + ((long long)n * a.csplit + c) * 2
-                                    : a.sums2 + ((long long)n * (a.C - a.csplit) + (c - a.csplit)) * 2;
+                                    : a.sums2 + ((long long)n * (h_C - a.csplit) + (c - a.csplit)) * 2;
         si += sp[0];
         qi += sp[1];
       }
@@ -163,9 +165,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
   // The launcher makes the thread count a multiple of CV, so a thread keeps ONE 8-channel vector for all its pixels:
   // gamma/beta are loaded once, the per-image values (mean, rstd, FiLM) only when the image changes.
   const long long tg = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long nth = (long long)a.main_blocks * blockDim.x;
+  const long long nth = (long long)h_main_blocks * blockDim.x;
   const int cv = (int)(tg % CV), c0 = cv * 8;
-  const long long pstep = nth / CV, npix = (long long)a.N * HWo;
+  const long long pstep = nth / CV, npix = (long long)h_N * HWo;
   float gam[8], bet[8], mu[8], rs[8], sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { gam[i] = a.gamma[c0 + i]; bet[i] = a.beta[c0 + i]; }
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
         rs[i] = stats[(n * 32 + g) * 2 + 1];
         if (FILM) {
           sc[i] = rh(1.f + rh(a.emb[(long long)n * a.emb_ld + c]));
-          sh[i] = rh(a.emb[(long long)n * a.emb_ld + a.C + c]);
+          sh[i] = rh(a.emb[(long long)n * a.emb_ld + h_C + c]);
         }
       }
     }
@@ -198,15 +200,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
     };
     float o[8];
     if (POOL) {
-      const int Wo = a.W >> 1;
+      const int Wo = h_W >> 1;
       const int yo = p / Wo, xo = p % Wo;
       float acc[8], xacc[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) { acc[i] = 0.f; xacc[i] = 0.f; }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        long long src = (long long)n * a.H * a.W + (2 * yo + (q >> 1)) * a.W + 2 * xo + (q & 1);
-        half8 v = *reinterpret_cast<const half8*>(a.x + src * a.C + c0);
+        long long src = (long long)n * h_H * h_W + (2 * yo + (q >> 1)) * h_W + 2 * xo + (q & 1);
+        half8 v = *reinterpret_cast<const half8*>(a.x + src * h_C + c0);
         float t[8];
         one(v, t);
 #pragma unroll
@@ -215,31 +217,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
       half8 ov, xv;
 #pragma unroll
       for (int i = 0; i < 8; ++i) { ov[i] = (half_t)(acc[i] * 0.25f); xv[i] = (half_t)(xacc[i] * 0.25f); }
-      *reinterpret_cast<half8*>(a.out + pix * a.C + c0) = ov;
-      if (a.xpool) *reinterpret_cast<half8*>(a.xpool + pix * a.C + c0) = xv;
+      *reinterpret_cast<half8*>(a.out + pix * h_C + c0) = ov;
+      if (a.xpool) *reinterpret_cast<half8*>(a.xpool + pix * h_C + c0) = xv;
     } else {
       half8 v;
       if (a.x2) {                                   // two-source input (skip concatenation); also emit the raw copy
         v = c0 < a.csplit ? *reinterpret_cast<const half8*>(a.x + pix * a.csplit + c0)
-                          : *reinterpret_cast<const half8*>(a.x2 + pix * (a.C - a.csplit) + (c0 - a.csplit));
-        *reinterpret_cast<half8*>(a.xcopy + pix * a.C + c0) = v;
+                          : *reinterpret_cast<const half8*>(a.x2 + pix * (h_C - a.csplit) + (c0 - a.csplit));
+        *reinterpret_cast<half8*>(a.xcopy + pix * h_C + c0) = v;
       } else {
-        v = *reinterpret_cast<const half8*>(a.x + pix * a.C + c0);
+        v = *reinterpret_cast<const half8*>(a.x + pix * h_C + c0);
       }
       one(v, o);
       if (SPLIT) {
         half8 hi, lo;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { hi[i] = (half_t)o[i]; lo[i] = (half_t)(o[i] - (float)hi[i]); }
-        half_t* dst = a.out + pix * (3LL * a.C);
+        half_t* dst = a.out + pix * (3LL * h_C);
         *reinterpret_cast<half8*>(dst + c0) = hi;
-        *reinterpret_cast<half8*>(dst + a.C + c0) = lo;
-        *reinterpret_cast<half8*>(dst + 2 * a.C + c0) = hi;
+        *reinterpret_cast<half8*>(dst + h_C + c0) = lo;
+        *reinterpret_cast<half8*>(dst + 2 * h_C + c0) = hi;
       } else {
         half8 ov;
 #pragma unroll
         for (int i = 0; i < 8; ++i) ov[i] = (half_t)o[i];
-        *reinterpret_cast<half8*>(a.out + pix * a.C + c0) = ov;
+        *reinterpret_cast<half8*>(a.out + pix * h_C + c0) = ov;
       }
     }
   }
@@ -263,11 +265,11 @@ int gn_apply_launch(const GnApplyArgs& a, hipStream_t s) {
   GnApplyArgs a2 = a;
   a2.main_blocks = blocks;
   dim3 g(blocks + (pf_on ? prefetch_blocks(a.pf, 256) : 0)), b(256);
-  if (a.split) hipLaunchKernelGGL((gn_apply_kernel<false, true, false, true>), g, b, 0, s, a2);
-  else if (a.pool) hipLaunchKernelGGL((gn_apply_kernel<false, true, true, false>), g, b, 0, s, a2);
-  else if (a.film) hipLaunchKernelGGL((gn_apply_kernel<true, true, false, false>), g, b, 0, s, a2);
-  else if (a.act) hipLaunchKernelGGL((gn_apply_kernel<false, true, false, false>), g, b, 0, s, a2);
-  else hipLaunchKernelGGL((gn_apply_kernel<false, false, false, false>), g, b, 0, s, a2);
+  if (a.split) hipLaunchKernelGGL((gn_apply_kernel<false, true, false, true>), g, b, 0, s, a2.main_blocks, a2.C, a2.H, a2.W, a2.N, a2);
+  else if (a.pool) hipLaunchKernelGGL((gn_apply_kernel<false, true, true, false>), g, b, 0, s, a2.main_blocks, a2.C, a2.H, a2.W, a2.N, a2);
+  else if (a.film) hipLaunchKernelGGL((gn_apply_kernel<true, true, false, false>), g, b, 0, s, a2.main_blocks, a2.C, a2.H, a2.W, a2.N, a2);
+  else if (a.act) hipLaunchKernelGGL((gn_apply_kernel<false, true, false, false>), g, b, 0, s, a2.main_blocks, a2.C, a2.H, a2.W, a2.N, a2);
+  else hipLaunchKernelGGL((gn_apply_kernel<false, false, false, false>), g, b, 0, s, a2.main_blocks, a2.C, a2.H, a2.W, a2.N, a2);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
