@@ -52,7 +52,10 @@ __device__ __forceinline__ int s3_swz(int chunk, int hp, int CH) {
 
 // SPC = 64-channel sub-blocks per staged chunk (CH / 64): the K-steps a consumer wave owns in one chunk
 template <int SPC>
-__global__ __launch_bounds__(S3_THREADS) void conv3_small_kernel(IgemmArgs a, S3Geom geo) {
+__global__ __launch_bounds__(S3_THREADS) void conv3_small_kernel(const void* hX, const void* hWt, int hH, int hW, int hCin, int hldx, int hldw, int hTH,
+                                                                 int hslot_bytes, int hninstr, int hwshift, IgemmArgs a, S3Geom geo) {
+  // h*: copies of the fields X, Wt, H, W, Cin, ldx, ldw of `a` and TH, slot_bytes, ninstr, w_shift of `geo` as leading scalar
+  // parameters, preloaded into SGPRs at dispatch (common.h, IgemmHot): the index arithmetic runs under the s_load of the blocks
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int MT = 4;
   constexpr int CH = SPC * 64;
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(S3_THREADS) void conv3_small_kernel(IgemmArgs a, S3
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool loader = wave >= S3_CONS;
   const int g = lane >> 4, col = lane & 15;
-  const int W = a.W, H = a.H, HW = H * W;
+  const int W = hW, H = hH, HW = H * W;
   // XCD-aware order: the pixel tiles that stream the same weight rows run next to each other on one XCD (shared L2)
   int tile_m, tile_n;
   {
@@ -73,19 +76,19 @@ __global__ __launch_bounds__(S3_THREADS) void conv3_small_kernel(IgemmArgs a, S3
     tile_m = swz % nx;
     tile_n = swz / nx;
   }
-  const int tiles_per_img = H / geo.TH;
+  const int tiles_per_img = H / hTH;
   const int n_img = tile_m / tiles_per_img;
-  const int row0 = (tile_m - n_img * tiles_per_img) * geo.TH;      // first image row of the tile
+  const int row0 = (tile_m - n_img * tiles_per_img) * hTH;      // first image row of the tile
   const int m0 = tile_m * 64;                                      // first output row (NHWC pixel index)
   const int n0 = tile_n * 16;
-  const int nch9 = a.Cin / CH;
+  const int nch9 = hCin / CH;
   const int slice = blockIdx.z;
   const int c_lo = geo.cut[slice], c_hi = geo.cut[slice + 1];      // this workgroup's chunks (global chunk numbers)
   const int nl = c_hi - c_lo;                                      // ring slots are indexed by the local number c - c_lo
   const int c9_hi = c_hi < nch9 ? c_hi : nch9;                     // 9-tap chunks: [c_lo, c9_hi); 1-tap: [max(c_lo, nch9), c_hi)
   const int c1_lo = (c_lo > nch9 ? c_lo : nch9) - nch9, c1_hi = c_hi - nch9;
   char* ring = smem_raw;
-  const int zero_off = S3_SLOTS * geo.slot_bytes;                  // 64 zero bytes behind the ring
+  const int zero_off = S3_SLOTS * hslot_bytes;                  // 64 zero bytes behind the ring
 
   f32x4 acc[MT];
 #pragma unroll
@@ -104,18 +107,18 @@ __global__ __launch_bounds__(S3_THREADS) void conv3_small_kernel(IgemmArgs a, S3
     const int lane_pix = lane_byte >> rb_shift;                        // pixel within the instruction's 1 KiB
     const int pc = (lane_byte & (row_bytes - 1)) >> 4;                 // physical 16-byte chunk within the pixel row
     constexpr int ppi = 1024 >> rb_shift;                              // pixels per instruction
-    const int mine = (geo.ninstr - lw + S3_LOAD - 1) / S3_LOAD;        // instructions of this wave per chunk
+    const int mine = (hninstr - lw + S3_LOAD - 1) / S3_LOAD;        // instructions of this wave per chunk
     auto issue = [&](int l) {
       const int c = c_lo + l;
-      char* slot = ring + (l % S3_SLOTS) * geo.slot_bytes;
+      char* slot = ring + (l % S3_SLOTS) * hslot_bytes;
       const bool one = c >= nch9;                      // a chunk of the folded 1x1 source
-      const half_t* base = one ? a.X2 : a.X;
-      const int ld = one ? a.ldx2 : a.ldx;
+      const half_t* base = one ? a.X2 : reinterpret_cast<const half_t*>(hX);
+      const int ld = one ? a.ldx2 : hldx;
       const int c0 = (one ? c - nch9 : c) * CH;
       const bool ups = !one && a.ups;
-      for (int i = lw; i < geo.ninstr; i += S3_LOAD) {
+      for (int i = lw; i < hninstr; i += S3_LOAD) {
         const int hp = i * ppi + lane_pix;
-        const int hy = hp >> geo.w_shift, x = hp & (W - 1);
+        const int hy = hp >> hwshift, x = hp & (W - 1);
         const int y = row0 + hy - 1;
         const bool ok = y >= 0 && y < H;
         const int sc = s3_swz(pc, hp, CH);
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(S3_THREADS) void conv3_small_kernel(IgemmArgs a, S3
     const int tap = wave;
     struct WFrag { half8 w[2]; };
     WFrag ringw[S3_RING];
-    const half_t* wbase = a.Wt + (long long)(n0 + col) * a.ldw + 8 * g;
+    const half_t* wbase = reinterpret_cast<const half_t*>(hWt) + (long long)(n0 + col) * hldw + 8 * g;
     const half_t* zbase = g_zero_line_s3 + 8 * g;
     // LDS byte offset (and swizzle key) of this lane's staged pixel for each 16-pixel sub-tile, at this wave's tap and at
     // the centre tap; a column outside the image reads the zero chunk instead
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(S3_THREADS) void conv3_small_kernel(IgemmArgs a, S3
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int p = j * 16 + col;
-        const int ty = p >> geo.w_shift, tx = p & (W - 1);
+        const int ty = p >> hwshift, tx = p & (W - 1);
         const int hc = (ty + 1) * W + tx, hp = hc + dy * W + dx;
         xz[j] = tx + dx < 0 || tx + dx >= W;
         xoff[j] = hp * (CH * 2); xkey[j] = hp;
@@ -208,14 +211,14 @@ __global__ __launch_bounds__(S3_THREADS) void conv3_small_kernel(IgemmArgs a, S3
 #ifdef S3_ABL_NOW       // (harness ablation: no weight stream)
       wload(zbase, f);
 #else
-      wload(c < c9_hi ? wbase + (long long)tap * a.Cin + (long long)c * CH + sub * 64 : zbase, f);
+      wload(c < c9_hi ? wbase + (long long)tap * hCin + (long long)c * CH + sub * 64 : zbase, f);
 #endif
     };
     auto chunk9 = [&](int c, auto first) {
       constexpr int R0 = decltype(first)::value;       // first ring register set of this chunk
       __builtin_amdgcn_s_barrier();                    // B(c)
       asm volatile("" ::: "memory");
-      const char* slot = ring + ((c - c_lo) % S3_SLOTS) * geo.slot_bytes;
+      const char* slot = ring + ((c - c_lo) % S3_SLOTS) * hslot_bytes;
 #pragma unroll
       for (int sub = 0; sub < SPC; ++sub) {
         wwait(ringw[R0 + sub], std::integral_constant<int, (S3_RING - 1) * 2>{});
@@ -248,12 +251,12 @@ __global__ __launch_bounds__(S3_THREADS) void conv3_small_kernel(IgemmArgs a, S3
       const bool own1 = wave < SPC;
       const int sub1 = own1 ? wave : 0;
       auto load1 = [&](int c1, WFrag& f) {
-        wload((own1 && c1 < c1_hi) ? wbase + (long long)9 * a.Cin + (long long)c1 * CH + sub1 * 64 : zbase, f);
+        wload((own1 && c1 < c1_hi) ? wbase + (long long)9 * hCin + (long long)c1 * CH + sub1 * 64 : zbase, f);
       };
       auto chunk1 = [&](int c1, WFrag& f) {
         __builtin_amdgcn_s_barrier();                  // B(nch9 + c1)
         asm volatile("" ::: "memory");
-        const char* slot = ring + ((nch9 + c1 - c_lo) % S3_SLOTS) * geo.slot_bytes;
+        const char* slot = ring + ((nch9 + c1 - c_lo) % S3_SLOTS) * hslot_bytes;
         wwait(f, std::integral_constant<int, 2>{});
         step(slot, xoff1, xkey1, false, sub1, f);
         __builtin_amdgcn_sched_barrier(0);
@@ -386,8 +389,10 @@ int launch_s3(const IgemmArgs& a, const S3Geom& geo, hipStream_t s) {
   auto kern = conv3_small_kernel<SPC>;
   ISHAP_TRY(ishap_set_max_lds((const void*)kern, 160 * 1024));
   dim3 grid(a.M / 64, (a.N + 15) / 16, geo.nslice);
-  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(S3_THREADS), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a, geo);
-  else hipLaunchKernelGGL(kern, grid, dim3(S3_THREADS), smem, s, a, geo);
+  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(S3_THREADS), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0,
+                                                (const void*)a.X, (const void*)a.Wt, a.H, a.W, a.Cin, a.ldx, a.ldw, geo.TH, geo.slot_bytes, geo.ninstr, geo.w_shift, a, geo);
+  else hipLaunchKernelGGL(kern, grid, dim3(S3_THREADS), smem, s, (const void*)a.X, (const void*)a.Wt, a.H, a.W, a.Cin, a.ldx, a.ldw, geo.TH,
+                          geo.slot_bytes, geo.ninstr, geo.w_shift, a, geo);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
