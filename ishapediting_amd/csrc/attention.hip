@@ -66,19 +66,24 @@ __device__ __forceinline__ half4 lds_read_tr4(const half_t* p) {
 // staging buffers, the same barriers) and the two online-softmax states are merged through LDS at the end.  With one
 // four-wave workgroup per CU (T = 1024, 8 heads: 128 workgroups) every global -> LDS -> MFMA round trip of a tile was
 // exposed; two waves per SIMD on interleaved tiles hide them (T = 1024: 19.9 -> ~11 us).
-template <int D>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(const void* h_qkv, void* h_out, float* h_lse, int h_T, int h_C, AttnArgs a0) {
+// TEAMS = 2 or 4 (round 3: four teams = 1024 threads when the sequence has >= 8 key tiles, so that a team walks T / 256 of them)
+template <int D, int TEAMS>
+__global__ __launch_bounds__(256 * TEAMS) void attn_fwd_kernel(const void* h_qkv, void* h_out, float* h_lse, int h_T, int h_C, AttnArgs a0) {
   // leading scalar parameters are preloaded into SGPRs at dispatch (common.h, IgemmHot); the block `a0` arrives by s_load
   AttnArgs a = a0;
   a.qkv = reinterpret_cast<const half_t*>(h_qkv); a.out = reinterpret_cast<half_t*>(h_out); a.lse = h_lse; a.T = h_T; a.C = h_C;
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
   constexpr int VS = D + 16;                 // V row stride: 160-byte rows keep the transposed reads conflict-free
-  __shared__ __attribute__((aligned(16))) half_t sK2[2][64 * RS];
-  __shared__ __attribute__((aligned(16))) half_t sV2[2][64 * VS];
-  __shared__ float mrg[256][DS * 4 + 2];
+  constexpr int MRG = DS * 4 + 2;            // floats of one lane's online-softmax state
+  // dynamic LDS: [TEAMS] K tiles, [TEAMS] V tiles; after the key loop the same memory holds the states of teams 1 .. TEAMS-1
+  extern __shared__ __attribute__((aligned(16))) char attn_smem[];
+  half_t* const sK2 = reinterpret_cast<half_t*>(attn_smem);
+  half_t* const sV2 = sK2 + TEAMS * 64 * RS;
+  float* const mrg = reinterpret_cast<float*>(attn_smem);
+  static_assert((TEAMS - 1) * 256 * MRG * 4 <= TEAMS * 64 * (RS + VS) * 2, "merge states alias the tile buffers");
   const int team = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-  half_t* const sK = sK2[team];
-  half_t* const sV = sV2[team];
+  half_t* const sK = sK2 + team * 64 * RS;
+  half_t* const sV = sV2 + team * 64 * VS;
   const int q0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
   const int ld = 3 * a.C;
   const int g = lane >> 4, col = lane & 15;
@@ -92,21 +97,21 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const void* h_qkv, void* 
 #pragma unroll
   for (int i = 0; i < DS; ++i) ot[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   TileRegs<D> rk, rv;
-  const int ntile = a.T / 64, niter = (ntile + 1) / 2;       // the same barrier count for both teams
+  const int ntile = a.T / 64, niter = (ntile + TEAMS - 1) / TEAMS;       // the same barrier count for every team
   if (team < ntile) {
     load_tile<D>(base + (long long)(team * 64) * ld + D, ld, rk, tid);
     load_tile<D>(base + (long long)(team * 64) * ld + 2 * D, ld, rv, tid);
   }
   for (int it = 0; it < niter; ++it) {
-    const int kt = (2 * it + team) * 64;
+    const int kt = (TEAMS * it + team) * 64;
     const bool live = kt < a.T;
     __syncthreads();
     if (live) {
       store_tile<D>(rk, sK, tid);
       store_tile<D, VS>(rv, sV, tid);
-      if (kt + 128 < a.T) {
-        load_tile<D>(base + (long long)(kt + 128) * ld + D, ld, rk, tid);
-        load_tile<D>(base + (long long)(kt + 128) * ld + 2 * D, ld, rv, tid);
+      if (kt + TEAMS * 64 < a.T) {
+        load_tile<D>(base + (long long)(kt + TEAMS * 64) * ld + D, ld, rk, tid);
+        load_tile<D>(base + (long long)(kt + TEAMS * 64) * ld + 2 * D, ld, rv, tid);
       }
     }
     __syncthreads();
@@ -155,26 +160,30 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const void* h_qkv, void* 
       }
     }
   }
-  // merge the two teams' states (team 1 -> LDS -> team 0): m' = max, sums rescaled by exp(m - m')
-  if (team == 1) {
-    mrg[tid][0] = m;
-    mrg[tid][1] = lsum;
+  // merge the teams' states (teams 1 .. -> LDS -> team 0, in team order): m' = max, sums rescaled by exp(m - m')
+  __syncthreads();                           // every team is done with its tiles: the states go where the tiles were
+  if (team > 0) {
+    float* dst = mrg + ((team - 1) * 256 + tid) * MRG;
+    dst[0] = m;
+    dst[1] = lsum;
 #pragma unroll
     for (int i = 0; i < DS; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mrg[tid][2 + i * 4 + r] = ot[i][r];
+      for (int r = 0; r < 4; ++r) dst[2 + i * 4 + r] = ot[i][r];
   }
   __syncthreads();
-  if (team == 1) return;
-  {
-    const float m1 = mrg[tid][0], l1 = mrg[tid][1];
+  if (team > 0) return;
+#pragma unroll
+  for (int t = 1; t < TEAMS; ++t) {
+    const float* src = mrg + ((t - 1) * 256 + tid) * MRG;
+    const float m1 = src[0], l1 = src[1];
     const float mn = fmaxf(m, m1);
     const float c0 = __expf(m - mn), c1 = __expf(m1 - mn);
     lsum = lsum * c0 + l1 * c1;
 #pragma unroll
     for (int i = 0; i < DS; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ot[i][r] = ot[i][r] * c0 + mrg[tid][2 + i * 4 + r] * c1;
+      for (int r = 0; r < 4; ++r) ot[i][r] = ot[i][r] * c0 + src[2 + i * 4 + r] * c1;
     m = mn;
   }
   const int q = q0 + wave * 16 + col;
@@ -450,8 +459,20 @@ static int check_attn(const AttnArgs& a) {
 int attn_forward_launch(const AttnArgs& a, hipStream_t s) {
   ISHAP_TRY(check_attn(a));
   dim3 g(a.T / 64, a.heads, a.N);
-  if (a.d == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, g, dim3(512), 0, s, (const void*)a.qkv, (void*)a.out, a.lse, a.T, a.C, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<32>, g, dim3(512), 0, s, (const void*)a.qkv, (void*)a.out, a.lse, a.T, a.C, a);
+  // four teams once a team of two would walk >= 4 key tiles (ISHAP_ATTN_TEAMS=2 keeps two; =4 forces four from 4 tiles on)
+  static const int teams_env = [] { const char* e = getenv("ISHAP_ATTN_TEAMS"); return e ? atoi(e) : 0; }();
+  const int ntile = a.T / 64;
+  const bool four = teams_env == 2 ? false : (teams_env == 4 ? ntile >= 4 : ntile >= 8);
+#define ATTN_FWD(Dv, TM)                                                                                          \
+  do {                                                                                                            \
+    auto kern = attn_fwd_kernel<Dv, TM>;                                                                          \
+    const int smem = TM * 64 * ((Dv + 8) + (Dv + 16)) * (int)sizeof(half_t);                                      \
+    ISHAP_TRY(ishap_set_max_lds((const void*)kern, smem));                                                        \
+    hipLaunchKernelGGL(kern, g, dim3(256 * TM), smem, s, (const void*)a.qkv, (void*)a.out, a.lse, a.T, a.C, a);    \
+  } while (0)
+  if (a.d == 64) { if (four) ATTN_FWD(64, 4); else ATTN_FWD(64, 2); }
+  else { if (four) ATTN_FWD(32, 4); else ATTN_FWD(32, 2); }
+#undef ATTN_FWD
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
