@@ -160,10 +160,11 @@ def visible_gpu_count():
     return n
 
 
-def c2_generate_leg(device, steps=1000):
-    """BASELINE.json configs[1] (C2) once at batch 1: the full `steps`-step DDPM sample of the 421M-parameter model
-    (generate.py --num_steps 1000), the 256^3 decode and marching cubes + 10 smoothing sweeps.  Reported next to the
-    headline (extra keys), never part of `value`."""
+def c2_generate_leg(device, steps=1000, batch=1):
+    """BASELINE.json configs[1] (C2) once at batch `batch` (1, and 8 = generate.py's default batch_size,
+    image_sample.py:173-184): the full `steps`-step DDPM sample of the 421M-parameter model (generate.py --num_steps 1000),
+    the 256^3 decode and marching cubes + 10 smoothing sweeps of every sample.  Reported next to the headline (extra keys),
+    never part of `value`."""
     from ishapediting_amd import synthetic
     from ishapediting_amd.gaussian_diffusion import create_gaussian_diffusion
     from ishapediting_amd.mesh import extract_surface, smooth_mesh
@@ -171,13 +172,13 @@ def c2_generate_leg(device, steps=1000):
     from ishapediting_amd.unet import UNetModel
     from ishapediting_amd.unet_spec import full_config
     cfg = full_config()
-    model = UNetModel(cfg, device, max_batch=1)
+    model = UNetModel(cfg, device, max_batch=batch)
     model.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 1234)))
     dec = MultiTriplane(1, device=device)
     dec.net.load_state_dict(synthetic.decoder_state_dict(4321))
     diff = create_gaussian_diffusion(timestep_respacing=str(steps))
     g = torch.Generator(device="cpu").manual_seed(5)
-    noise = torch.randn((1, 96, 128, 128), generator=g).to(device)
+    noise = torch.randn((batch, 96, 128, 128), generator=g).to(device)
     warm = create_gaussian_diffusion(timestep_respacing="4")
     warm.p_sample_loop(model, noise.shape, noise=noise, device=device)        # kernels loaded, allocator warm
     torch.cuda.synchronize()
@@ -185,19 +186,126 @@ def c2_generate_leg(device, steps=1000):
     sample = diff.p_sample_loop(model, noise.shape, noise=noise, device=device)
     torch.cuda.synchronize()
     t1 = time.time()
-    vol = decode_volume(dec, sample[:1], 1.0, 0.0, RES)
+    vols = [decode_volume(dec, sample[b:b + 1], 1.0, 0.0, RES) for b in range(batch)]
     torch.cuda.synchronize()
     t2 = time.time()
-    verts, tris = extract_surface(vol)
-    smooth_mesh(verts, tris, 10, box_max=float(RES - 1))
+    for vol in vols:
+        verts, tris = extract_surface(vol)
+        smooth_mesh(verts, tris, 10, box_max=float(RES - 1))
     torch.cuda.synchronize()
     t3 = time.time()
     del model
+    if batch > 1:
+        return {f"c2_batch{batch}_s_per_shape": round((t3 - t0) / batch, 4),
+                f"c2_batch{batch}_unet_sample_steps_per_s": round(steps * batch / (t1 - t0), 1),
+                f"c2_batch{batch}_sample_s": round(t1 - t0, 4), f"c2_batch{batch}_decode_ms_per_shape": round((t2 - t1) * 1e3 / batch, 2),
+                f"c2_batch{batch}_marching_cubes_ms_per_shape": round((t3 - t2) * 1e3 / batch, 2)}
     return {"c2_s_per_shape": round(t3 - t0, 4), "c2_unet_steps_per_s": round(steps / (t1 - t0), 1),
             "c2_sample_s": round(t1 - t0, 4), "c2_decode_ms": round((t2 - t1) * 1e3, 2),
             "c2_marching_cubes_ms": round((t3 - t2) * 1e3, 2), "c2_steps": steps,
             "c2_note": "random-init weights decode to a noise volume: the marching-cubes time is that of ~16M vertices "
                        "(a shape-like 256^3 volume takes surface_extract_ms_sphere256)"}
+
+
+def airplane_like_mesh(device, res=128):
+    """SURVEY 8(d) C4 input: a synthetic watertight "airplane-like" mesh -- the union of four ellipsoids (fuselage, wing,
+    tail plane, fin) -- extracted on the device from its implicit function (csrc/surface.hip), vertices in [-1, 1]^3."""
+    from ishapediting_amd.mesh import extract_surface
+    ax = torch.linspace(-1, 1, res, device=device)
+    x, y, z = ax[:, None, None], ax[None, :, None], ax[None, None, :]
+    parts = [((0.0, 0.0, 0.0), (0.80, 0.11, 0.11)), ((0.05, 0.0, 0.0), (0.16, 0.75, 0.035)),
+             ((-0.68, 0.0, 0.02), (0.09, 0.27, 0.025)), ((-0.68, 0.0, 0.12), (0.10, 0.025, 0.16))]
+    f = None
+    for (cx, cy, cz), (rx, ry, rz) in parts:
+        e = 1.0 - (((x - cx) / rx) ** 2 + ((y - cy) / ry) ** 2 + ((z - cz) / rz) ** 2)
+        f = e if f is None else torch.maximum(f, e)
+    v, t = extract_surface(f.contiguous())
+    return v / (res - 1) * 2 - 1, t
+
+
+def c4_real_shape_leg(device, shape_profile=None):
+    """BASELINE.json configs[3] (C4) once at FULL length with the reference's defaults (num_steps 200, w_time 170,
+    40 000-point batches, drag_utils.py:44-57): mesh -> 200 000 occupancy samples (on-device ray parity) ->
+    train_triplane's guided reconstruction, 200 steps of {UNet forward, decoder BCE on 40 000 points + decoder backward,
+    FULL-DEPTH UNet input-gradient backward, guided update} (drag_utils.py:442-463) -> 256^3 decode of the reconstruction
+    -> ddpm_inversion over 170 steps (gaussian_diffusion.py:512-532) -> 170 guided drag iterations + final 256^3 decode
+    (drag_utils.py:336-399).  Then one more reconstruction pass of 8 steps with HIP events on every implicit-GEMM launch:
+    the per-shape table and the roofline record of the reconstruction step (1.278 TFLOP algorithmic)."""
+    import tempfile
+    from ishapediting_amd import synthetic, _lib
+    from ishapediting_amd.drag_utils import DragStuff, get_args
+    from ishapediting_amd import mesh as mesh_backend
+    from ishapediting_amd.unet_spec import full_config
+    args = get_args(["--shape_resolution", str(RES)])            # reference defaults: num_steps 200, w_time 170
+    ds = DragStuff(device, args=args)
+    ds.load_weights(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(full_config(), 1236)), synthetic.decoder_state_dict(4321),
+                    -np.ones(96, np.float32), np.ones(96, np.float32))
+    v, t = airplane_like_mesh(device)
+    src, tgt = synthetic.handles(HANDLES, seed=11)
+    sync = torch.cuda.synchronize
+    ds.reconstruct(*[x.to(device) for x in (torch.rand(50000, 3) * 2 - 1, torch.rand(50000).round())], steps=[199, 198])   # warm-up: kernels loaded
+    sync()
+    t0 = time.time()
+    pts, occ = mesh_backend.sample_occupancy((v, t), None, True, args.points_size, args.points_uniform_ratio, device=device)
+    pts = torch.as_tensor(np.asarray(pts) if not torch.is_tensor(pts) else pts, dtype=torch.float32).to(device)
+    occ = torch.as_tensor(np.asarray(occ) if not torch.is_tensor(occ) else occ, dtype=torch.float32).reshape(-1).to(device)
+    sync()
+    t1 = time.time()
+    img = ds.reconstruct(pts, occ)                                # drag_utils.py:442-463
+    sync()
+    t2 = time.time()
+    ds.clear_params()
+    ds.mesh = ds.get_mesh(tri_feat=img)                           # :467-469 (256^3 decode + surface of the reconstruction)
+    sync()
+    t3 = time.time()
+    ds.latent_inversion(tri_feat=img)                             # :471 -> gaussian_diffusion.py:512-532 (+ decode of the inverted sample)
+    sync()
+    t4 = time.time()
+    for _ in ds.training(src, tgt, scale=1200, cof=0.4):
+        pass
+    sync()
+    t5 = time.time()
+    n_rec, n_w = args.num_steps, args.w_time
+    out = {"c4_s_per_shape": round(t5 - t0, 4), "c4_occupancy_sampling_s": round(t1 - t0, 4),
+           "c4_reconstruct_s": round(t2 - t1, 4), "c4_reconstruct_ms_per_step": round((t2 - t1) * 1e3 / n_rec, 3),
+           "c4_reconstruct_tflops": round(1.278 * n_rec / (t2 - t1), 1),
+           "c4_reconstruction_decode_and_surface_s": round(t3 - t2, 4),
+           "c4_inversion_s": round(t4 - t3, 4), "c4_inversion_unet_steps_per_s": round(n_w / (t4 - t3), 1),
+           "c4_drag_s": round(t5 - t4, 4), "c4_drag_ms_per_guided_step": round((t5 - t4) * 1e3 / n_w, 3),
+           "c4_mesh_vertices": int(v.shape[0]), "c4_occupancy_samples": int(pts.shape[0]),
+           "c4_config": f"synthetic airplane-like mesh (union of 4 ellipsoids), {n_rec} reconstruction steps x 40000 points, inversion {n_w}, drag {n_w} guided iterations, 256^3 decodes"}
+    # ---- the reconstruction step under the per-launch event profile ----
+    L = _lib.lib()
+    L.ishap_profile_begin()
+    steps = list(range(107, 99, -1))
+    sync()
+    tp0 = time.time()
+    ds.reconstruct(pts, occ, steps=steps)
+    sync()
+    tp = time.time() - tp0
+    NV = 8
+    buf3 = (C.c_double * (NV * 3))()
+    L.ishap_profile_end(buf3, NV)
+    buf = C.create_string_buffer(1 << 17)
+    L.ishap_profile_shapes(buf, len(buf))
+    csv = buf.value.decode()
+    if shape_profile:
+        with open(shape_profile, "w") as f:
+            f.write(f"# {len(steps)} reconstruction steps (UNet forward + full-depth input-gradient backward)\nM,N,K,conv3,tile,ksplit,launches,main_ms,reduce_ms,gflop\n" + csv)
+    conv_ms = conv_gf = 0.0
+    for row in csv.strip().splitlines():
+        M_, N_, K_, c3, _tile, _ks, n_, main_ms, red_ms, gf = (float(x) for x in row.split(","))
+        conv_ms += main_ms + red_ms
+        conv_gf += gf
+    out["c4_reconstruct_roofline"] = {
+        "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_MFMA_F16_TFLOPS,
+        "achieved": round(1.278 * n_rec / (t2 - t1), 1), "frac": round(1.278 * n_rec / (t2 - t1) / PEAK_MFMA_F16_TFLOPS, 4),
+        "what": "whole reconstruction step: 1.278 TFLOP algorithmic (SURVEY 8d) / measured step time of the 200-step run",
+        "conv_gemm_ms_per_step": round(conv_ms / len(steps), 3), "conv_gemm_gflop_per_step": round(conv_gf / len(steps), 1),
+        "conv_gemm_tflops": round(conv_gf / max(conv_ms, 1e-9), 1),
+        "profiled_step_ms": round(tp * 1e3 / len(steps), 3)}
+    del ds
+    return out
 
 
 def spawn_workers(a):
@@ -241,6 +349,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c2", action="store_true", help="skip the generate-path leg (BASELINE configs[1]) after the headline")
     ap.add_argument("--c2-steps", type=int, default=1000)
+    ap.add_argument("--no-c2-batch8", action="store_true", help="skip the batch-8 generate leg (generate.py's default batch)")
+    ap.add_argument("--no-c4", action="store_true", help="skip the real-shape leg (BASELINE configs[3]) after the headline")
+    ap.add_argument("--c4-shape-profile", default=None, help="write the per-shape conv/GEMM CSV of the reconstruction step here")
     ap.add_argument("--shape-profile", default=None, help="write the per-shape conv/GEMM timing CSV of one edit here")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -275,10 +386,20 @@ def main():
     recv = [torch.empty((RES, RES, RES), dtype=torch.float32, device=device) for _ in range(world)] \
         if (world > 1 and rank == 0) else None
 
+    # per-rank diagnostics of the N > 1 run (no host synchronisation inside the timed region): events on this rank's
+    # compute stream around the edit and around the gather call
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps + a.warmup)]
+    it = [0]
+
     def step():
+        e0, e1, e2 = ev[it[0]]
+        it[0] += 1
+        e0.record()
         vol = one_edit(ds, src, tgt)
+        e1.record()
         if world > 1:     # the path's only collective: every rank's occupancy volume to rank 0 (RCCL gather, 67 MB per rank)
             gather_volumes([vol], world, dst=0, full_shape=(RES, RES, RES), recv=recv)
+        e2.record()
         return vol
 
     for _ in range(a.warmup):
@@ -295,6 +416,16 @@ def main():
     dt = float(tmax.item())
     shapes = a.steps * world
     sec_per_shape = dt / shapes
+    torch.cuda.synchronize()
+    mine = torch.tensor([sum(e[0].elapsed_time(e[1]) for e in ev[a.warmup:]) / a.steps,
+                         sum(e[1].elapsed_time(e[2]) for e in ev[a.warmup:]) / a.steps, t_setup * 1e3], dtype=torch.float64, device=device)
+    per_rank = [mine.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine)
+    per_rank = [{"rank": r, "edit_ms": round(float(v[0]), 2), "gather_ms": round(float(v[1]), 2), "setup_s": round(float(v[2]) / 1e3, 2)}
+                for r, v in enumerate(per_rank)]
+    print(f"[bench] rank {rank}: edit {per_rank[rank]['edit_ms']} ms, gather call {per_rank[rank]['gather_ms']} ms per step "
+          f"(stream time; rank 0's gather includes waiting for the slowest rank)", file=sys.stderr, flush=True)
 
     # ---- roofline leg: the same edit once more with HIP events around every implicit-GEMM launch ----
     roofline = None
@@ -400,13 +531,21 @@ def main():
             "surface_extract_ms": round(surface_ms, 2),
             "surface_extract_ms_sphere256": round(surface_ms_sphere, 2), "sphere256_vertices": int(sv2.shape[0]),
             "roofline": roofline, "roofline_small_maps": small_maps, "cpu_baseline": cpu,
+            "per_rank": per_rank,
         }
         if cpu:
             line["speedup_vs_cpu_baseline"] = round(cpu["value"] / sec_per_shape, 1)
-        if world == 1 and not a.no_c2:
+        if world == 1 and not (a.no_c2 and a.no_c4):
             del ds                                                   # the edit context's arena + guidance cache
             torch.cuda.empty_cache()
+        if world == 1 and not a.no_c2:
             line.update(c2_generate_leg(device, a.c2_steps))
+            torch.cuda.empty_cache()
+            if not a.no_c2_batch8:
+                line.update(c2_generate_leg(device, a.c2_steps, batch=8))
+                torch.cuda.empty_cache()
+        if world == 1 and not a.no_c4:
+            line.update(c4_real_shape_leg(device, a.c4_shape_profile))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -23,6 +23,17 @@ const char* ishap_last_error(void);
  * fails (-3, message in ishap_last_error) if an EARLIER launch raised it.  This call checks on demand, e.g. after a
  * stream synchronise at the end of a loop: 0 = no failure since the last report; the word is cleared once reported. */
 int ishap_device_status(void);
+/* Tenancy.  The group-local GroupNorm kernels of the small maps run several workgroups per (image, group) that meet INSIDE
+ * one launch (gd/nn.py:16-18 needs group-wide sums); such a grid only completes when all of its workgroups are resident
+ * together.  Within one process the library arbitrates: per device, ONE (model context, stream) pair at a time may launch
+ * such grids; a call on another context / thread / stream that arrives while the holder's work is still in flight runs the
+ * same kernels with one workgroup per group (same values, a few microseconds slower per launch) -- no action needed.
+ * The library is otherwise SINGLE-TENANT per GPU: another PROCESS using the same device, or a caller stream created with a
+ * compute-unit mask, can keep part of such a grid from becoming resident; the wait is bounded, and the failure is reported
+ * as described above (status word, NaN outputs, -3 from the next call), never a hang or a silently wrong result.
+ * ishap_rendezvous_would_grant: diagnostic, no side effects -- 1 if a launch sequence of `owner` (a model context, or NULL
+ * for the stand-alone operator calls) on `stream` would be allowed in-launch rendezvous right now. */
+int ishap_rendezvous_would_grant(const void* owner, void* stream);
 int ishap_version(void);
 
 /* ---------------------------------------------------------------- UNet (gd/unet.py:396-671) */

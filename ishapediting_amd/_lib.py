@@ -45,6 +45,7 @@ SYMBOLS = {
     "ishap_last_error": (C.c_char_p, []),
     "ishap_version": (C.c_int, []),
     "ishap_device_status": (C.c_int, []),
+    "ishap_rendezvous_would_grant": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ishap_group_norm32_scratch_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "ishap_group_norm32": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),

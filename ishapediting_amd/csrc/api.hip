@@ -56,6 +56,59 @@ int ishap_cu_count() {
   return n;
 }
 
+namespace {
+struct Tenant {
+  std::mutex mu;
+  const void* owner = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;      // recorded when the tenant's last sequence was enqueued completely
+  bool have = false, open = false, recorded = false;
+};
+Tenant g_tenant[64];
+}  // namespace
+
+bool ishap_rendezvous_begin(const void* owner, hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  Tenant& t = g_tenant[dev];
+  std::lock_guard<std::mutex> lk(t.mu);
+  if (t.have && t.owner == owner && t.stream == s) {
+    if (t.open) return false;                   // re-entered from another thread on the same (owner, stream): do not share
+    t.open = true;                              // same in-order stream: the earlier sequence precedes this one on the device
+    return true;
+  }
+  if (t.have) {
+    if (t.open) return false;                   // another sequence is being enqueued right now
+    if (t.recorded && hipEventQuery(t.done) != hipSuccess) return false;   // ... or is still running
+  }
+  if (!t.done && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) { t.done = nullptr; return false; }
+  t.owner = owner; t.stream = s; t.have = true; t.open = true; t.recorded = false;
+  return true;
+}
+
+void ishap_rendezvous_end(const void* owner, hipStream_t s, bool granted) {
+  if (!granted) return;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+  Tenant& t = g_tenant[dev];
+  std::lock_guard<std::mutex> lk(t.mu);
+  if (!t.have || t.owner != owner || t.stream != s) return;
+  t.recorded = hipEventRecord(t.done, s) == hipSuccess;
+  t.open = false;
+  if (!t.recorded) t.have = false;
+}
+
+extern "C" int ishap_rendezvous_would_grant(const void* owner, void* stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  Tenant& t = g_tenant[dev];
+  std::lock_guard<std::mutex> lk(t.mu);
+  if (!t.have) return 1;
+  if (t.owner == owner && t.stream == (hipStream_t)stream) return t.open ? 0 : 1;
+  if (t.open) return 0;
+  return (!t.recorded || hipEventQuery(t.done) == hipSuccess) ? 1 : 0;
+}
+
 extern "C" {
 
 const char* ishap_last_error(void) { return g_err.c_str(); }

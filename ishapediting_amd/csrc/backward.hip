@@ -182,6 +182,8 @@ static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out, int split =
 int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out, int cot_out_f16, const float* scale2,
                        float* dx, hipStream_t s, bool dry) {
   Exec e{u, s, dry};
+  TenancyScope tenancy(u, s, dry);
+  e.tenant = tenancy.granted;
   u->arena.off = u->fwd_mark;
   u->stat_off = u->stat_fwd_mark;
   if (!dry) {

@@ -45,6 +45,19 @@ unsigned* ishap_status_word();        // null only if the pinned allocation fail
 int ishap_check_status();             // 0, or -3 with the error string set (the word is cleared once reported)
 int ishap_cu_count();                 // compute units of the current device (cached per device)
 
+// Rendezvous tenancy (process-wide, per device).  A kernel whose workgroups wait for each other inside one launch (the
+// group-local GroupNorm kernels with parts > 1) is only safe while no OTHER grid of that kind can be half-resident beside it:
+// two such grids could each hold compute units the other needs.  One (owner, stream) pair per device may therefore launch
+// rendezvous grids at a time: a call sequence (a UNet forward / backward, a stand-alone GroupNorm call) asks at its start
+// and is told `false` -- it then runs the same kernels with ONE workgroup per group, which wait for nobody -- while another
+// context, thread or stream of this process has such a sequence open or still in flight on the device (its closing event
+// has not completed).  Launches that never wait (everything else in the library) need no tenancy and cannot deadlock a
+// tenant: they finish by themselves and free their compute units.  What this cannot see: other PROCESSES on the same GPU
+// and compute-unit-masked streams; there the bounded spin + status word (above) turn a starved rendezvous into an error
+// (include/ishap.h, "Tenancy").
+bool ishap_rendezvous_begin(const void* owner, hipStream_t s);   // true: this sequence may use in-launch rendezvous
+void ishap_rendezvous_end(const void* owner, hipStream_t s, bool granted);   // closes the sequence (records its event on s)
+
 #define ISHAP_TRY(expr)        \
   do {                         \
     int _r = (expr);           \

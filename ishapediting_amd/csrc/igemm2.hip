@@ -16,6 +16,18 @@ typedef __attribute__((address_space(3))) void lds_void;
 #ifndef IG2_LOADERS
 #define IG2_LOADERS 4          // loader waves per workgroup (4 measured faster than 8)
 #endif
+// L2 prefetch of the weight panel (round 4).  The CUs of an XCD walk K in step, so every ring stage holds lines no CU of
+// the XCD has touched before (this K-step's slab of the weight panel): each stage lands at the latency of an L2 MISS and
+// the K-step takes miss latency / (NST - 1).  MFMA wave 0 (1: the second 64 rows of a 128-row panel) therefore touches one
+// dword of every 128-byte weight line IG2_PF_DIST K-steps ahead of the step being multiplied, by LDS-DMA into a 256-byte
+// scratch (no register to keep alive, no effect on the loader waves' vmcnt counting): by the time the loaders stage that
+// step its lines are L2 hits.  IG2_PF_SHARE: the m-tiles of an XCD that share a panel take turns (step % sharers).
+#ifndef IG2_PF_DIST
+#define IG2_PF_DIST 0
+#endif
+#ifndef IG2_PF_SHARE
+#define IG2_PF_SHARE 0
+#endif
 
 // HALVES = 2: the workgroup is two such 8-wave teams, each with its own ring, working on the two halves of the K range
 // and meeting once in LDS at the end -- split-K by two without partial tiles in HBM or a reduce launch.  It gives a CU
@@ -55,6 +67,7 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
   // linear id so that one XCD gets a contiguous run of tiles (n fastest, then m): neighbouring image rows, whose 3x3
   // halos overlap, and both n-tiles of the same rows then share an L2.  Pure speed: any placement is correct.
   int tile_m, tile_n, tile_z;
+  int pf_turn = 0, pf_mask = 0;          // weight-prefetch duty among the m-tiles of this XCD that share a panel
   {
     // grid extents: from the preloaded arguments when they are powers of two (gridDim.* is a load from the hidden arguments)
     const int nx = h.ny_shift() >= 0 ? (1 << h.nx_shift()) : (int)gridDim.x, ny = h.ny_shift() >= 0 ? (1 << h.ny_shift()) : (int)gridDim.y;
@@ -66,6 +79,11 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
       tile_n = swz & (ny - 1);
       tile_m = (swz >> h.ny_shift()) & (nx - 1);
       tile_z = swz >> (h.ny_shift() + h.nx_shift());
+      if (IG2_PF_SHARE && r == 0 && (q >> h.ny_shift()) >= 2 && ((q >> h.ny_shift()) & ((q >> h.ny_shift()) - 1)) == 0 &&
+          (q & (ny - 1)) == 0 && (q >> h.ny_shift()) <= nx) {
+        pf_mask = (q >> h.ny_shift()) - 1;       // q tiles per XCD, n fastest: q / ny m-tiles of one z share a weight panel
+        pf_turn = (pos >> h.ny_shift()) & pf_mask;
+      }
     } else {
       tile_n = swz % ny;
       tile_m = (swz / ny) % nx;
@@ -296,12 +314,26 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
     // rate an MFMA-dense loop on random data sustains at the clock the chip holds under that load (MI355X_MICROARCH.md,
     // DVFS); spreading the reads one per MFMA gap instead of in a burst changed nothing.
     using std::integral_constant;
+#if IG2_PF_DIST > 0
+    __shared__ int pf_scratch[64];
+    const bool pf_wave = wave8 < BN / 64;
+    const half_t* pfp = Wt + (long long)(n0 + wave8 * 64 + lane) * h.ldw + (long long)ks0 * BK;
+    auto pf_issue = [&](int step) {
+      if (((ks0 + step) & pf_mask) == pf_turn)
+        __builtin_amdgcn_global_load_lds(pfp + step * BK, (lds_void*)pf_scratch, 4, 0, 0);
+    };
+    if (pf_wave)
+      for (int s2 = NST - 1; s2 < min(nk, IG2_PF_DIST); ++s2) pf_issue(s2);
+#endif
     __builtin_amdgcn_s_barrier();                // step 0 has landed
     asm volatile("" ::: "memory");
     IG_STAMP(2, wave_all == 0);
     if (nk > 0) read_half(0, 0, xa, wa);
     for (int k = 0; k < nk_loop; ++k) {
       const bool act = k < nk;                   // the shorter half (odd step count) idles through the last barrier
+#if IG2_PF_DIST > 0
+      if (pf_wave && k + IG2_PF_DIST < nk) pf_issue(k + IG2_PF_DIST);
+#endif
       if (act) {
         read_half(k, 1, xb, wb);
         wait_frags(integral_constant<int, MT + NT>{}, xa, wa);
@@ -394,7 +426,10 @@ bool igemm2_two_teams(const IgemmArgs& a, bool big) {
 
 // main kernel only (the caller adds the split-K reduce); big = 128x128 tile, else 64x64
 int igemm2_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
-  if (big) return a.conv3 ? launch2<128, 128, 4, true>(a, s) : launch2<128, 128, 4, false>(a, s);
+#ifndef IG2_BIG_NST
+#define IG2_BIG_NST 4
+#endif
+  if (big) return a.conv3 ? launch2<128, 128, IG2_BIG_NST, true>(a, s) : launch2<128, 128, IG2_BIG_NST, false>(a, s);
 #ifndef IG2_SMALL_NST
 #define IG2_SMALL_NST 4
 #endif

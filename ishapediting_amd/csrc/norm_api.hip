@@ -83,8 +83,13 @@ int ishap_group_norm32(const void* x_nhwc_f16, const float* gamma, const float* 
     GnLocalArgs g;
     g.xa = x; g.Ca = C; g.out = (half_t*)y_nhwc_f16; g.stats_out = stats; g.gamma = gamma; g.beta = beta;
     g.N = N; g.H = H; g.W = W; g.C = C; g.film = 0; g.act = silu; g.pool = 0;
-    g.rec = route == 3 ? sc.rec : nullptr;
-    return gn_local_launch(g, s);
+    // route 3 (several workgroups per group meeting inside the launch) needs the device's rendezvous tenancy (common.h);
+    // while another context / stream of the process holds it the call degrades to one workgroup per group (route 2)
+    const bool granted = route == 3 && ishap_rendezvous_begin(nullptr, s);
+    g.rec = granted ? sc.rec : nullptr;
+    const int r = gn_local_launch(g, s);
+    ishap_rendezvous_end(nullptr, s, granted);
+    return r;
   }
   GnApplyArgs g;
   g.x = x; g.out = (half_t*)y_nhwc_f16; g.gamma = gamma; g.beta = beta;
@@ -94,9 +99,12 @@ int ishap_group_norm32(const void* x_nhwc_f16, const float* gamma, const float* 
     g.stats = stats;
   } else {
     // producer stand-in: copy = x * I through the implicit-GEMM kernel, whose epilogue gathers the per-channel sums
-    ISHAP_REQUIRE(C % 64 == 0 && ((long long)N * HW) % 64 == 0 && C % 8 == 0, "route 4: C % 64 == 0, N*H*W % 64 == 0");
+    // the epilogue credits a tile's sums to ONE image (n_img = m0 / HW): a tile must not straddle images, whichever tile
+    // height (64 or 128 rows) the launcher picks
+    ISHAP_REQUIRE(C % 64 == 0 && (HW % 128 == 0 || N == 1) && ((long long)N * HW) % 64 == 0, "route 4: C % 64 == 0, H*W % 128 == 0 (N*H*W % 64 == 0 at batch 1)");
     const int rows = (int)align_up((size_t)C, 128);
     hipLaunchKernelGGL(identity_fill_kernel, dim3((rows * C + 255) / 256), dim3(256), 0, s, sc.ident, C, rows);
+    ISHAP_CHECK_HIP(hipGetLastError());
     IgemmArgs a;
     a.X = x; a.Wt = sc.ident; a.out = sc.copy; a.M = N * HW; a.N = C; a.K = C; a.conv3 = 0; a.Cin = C;
     a.ldx = C; a.ldw = C; a.ldo = C; a.H = H; a.W = W; a.out_mode = IG_OUT_F16; a.ksplit = 1;
@@ -125,8 +133,11 @@ int ishap_group_norm32_backward(const void* g_nhwc_f16, const void* x_nhwc_f16, 
     a.g = (const half_t*)g_nhwc_f16; a.x = (const half_t*)x_nhwc_f16; a.dx = (half_t*)dx_nhwc_f16;
     a.stats = stats; a.gamma = gamma; a.beta = beta; a.N = N; a.H = H; a.W = W; a.C = C; a.film = 0; a.act = silu;
     a.gmode = GB_SAME;
-    a.rec = route == 3 ? sc.rec : nullptr;
-    return gn_bwd_local_launch(a, s);
+    const bool granted = route == 3 && ishap_rendezvous_begin(nullptr, s);
+    a.rec = granted ? sc.rec : nullptr;
+    const int r = gn_bwd_local_launch(a, s);
+    ishap_rendezvous_end(nullptr, s, granted);
+    return r;
   }
   GnBwdArgs a;
   a.g = (const half_t*)g_nhwc_f16; a.x = (const half_t*)x_nhwc_f16; a.dx = (half_t*)dx_nhwc_f16;

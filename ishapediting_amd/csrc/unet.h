@@ -187,6 +187,17 @@ struct Exec {
   bool keep = false;   // the forward keeps what a following backward re-reads
   float* ws = nullptr;          // split-K / GroupNorm-statistics scratch of this launch sequence (null: the context's)
   float* gn_partial = nullptr;
+  bool tenant = true;           // this sequence holds the device's rendezvous tenancy (common.h ishap_rendezvous_begin)
+};
+// RAII around a launch sequence: asks for the tenancy at construction, closes it (event on the stream) at scope exit
+struct TenancyScope {
+  const void* owner; hipStream_t s; bool granted;
+  TenancyScope(const void* o, hipStream_t st, bool dry) : owner(o), s(st), granted(dry ? true : ishap_rendezvous_begin(o, st)), dry_(dry) {}
+  ~TenancyScope() { if (!dry_) ishap_rendezvous_end(owner, s, granted); }
+  TenancyScope(const TenancyScope&) = delete;
+  TenancyScope& operator=(const TenancyScope&) = delete;
+ private:
+  bool dry_;
 };
 // Arena allocation that FAILS THE CALL when the arena sized by the create-time dry runs is exceeded (a null pointer
 // must never reach a kernel): ISHAP_ALLOC(ptr, e, count) inside any function returning an int status.

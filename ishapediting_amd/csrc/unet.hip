@@ -259,7 +259,7 @@ long long* salloc(Exec& e, size_t count) {
   return u->stat_off <= u->stat_cap ? u->stat_base + o : nullptr;
 }
 
-bool exec_is_solo(const Exec& e) { return e.dry || (!e.u->tail_pending && (e.u->side == nullptr || e.s != e.u->side)); }
+bool exec_is_solo(const Exec& e) { return e.dry || (e.tenant && !e.u->tail_pending && (e.u->side == nullptr || e.s != e.u->side)); }
 
 bool small_map(int HW) {
   static const int on = [] { const char* v = getenv("ISHAP_LOCAL_GN"); return v ? atoi(v) : 1; }();
@@ -528,6 +528,8 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
   ISHAP_REQUIRE(N >= 1 && N <= cfg.max_batch && N <= 16, "batch size outside [1, max_batch]");
   ISHAP_REQUIRE(feat_layer < (int)u->out_blocks.size(), "feat_layer out of range");
   Exec e{u, s, dry};
+  TenancyScope tenancy(u, s, dry);       // in-launch rendezvous only while no other context / stream of the process runs such grids here
+  e.tenant = tenancy.granted;
   e.keep = (keep & 1) != 0;
   const bool overlap = (keep & 2) != 0 && !dry && feat_layer >= 0 && feat_layer + 1 < (int)u->out_blocks.size();
   if (!dry) ISHAP_TRY(unet_join_tail(u, s));       // the previous forward's tail still owns the arena it is about to reuse

@@ -183,6 +183,10 @@ def synthesize_latent(model, diffusion, args=None, t1=None, t2=0, inter_latent_i
     elif t1 == 0:
         return {"img": img[:args.num_samples], "inter_latent": [], "inter_feat": [], "pred_xstart": [], "model_output": None}
     sample_fun = diffusion.ddim_sample if getattr(args, "use_ddim", False) else diffusion.p_sample_guidance
+    if calc_grad and getattr(args, "use_ddim", False):
+        # only p_sample_guidance routes a requires_grad input through differentiable.UNetCall; ddim_sample would cut the
+        # graph silently (the reference keeps it, drag_utils.py:96-113) -- refuse rather than return detached tensors
+        raise NotImplementedError("synthesize_latent(calc_grad=True) with use_ddim: the DDIM sampler has no autograd bridge")
     inter_latent, inter_feat, predict_x0, model_output, variance, noise = [], [], [], None, [], []
     with (th.enable_grad() if calc_grad else th.no_grad()):
         for i in range(t1 - 1, t2 - 1, -1):

@@ -38,6 +38,20 @@ def unnormalize(sample, stats_dir=None, lower_bound=None, upper_bound=None):
     return sample * ((mx - mn) / 2) + (mn + mx) / 2
 
 
+def gather_samples(sample: th.Tensor, num_samples: int) -> np.ndarray:
+    """The tail of noise2shape (image_sample.py:188-197): NCHW -> NHWC, one all_gather over the ranks (rank order), the
+    batches concatenated along axis 0 and cut to `num_samples`.  Single process: the local batch alone."""
+    sample = sample.permute(0, 2, 3, 1).contiguous()
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        gathered = [th.zeros_like(sample) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, sample)
+        dist.barrier()
+    else:
+        gathered = [sample]
+    arr = np.concatenate([s.cpu().numpy() for s in gathered], axis=0)
+    return arr[:num_samples]
+
+
 def noise2shape(args=None, state_dict=None, bounds=None, noise=None, step_noise=None):
     """image_sample.py:138-201.  `state_dict` / `bounds` let callers without checkpoint files (tests, synthetic
     benchmarks) pass weights and (lower, upper) normalisation bounds directly."""
@@ -58,12 +72,4 @@ def noise2shape(args=None, state_dict=None, bounds=None, noise=None, step_noise=
             sample = unnormalize(sample, lower_bound=bounds[0], upper_bound=bounds[1])
         else:
             sample = unnormalize(sample, stats_dir=args.stats_dir)
-    sample = sample.permute(0, 2, 3, 1).contiguous()
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        gathered = [th.zeros_like(sample) for _ in range(dist.get_world_size())]
-        dist.all_gather(gathered, sample)
-        dist.barrier()
-    else:
-        gathered = [sample]
-    arr = np.concatenate([s.cpu().numpy() for s in gathered], axis=0)
-    return arr[: args.num_samples]
+    return gather_samples(sample, args.num_samples)

@@ -84,27 +84,35 @@ def smooth_mesh(verts: torch.Tensor, tris: torch.Tensor, iterations: int = 10, b
     return out
 
 
-def chamfer_distance(pa: torch.Tensor, pb: torch.Tensor, point_num=20000, seed: int = 0) -> float:
+def chamfer_distance(pa: torch.Tensor, pb: torch.Tensor, point_num=20000, seed: int = 0, query_num=None) -> float:
     """meshProcess.py:18-35: mean squared nearest-neighbour distance a->b plus b->a on `point_num` samples per side
     (the reference samples mesh surfaces with Open3D; here the samples are drawn from the given point sets).
-    point_num=None uses every point (no sampling floor)."""
+    point_num=None uses every point (no sampling floor).  query_num (with point_num=None): only the QUERY side of each
+    direction is a random subset of that many points, the nearest neighbour is searched in the COMPLETE other set -- an
+    unbiased estimate of the all-points value without its quadratic cost and without a sampling floor (the floor of the
+    sampled form comes from thinning the target set)."""
     _need_gpu(pa, "chamfer_distance")
     g = torch.Generator(device="cpu").manual_seed(seed)
 
-    def pick(p):
-        if point_num is None or p.shape[0] <= point_num:
+    def pick(p, n):
+        if n is None or p.shape[0] <= n:
             return p
-        return p[torch.randperm(p.shape[0], generator=g)[:point_num].to(p.device)]
-    a = pick(pa).detach().to(torch.float32).contiguous()
-    b = pick(pb).detach().to(device=a.device, dtype=torch.float32).contiguous()
+        return p[torch.randperm(p.shape[0], generator=g)[:n].to(p.device)]
+
+    def run(a, b):
+        nearest = torch.empty(max(a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+        out2 = torch.empty(2, dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.lib().ishap_chamfer(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], nearest.data_ptr(),
+                                                out2.data_ptr(), _lib.stream_ptr(a.device)))
+        return out2.tolist()
+    a = pick(pa, point_num).detach().to(torch.float32).contiguous()
+    b = pick(pb, point_num).detach().to(device=a.device, dtype=torch.float32).contiguous()
     if a.shape[0] == 0 or b.shape[0] == 0:
         return float("nan")
-    nearest = torch.empty(max(a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
-    out2 = torch.empty(2, dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
-        _lib.check(_lib.lib().ishap_chamfer(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], nearest.data_ptr(),
-                                            out2.data_ptr(), _lib.stream_ptr(a.device)))
-    d = out2.tolist()
+    if query_num is not None and point_num is None:
+        return float(run(pick(a, query_num).contiguous(), b)[0] + run(pick(b, query_num).contiguous(), a)[0])
+    d = run(a, b)
     return float(d[0] + d[1])
 
 

@@ -415,8 +415,9 @@ def decode_volume(net, latent: torch.Tensor, rng, mid, res: int, chunk: int = 50
 # ----------------------------------------------------------------------------
 
 
-def sample_with_guidance_cache(diff: DiffusionOracle, unet: UNetOracle, img, num_steps, w_time, feat_layer, noises):
-    """drag_utils.py:266-277. noises[i] is the injected randn for loop index i."""
+def sample_with_guidance_cache(diff: DiffusionOracle, unet: UNetOracle, img, num_steps, w_time, feat_layer, noises, progress=None):
+    """drag_utils.py:266-277. noises[i] is the injected randn for loop index i.  progress(i): called once per step (long
+    full-size runs print a line so that the job is seen to be alive)."""
     w = None
     cache = []
     with torch.no_grad():
@@ -427,11 +428,13 @@ def sample_with_guidance_cache(diff: DiffusionOracle, unet: UNetOracle, img, num
                 w = img.clone()
             if i < w_time:
                 cache.append(resize_feat_align(o["inter_feat"]))
+            if progress:
+                progress(i)
     return img, w, cache
 
 
 def drag_loop(diff: DiffusionOracle, unet: UNetOracle, w, cache, setup: DragSetup, w_time, feat_layer, scale, cof,
-              noises, loss_type="l2"):
+              noises, loss_type="l2", progress=None):
     """drag_utils.py:336-398 (case 2: variance not fixed). Returns final latent and per-step losses."""
     img = w.clone().detach()
     losses = []
@@ -443,6 +446,8 @@ def drag_loop(diff: DiffusionOracle, unet: UNetOracle, w, cache, setup: DragSetu
         g, = torch.autograd.grad(loss, img)
         losses.append(float(loss.detach()))
         img = (o["sample"] + o["variance"] * (scale * g)).detach()
+        if progress:
+            progress(i)
     return img, losses
 
 

@@ -16,13 +16,20 @@ import torch
 def mc_vertices(volume: torch.Tensor, level: float = 0.0) -> torch.Tensor:
     """The vertex set marching cubes produces: one vertex per grid edge whose end points straddle `level`,
     at the linearly interpolated crossing (grid coordinates, [V,3]).  Triangulation tables are not needed for
-    vertex counts or for the Chamfer metric of meshProcess.py:18-35."""
+    vertex counts or for the Chamfer metric of meshProcess.py:18-35.
+
+    Tie rule (a voxel exactly AT the level): a corner is classified by `value <= level` vs `value > level`, the partition
+    PyMCubes' published marching_cubes uses (`if (v[m] <= isovalue) cubeindex |= 1 << m;`, _mcubes/marchingcubes.h --
+    restated from the published source, PyMCubes is not installed here: parity unpinned) and the one
+    csrc/surface.hip:corner_bits and `marching_cubes` below use (`value - level > 0` = the other side of the same cut).
+    An at-level voxel therefore sits with the values below the level, and an edge from it to a value above the level
+    carries a vertex AT the voxel (t = 0)."""
     v = volume.float() - level
     out = []
     for axis in range(3):
         a = v.narrow(axis, 0, v.shape[axis] - 1)
         b = v.narrow(axis, 1, v.shape[axis] - 1)
-        cross = (a < 0) != (b < 0)
+        cross = (a > 0) != (b > 0)
         idx = cross.nonzero()
         if idx.numel() == 0:
             continue

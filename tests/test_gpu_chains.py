@@ -529,6 +529,17 @@ def test_synthesize_latent_calc_grad_matches_oracle_autograd():
     # a leaf created inside (img=None) carries the graph too
     r1 = synthesize_latent(m, diff, args, t1=1, calc_grad=True, feat_layer=fl)
     assert r1["img"].requires_grad
+    # and out["img"] backpropagates to the leaf the caller passed
+    leaf = x0.to(dev()).clone().requires_grad_(True)
+    r2 = synthesize_latent(m, diff, args, t1=Tn, t2=Tn - 1, img=leaf, calc_grad=True, noise=noise.to(dev()), feat_layer=fl)
+    r2["img"].square().sum().backward()
+    assert leaf.grad is not None and bool(torch.isfinite(leaf.grad).all()) and float(leaf.grad.abs().max()) > 0
+    # the DDIM sampler has no autograd bridge: asking for a graph through it is refused, not silently detached
+    import copy
+    args_ddim = copy.copy(args)
+    args_ddim.use_ddim = True
+    with pytest.raises(NotImplementedError):
+        synthesize_latent(m, diff, args_ddim, t1=1, calc_grad=True, feat_layer=fl)
 
 
 # ------------------------------------------------------------------------------------------ runtime switches

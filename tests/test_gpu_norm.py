@@ -173,6 +173,42 @@ def test_model_with_large_group_means_vs_reference_runs(gold):
         assert e16 < tol and e32 < tol, (k, e16, e32)
 
 
+# ------------------------------------------------------------------------------------------ one rendezvous tenant per device
+def test_rendezvous_tenancy_second_context_degrades_to_one_workgroup_per_group():
+    """csrc/common.h ishap_rendezvous_begin: while one (context, stream) pair has launch sequences with in-launch
+    rendezvous grids in flight, a second model context on another stream must not launch such grids of its own (two
+    half-resident grids could wait on each other's compute units): its forward runs the group-local GroupNorm kernels with
+    ONE workgroup per group -- bitwise the values of the rendezvous route -- and regains the rendezvous once the device is idle."""
+    from ishapediting_amd.unet import UNetModel
+    cfg = offset64_config()
+    sd = synthetic.round_torso_to_fp16(synthetic.unet_state_dict_offset(cfg, 141, offset=1.0))
+    m1, m2 = UNetModel(cfg, dev()), UNetModel(cfg, dev())
+    m1.load_state_dict(sd)
+    m2.load_state_dict(sd)
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, cfg.in_channels, cfg.image_size, cfg.image_size, generator=g).to(dev())
+    ts = torch.tensor([17.0])
+    ref, _ = m2(x, ts, feat_layer=1)
+    torch.cuda.synchronize()
+    ref = ref.clone()
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(sA):
+        torch.cuda._sleep(40_000_000)                # >= 20 ms of device time in front of m1's work on stream A
+        m1(x, ts, feat_layer=1)
+    busy = int(L.ishap_rendezvous_would_grant(None, sB.cuda_stream))
+    with torch.cuda.stream(sB):
+        out_b, _ = m2(x, ts, feat_layer=1)
+    torch.cuda.synchronize()
+    idle = int(L.ishap_rendezvous_would_grant(None, sB.cuda_stream))
+    assert busy == 0 and idle == 1
+    assert int(L.ishap_device_status()) == 0
+    assert torch.equal(out_b, ref)
+    out_c, _ = m2(x, ts, feat_layer=1)               # alone again: the rendezvous route, the same values
+    torch.cuda.synchronize()
+    assert torch.equal(out_c, ref)
+
+
 # ------------------------------------------------------------------------------------------ the rendezvous gives up loudly
 _GIVE_UP = r"""
 import sys, torch

@@ -93,6 +93,49 @@ def _worker(rank, world, port, n_edits, q):
     dist.destroy_process_group()
 
 
+def _sample_worker(rank, world, port, num_samples, q):
+    import torch.distributed as dist
+    from ishapediting_amd.image_sample import gather_samples
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    # fake per-rank batches [2, C=3, 4, 5]: value = 100 * rank + 10 * batch index + channel
+    b = torch.arange(2).reshape(2, 1, 1, 1) * 10.0 + torch.arange(3).reshape(1, 3, 1, 1) + 100.0 * rank
+    arr = gather_samples(b.expand(2, 3, 4, 5).contiguous(), num_samples)
+    q.put((rank, arr.shape, arr[:, 0, 0, :].tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_samples", [3, 4, 9])
+def test_noise2shape_gather_tail_world_size_2_gloo(num_samples):
+    """image_sample.py:188-197 of the reference: NHWC permute, all_gather in RANK order, concatenate, cut to num_samples
+    (3: the cut falls inside rank 1's batch; 9: more than the two ranks produced -- everything is kept)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, num_samples, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = min(num_samples, 4)
+    want = [[100.0 * (i // 2) + 10.0 * (i % 2) + c for c in range(3)] for i in range(4)][:n]
+    for rank, shape, rows in got:                      # all_gather: EVERY rank holds the full, ordered result
+        assert tuple(shape) == (n, 4, 5, 3) and rows == want
+
+
+def test_noise2shape_gather_tail_single_process():
+    from ishapediting_amd.image_sample import gather_samples
+    x = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)
+    arr = gather_samples(x, 1)
+    assert arr.shape == (1, 4, 5, 3) and np.array_equal(arr[0], x[0].permute(1, 2, 0).numpy())
+
+
 @pytest.mark.parametrize("n_edits", [1, 2, 3, 4])
 def test_gather_volumes_world_size_2_gloo(n_edits):
     import socket

@@ -304,6 +304,13 @@ def test_marching_cubes_statement_topology():
     e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]).sort(dim=1).values
     _, counts = torch.unique(e, dim=0, return_counts=True)
     assert int(counts.max()) == 2 and v.shape[0] == mc_vertices(noise).shape[0]
+    # tie rule: voxels exactly at the level sit with the values below it in BOTH statements (`value > level` is the cut)
+    ties = torch.randint(-1, 2, (12, 12, 12), generator=torch.Generator().manual_seed(3)).float()
+    v, f = marching_cubes(ties)
+    assert v.shape[0] == mc_vertices(ties).shape[0]
+    at = torch.zeros(4, 4, 4); at[1, 1, 1] = 1.0; at[2, 1, 1] = 0.0          # one voxel above, its neighbours at the level
+    assert mc_vertices(at).shape[0] == 6 and marching_cubes(at)[0].shape[0] == 6
+    assert mc_vertices(-at).shape[0] == 0                                     # one voxel below, the rest AT the level: no surface
 
 
 @pytest.mark.parametrize("eta", [0.0, 0.7])

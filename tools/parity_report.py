@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def surface_report(vol_gpu, vol_cpu, va, res, dev, extract_surface, mesh_chamfer):
+def surface_report(vol_gpu, vol_cpu, va, vb, res, dev, extract_surface, mesh_chamfer):
     """the device marching cubes on both volumes: vertex count (= the checker's sign-changing grid edges), closedness, and
     calc_chamfer as the reference defines it -- 20 000 points sampled uniformly by area on each surface"""
     out = {}
@@ -31,7 +31,10 @@ def surface_report(vol_gpu, vol_cpu, va, res, dev, extract_surface, mesh_chamfer
         out[f"device_mc_triangles_on_{name}_volume"] = int(t.shape[0])
         out[f"device_mc_open_edges_on_{name}_volume"] = int((cnt == 1).sum())      # edges on the volume's faces only
     out["device_mc_equals_checker_vertex_count"] = out["device_mc_vertices_on_device_volume"] == int(va.shape[0])
-    out["chamfer_area_uniform_20k"] = mesh_chamfer(meshes[0], meshes[1], 20000)
+    out["device_mc_equals_checker_vertex_count_on_oracle_volume"] = out["device_mc_vertices_on_oracle_volume"] == int(vb.shape[0])
+    # sampled by area at the reference's default 20 000 points: on a surface of this area the value IS its sampling floor
+    # (reported next to it) -- a floor, not a parity measurement
+    out["chamfer_area_uniform_20k_FLOOR_LIMITED"] = mesh_chamfer(meshes[0], meshes[1], 20000)
     out["chamfer_area_uniform_20k_floor"] = mesh_chamfer(meshes[1], (meshes[1][0].clone(), meshes[1][1].clone()), 20000, seed=1)
     return out
 
@@ -42,8 +45,14 @@ def surface_area(mesh):
     return float(0.5 * torch.cross(v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 0]], dim=1).norm(dim=1).sum())
 
 
+def lowpass(lat, k):
+    """box filter k x k (average pool + bilinear upsample): a LINEAR map of the latent, applied to both runs alike"""
+    import torch.nn.functional as F
+    return F.interpolate(F.avg_pool2d(lat, k), scale_factor=k, mode="bilinear", align_corners=False)
+
+
 def shape_like_report(dec_sd, dev, res, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices, edit_dev=None, edit_cpu=None,
-                      point_num=500000, smooth=0.005, amp=0.0005):
+                      point_num=500000, smooth=0.005, amp=0.0005, lowpass_k=0):
     """The decode + surface comparison on a SHAPE-LIKE level set.  A smooth, low-amplitude triplane latent makes the
     random-weight decoder a smooth function of position; the EDIT's own results (the final latents of the device run and
     of the oracle run: sampling + guided iterations with the same seeds, weights and handles) ride on it as a small
@@ -62,8 +71,14 @@ def shape_like_report(dec_sd, dev, res, extract_surface, mesh_chamfer, chamfer_d
         a, b, p, q = torch.randn(4, generator=g)
         lat[0, c] = smooth * (a * torch.cos(1.5 * xx + p) + b * torch.cos(1.5 * yy + q))
     # amp: the edit's latent (|x| <= 1) rides on the smooth field at a tenth of its amplitude
-    lat_dev = lat + (amp * edit_dev.float().cpu() if edit_dev is not None else 0)
-    lat_cpu = lat + (amp * edit_cpu.float().cpu() if edit_cpu is not None else 0)
+    if lowpass_k:
+        # FULL-AMPLITUDE variant: the edit's final latent itself, low-passed so that the random-weight decoder sees a smooth
+        # field (a shape-like level set); nothing is scaled down, low-frequency differences of the two runs pass 1:1
+        lat_dev = amp * lowpass(edit_dev.float().cpu(), lowpass_k)
+        lat_cpu = amp * lowpass(edit_cpu.float().cpu(), lowpass_k)
+    else:
+        lat_dev = lat + (amp * edit_dev.float().cpu() if edit_dev is not None else 0)
+        lat_cpu = lat + (amp * edit_cpu.float().cpu() if edit_cpu is not None else 0)
     dec = MultiTriplane(1, device=dev)
     dec.net.load_state_dict(dec_sd)
     vg = decode_volume(dec, lat_dev.to(dev), 1.0, 0.0, res)
@@ -80,16 +95,20 @@ def shape_like_report(dec_sd, dev, res, extract_surface, mesh_chamfer, chamfer_d
     vb = mc_vertices(vc, level) / res * 2 - 1
     area = surface_area(meshes[1])
     out.update({
-        "what": f"decode of (smooth triplane of amplitude {smooth} + {amp} x the edit's final latent), device edit vs oracle edit" if edit_dev is not None
-                else "decode of a smooth triplane",
+        "what": (f"decode of {amp} x lowpass_{lowpass_k}(the edit's final latent): the edit at full relative amplitude on a smooth field" if lowpass_k else
+                 f"decode of (smooth triplane of amplitude {smooth} + {amp} x the edit's final latent): the edit is ATTENUATED to {amp / smooth:.2f} of the carrier, so this "
+                 "case checks decode + surface extraction, not the edit path" if edit_dev is not None else "decode of a smooth triplane"),
+        "device_mc_equals_checker_vertex_count": out["vertices_device_volume"] == int(va.shape[0]),
+        "device_mc_equals_checker_vertex_count_on_oracle_volume": out["vertices_oracle_volume"] == int(vb.shape[0]),
+        "latent_rel_l2_after_filter": float((lat_dev - lat_cpu).norm() / lat_cpu.norm()),
         "res": res, "level": level, "logit_max_abs_err": float((vg.cpu() - vc).abs().max()), "logit_rms": float(vc.pow(2).mean().sqrt()),
         "sign_flips_about_level": int(((vg.cpu() > level) != (vc > level)).sum()),
         "checker_vertex_count_device_volume": int(va.shape[0]), "checker_vertex_count_oracle_volume": int(vb.shape[0]),
         "surface_area": area,
         "chamfer_all_vertices": chamfer_distance(va.to(dev), vb.to(dev), None),
-        "chamfer_area_uniform_20k": mesh_chamfer(meshes[0], meshes[1], 20000),
+        "chamfer_area_uniform_20k_FLOOR_LIMITED": mesh_chamfer(meshes[0], meshes[1], 20000),
         "chamfer_area_uniform_20k_floor": mesh_chamfer(meshes[1], (meshes[1][0].clone(), meshes[1][1].clone()), 20000, seed=1),
-        f"chamfer_area_uniform_{point_num // 1000}k": mesh_chamfer(meshes[0], meshes[1], point_num),
+        f"chamfer_area_uniform_{point_num // 1000}k_FLOOR_LIMITED": mesh_chamfer(meshes[0], meshes[1], point_num),
         f"chamfer_area_uniform_{point_num // 1000}k_floor": mesh_chamfer(meshes[1], (meshes[1][0].clone(), meshes[1][1].clone()), point_num, seed=1),
         f"chamfer_floor_estimate_2A_over_piN_{point_num // 1000}k": 2.0 * area / (3.141592653589793 * point_num),
     })
@@ -101,7 +120,8 @@ def main():
     ap.add_argument("--T", type=int, default=12)
     ap.add_argument("--W", type=int, default=4)
     ap.add_argument("--res", type=int, default=96)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "round3_parity.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "round4_parity.json"))
+    ap.add_argument("--threads", type=int, default=min(16, os.cpu_count()))
     a = ap.parse_args()
     from ishapediting_amd import synthetic
     from ishapediting_amd.drag_utils import DragStuff, get_args
@@ -135,20 +155,28 @@ def main():
     vol_gpu = ds.volume.cpu()
     lat_gpu = ds.tri_feat.cpu()
     # ---------------- oracle (fp32, CPU) ----------------
-    torch.set_num_threads(min(16, os.cpu_count()))
+    torch.set_num_threads(a.threads)
     net = O.UNetOracle(build_spec(cfg), sd, fp16=False)
     diff = O.DiffusionOracle(O.Tables(str(a.T)))
     t0 = time.time()
-    img, w, cache = O.sample_with_guidance_cache(diff, net, lat, a.T, a.W, 8, {a.T - 1 - k: n1[k] for k in range(a.T)})
+    tick = lambda what: (lambda i: print(f"oracle {what} step {i} ({time.time() - t0:.0f} s)", file=sys.stderr, flush=True) if i % 10 == 0 else None)
+    img, w, cache = O.sample_with_guidance_cache(diff, net, lat, a.T, a.W, 8, {a.T - 1 - k: n1[k] for k in range(a.T)}, progress=tick("sampling"))
     setup = O.DragSetup(src, tgt, 12, 2.0 / a.res, cache[0].shape[-1])
-    final, losses = O.drag_loop(diff, net, w, cache, setup, a.W, 8, scale, cof, {a.W - 1 - k: n2[k] for k in range(a.W)})
+    final, losses = O.drag_loop(diff, net, w, cache, setup, a.W, 8, scale, cof, {a.W - 1 - k: n2[k] for k in range(a.W)}, progress=tick("guided"))
     rng = torch.from_numpy((hi - lo) / 2).reshape(1, 96, 1, 1)
     mid = torch.from_numpy((hi + lo) / 2).reshape(1, 96, 1, 1)
     vol_cpu = O.decode_volume(dec_sd, final, rng, mid, a.res)
     t_cpu = time.time() - t0
+    vol_cpu_unedited = O.decode_volume(dec_sd, img, rng, mid, a.res)      # the oracle's mesh0 volume: the NULL for every metric below
     # ---------------- report ----------------
     rel = lambda x, y: float((x - y).norm() / y.norm())
     va, vb = mc_vertices(vol_gpu.cpu()) / a.res * 2 - 1, mc_vertices(vol_cpu.cpu()) / a.res * 2 - 1     # visualize.py:101 convention
+    v0 = mc_vertices(vol_cpu_unedited) / a.res * 2 - 1
+    big = max(va.shape[0], vb.shape[0]) > 1_500_000
+    # every vertex of one surface against EVERY vertex of the other (no target thinning, hence no sampling floor); on
+    # surfaces of millions of vertices the query side is a 200 000-point random subset (unbiased, mesh.chamfer_distance)
+    allv = lambda x, y: chamfer_distance(x.to(dev), y.to(dev), None, query_num=200000 if big else None) if min(x.shape[0], y.shape[0]) > 0 else None
+    dl, ol = np.array([float(l) for l in ds.last_losses]), np.array(losses)
     rep = {
         "config": {"T": a.T, "guided_steps": a.W, "decode_res": a.res, "handles": 3, "scale": scale, "cof": cof,
                    "weights": "synthetic seed 1234 (421M params)", "feature_range": "+-0.05"},
@@ -159,12 +187,21 @@ def main():
         "logit_rms": float(vol_cpu.pow(2).mean().sqrt()),
         "sign_flips": int(((vol_gpu > 0) != (vol_cpu > 0)).sum()), "voxels": int(vol_cpu.numel()),
         "mc_vertices_device": int(va.shape[0]), "mc_vertices_oracle": int(vb.shape[0]),
-        "chamfer_all_vertices": chamfer_distance(va.to(dev), vb.to(dev), None) if min(va.shape[0], vb.shape[0]) > 0 else None,
-        "chamfer_20k_samples": chamfer_distance(va.to(dev), vb.to(dev), 20000) if min(va.shape[0], vb.shape[0]) > 0 else None,
+        "PARITY_chamfer_all_vertices": allv(va, vb),
+        "chamfer_all_vertices_queries": "200000-point random query subset per direction, complete target set" if big else "all",
+        # the same metrics against the oracle's UNEDITED volume: what a wrong edit would score (the metric's resolving power)
+        "NULL_chamfer_all_vertices_device_edit_vs_oracle_unedited": allv(va, v0),
+        "NULL_sign_flips_oracle_edit_vs_oracle_unedited": int(((vol_cpu > 0) != (vol_cpu_unedited > 0)).sum()),
+        "NULL_logit_rms_oracle_edit_vs_oracle_unedited": float((vol_cpu - vol_cpu_unedited).pow(2).mean().sqrt()),
+        "NULL_latent_rel_l2_oracle_edit_vs_oracle_unedited": rel(img, final),
+        "chamfer_20k_samples_FLOOR_LIMITED": chamfer_distance(va.to(dev), vb.to(dev), 20000) if min(va.shape[0], vb.shape[0]) > 0 else None,
         "chamfer_20k_sampling_floor": chamfer_distance(vb.to(dev), vb.clone().to(dev), 20000, seed=1),
-        **surface_report(vol_gpu, vol_cpu, va, a.res, dev, extract_surface, mesh_chamfer),
-        "shape_like_edit": shape_like_report(dec_sd, dev, 128, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices,
-                                             edit_dev=lat_gpu, edit_cpu=final),
+        **surface_report(vol_gpu, vol_cpu, va, vb, a.res, dev, extract_surface, mesh_chamfer),
+        "shape_like_edit_attenuated": shape_like_report(dec_sd, dev, 128, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices,
+                                                        edit_dev=lat_gpu, edit_cpu=final),
+        "shape_like_edit_full_amplitude": shape_like_report(dec_sd, dev, 128, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices,
+                                                            edit_dev=lat_gpu, edit_cpu=final, amp=0.05, lowpass_k=16),
+        "drag_loss_max_rel_diff": float(np.max(np.abs(dl - ol) / np.maximum(np.abs(ol), 1e-30))) if len(dl) == len(ol) and len(ol) else None,
         "oracle_drag_losses": losses, "device_drag_losses": [float(l) for l in ds.last_losses],
         "seconds_device": round(t_gpu, 2), "seconds_oracle_cpu": round(t_cpu, 1),
     }
