@@ -99,9 +99,9 @@ int ishap_group_norm32(const void* x_nhwc_f16, const float* gamma, const float* 
     g.stats = stats;
   } else {
     // producer stand-in: copy = x * I through the implicit-GEMM kernel, whose epilogue gathers the per-channel sums
-    // the epilogue credits a tile's sums to ONE image (n_img = m0 / HW): a tile must not straddle images, whichever tile
-    // height (64 or 128 rows) the launcher picks
-    ISHAP_REQUIRE(C % 64 == 0 && (HW % 128 == 0 || N == 1) && ((long long)N * HW) % 64 == 0, "route 4: C % 64 == 0, H*W % 128 == 0 (N*H*W % 64 == 0 at batch 1)");
+    // the epilogue credits a tile's sums to ONE image (n_img = m0 / HW): a tile must not straddle images.  The launcher only
+    // takes 128-row tiles when H*W % 128 == 0 (igemm.hip), so 64-row tiles are what has to divide an image here
+    ISHAP_REQUIRE(C % 64 == 0 && ((long long)N * HW) % 64 == 0 && (N == 1 || HW % 64 == 0), "route 4: C % 64 == 0, N*H*W % 64 == 0, and H*W % 64 == 0 at batch > 1");
     const int rows = (int)align_up((size_t)C, 128);
     hipLaunchKernelGGL(identity_fill_kernel, dim3((rows * C + 255) / 256), dim3(256), 0, s, sc.ident, C, rows);
     ISHAP_CHECK_HIP(hipGetLastError());

@@ -68,9 +68,14 @@ def test_surface_matches_cpu_statement(case, method):
         assert v_d.shape[0] == S.mc_vertices(vol).shape[0]
     if case == "ties":
         # vertices of the edges that leave an at-level voxel coincide (t = 0), so nearest-neighbour matching is not a
-        # bijection here; the device emits in the statement's order (owner voxel, then axis), so compare index by index
-        assert float((v_d.cpu() - v_o).abs().max()) <= 2e-5
-        assert canon_faces(f_d) == canon_faces(f_o)
+        # bijection here.  Values are -1 / 0 / 1, so every coordinate is an exact multiple of 0.5: the vertex MULTISETS must
+        # be equal; marching cubes also emits in the statement's order (owner voxel, then axis): same faces index by index
+        def rows(v):
+            return sorted(map(tuple, v.cpu().tolist()))
+        assert rows(v_d) == rows(v_o)
+        if method == "marching_cubes":
+            assert float((v_d.cpu() - v_o).abs().max()) == 0.0
+            assert canon_faces(f_d) == canon_faces(f_o)
         at_corner = (v_o == v_o.round()).all(dim=1)
         assert int(at_corner.sum()) > 100          # the case does exercise the tie
         return

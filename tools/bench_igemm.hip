@@ -6,6 +6,7 @@
 #include <vector>
 #include "../ishapediting_amd/csrc/igemm2.hip"
 #include "../ishapediting_amd/csrc/igemm3.hip"
+#include "../ishapediting_amd/csrc/igemm4.hip"
 #include "../ishapediting_amd/csrc/igemm_skinny.hip"
 #include "../ishapediting_amd/csrc/igemm_small3.hip"
 hipEvent_t g_igemm_prof_start = nullptr, g_igemm_prof_stop = nullptr;
@@ -59,9 +60,11 @@ int main(int argc, char** argv) {
     if (gen == 5) { IgemmArgs b = a; b.ksplit = ksplit; b.ws = ws; igemm_small3_launch(b, 0, 0); }
     else if (gen == 4) igemm_skinny_launch(a, mt, 0);
     else if (gen == 3 && igemm3_applicable(a, big)) igemm3_launch_main(a, big, 0);
+    else if (gen == 6 && igemm4_applicable(a, big)) igemm4_launch_main(a, big, 0);
     else igemm2_launch_main(a, big, 0);
   };
-  if (gen == 4 || gen == 5) {                     // check against the tiled kernel
+  if (gen == 6 && !igemm4_applicable(a, big)) { printf("gen6: shape not applicable\n"); return 1; }
+  if (gen == 4 || gen == 5 || gen == 6) {         // check against the tiled kernel
     half_t* O1; hipMalloc(&O1, (size_t)M * Cout * 2);
     IgemmArgs b = a; b.out = O1; b.stat_out = nullptr; b.ksplit = 1;
     igemm2_launch_main(b, 0, 0);
@@ -69,7 +72,7 @@ int main(int argc, char** argv) {
     std::vector<half_t> o((size_t)M * Cout), o1((size_t)M * Cout);
     hipMemcpy(o.data(), O, o.size() * 2, hipMemcpyDeviceToHost);
     hipMemcpy(o1.data(), O1, o1.size() * 2, hipMemcpyDeviceToHost);
-    if (gen == 5 && ksplit > 1) {                 // partial tiles: add the slices up on the host
+    if ((gen == 5 || gen == 6) && ksplit > 1) {   // partial tiles: add the slices up on the host
       std::vector<float> sl((size_t)ksplit * M * Cout);
       hipMemcpy(sl.data(), ws, sl.size() * 4, hipMemcpyDeviceToHost);
       for (size_t i = 0; i < o.size(); ++i) { float v = 0; for (int z = 0; z < ksplit; ++z) v += sl[(size_t)z * M * Cout + i]; o[i] = (half_t)v; }
