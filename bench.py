@@ -283,7 +283,7 @@ def c4_real_shape_leg(device, shape_profile=None):
     ds.reconstruct(pts, occ, steps=steps)
     sync()
     tp = time.time() - tp0
-    NV = 8
+    NV = 11
     buf3 = (C.c_double * (NV * 3))()
     L.ishap_profile_end(buf3, NV)
     buf = C.create_string_buffer(1 << 17)
@@ -434,7 +434,7 @@ def main():
         L.ishap_profile_begin()
         one_edit(ds, src, tgt)
         torch.cuda.synchronize()
-        NV = 8
+        NV = 11
         out = (C.c_double * (NV * 3))()
         L.ishap_profile_end(out, NV)
         buf = C.create_string_buffer(1 << 17)
@@ -464,7 +464,8 @@ def main():
         names = ["igemm2_kernel<128, 128, 4, true, 1>", "igemm2_kernel<64, 64, 4, true, 1>",
                  "igemm2_kernel<128, 128, 4, false, 1>", "igemm2_kernel<64, 64, 4, false, 1>",
                  "igemm2_kernel<64, 64, 4, true, 2>", "igemm_skinny_kernel<*, false>", "igemm_kernel<128, 128, 32, 2, 2, true>",
-                 "conv3_small_kernel<4>"]
+                 "conv3_small_kernel<4>", "igemm4_kernel<128, 128, 128, 5, 3, 1>", "igemm4_kernel<64, 64, *, 6, 3, 1>",
+                 "igemm4_kernel<64, 64, *, 6, 3, 2>"]
         v = max(range(NV), key=lambda i: out[i * 3 + 1])
         launches, ms, flops = out[v * 3], out[v * 3 + 1], out[v * 3 + 2]
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

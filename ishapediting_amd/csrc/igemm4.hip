@@ -27,16 +27,38 @@
 __device__ __attribute__((aligned(128))) half_t g_zero_line4[64];   // zero-initialised: source of out-of-image rows
 typedef __attribute__((address_space(3))) void lds_void4;
 
-// activation slabs whose first K-step u lies in [s + 1, s + dist - 1], for s = ph (mod 3)
-constexpr int ig4_slabs_ahead(int ph, int dist) {
-  int c = 0;
-  for (int j = 1; j < dist; ++j) c += ((ph + j) % 3 == 0) ? 1 : 0;
-  return c;
+
+
+#ifndef IG4_PRO
+#define IG4_PRO 2              // K-steps issued before the first wait; the ring then fills two steps per iteration
+#endif
+
+#ifdef ABL_NOLOAD             // harness probe: the K loop without its DMA (addresses still computed; wrong results)
+#define IG4_DMA(src, dst) asm volatile("" ::"v"(src), "v"((unsigned)(unsigned long long)(lds_void4*)(dst)))
+#else
+#define IG4_DMA(src, dst) __builtin_amdgcn_global_load_lds((src), (lds_void4*)(dst), 16, 0, 0)
+#endif
+
+// s_waitcnt vmcnt takes an immediate; the loader waves know the count only at run time (block-uniform), hence the switch
+__device__ __forceinline__ void ig4_wait_vm(int n) {
+#define IG4_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    IG4_W(0) IG4_W(1) IG4_W(2) IG4_W(3) IG4_W(4) IG4_W(5) IG4_W(6) IG4_W(7) IG4_W(8) IG4_W(9) IG4_W(10) IG4_W(11) IG4_W(12)
+    IG4_W(13) IG4_W(14) IG4_W(15) IG4_W(16) IG4_W(17) IG4_W(18) IG4_W(19) IG4_W(20) IG4_W(21) IG4_W(22) IG4_W(23) IG4_W(24)
+    IG4_W(25) IG4_W(26) IG4_W(27) IG4_W(28) IG4_W(29) IG4_W(30) IG4_W(31) IG4_W(32) IG4_W(33) IG4_W(34) IG4_W(35) IG4_W(36)
+    IG4_W(37) IG4_W(38) IG4_W(39) IG4_W(40)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;     // never more than 40 outstanding by construction; safe anyway
+  }
+#undef IG4_W
 }
 
-template <int BM, int BN, int WD, int NSTW, int NSTX>
-__global__ __launch_bounds__(512) void igemm4_kernel(const void* hX, const void* hWt, int hK, int hCin, int hldx, int hldw, int hH, int hW,
-                                                     int hksplit, int hnwg, unsigned hpacked, IgemmArgs a) {
+// HALVES = 2: two 8-wave teams with their own rings split the K range and meet in the epilogue (igemm2's two-team form: a
+// CU that holds one workgroup gets two rings' worth of loads in flight and two MFMA waves per SIMD).
+// Folded second source (IgemmArgs::X2 / K2, a ResBlock's 1x1 skip convolution riding on its conv2): after the 3x3 part
+// the K loop goes on with K2 / 64 steps that each stage their own slab of X2 rows and read it unshifted.
+template <int BM, int BN, int WD, int NSTW, int NSTX, int HALVES = 1>
+__global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, const void* hWt, int hK, int hCin, int hldx, int hldw, int hH, int hW,
+                                                              int hksplit, int hnwg, unsigned hpacked, IgemmArgs a) {
   const IgemmHot h{(const half_t*)hX, (const half_t*)hWt, hK, hCin, hldx, hldw, hH, hW, hksplit, hnwg, hpacked};
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BK = 64;
@@ -44,22 +66,31 @@ __global__ __launch_bounds__(512) void igemm4_kernel(const void* hX, const void*
   constexpr int WI = BN / 8 / 4;                   // weight DMA instructions per loader wave per K-step
   constexpr int WSLOT = BN * BK;                   // halfs
   constexpr int XSLOT = (BM + 8) * BK;             // BM pixel rows + the zero row (row BM) + padding to a 1 KiB multiple
+  constexpr int RING = NSTW * WSLOT + NSTX * XSLOT;   // halfs per team
   constexpr int TMW = BM / 2, TNW = BN / 2, MT = TMW / 16, NT = TNW / 16;
-  constexpr int DIST = NSTW - 1;                   // K-steps in flight
+  constexpr int DIST = NSTW - 1;                   // K-steps in flight in the steady state
+  constexpr int PRO = DIST < IG4_PRO ? DIST : IG4_PRO;
   static_assert(NSTX * 3 >= DIST + 3, "activation ring too shallow for the prefetch distance");
   static_assert(BM % WD == 0 && WD % 16 == 0, "a tile is whole image rows; a 16-pixel MFMA sub-tile stays inside a row");
+  static_assert(DIST * (WI + XI) <= 40, "ig4_wait_vm covers up to 40 outstanding loads");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  half_t* const sW = reinterpret_cast<half_t*>(smem_raw);      // [NSTW][WSLOT]
-  half_t* const sX = sW + NSTW * WSLOT;                        // [NSTX][XSLOT]
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = HALVES == 2 ? wave_all >> 3 : 0;
+  const int wave8 = wave_all & 7;
+  half_t* const sW = reinterpret_cast<half_t*>(smem_raw) + team * RING;      // [NSTW][WSLOT]
+  half_t* const sX = sW + NSTW * WSLOT;                                      // [NSTX][XSLOT]
   const bool loader = wave8 >= 4;
   const int wave = wave8 & 3;
   const int wm = wave >> 1, wn = wave & 1;
-  IG_STAMP(0, wave8 == 0);
+  IG_STAMP(0, wave_all == 0);
   // zero rows (never written by the DMA): the source of a shifted pixel that falls off its image row
-  if (tid < NSTX * 8) *reinterpret_cast<f32x4*>(sX + (tid >> 3) * XSLOT + BM * BK + (tid & 7) * 8) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (tid < HALVES * NSTX * 8) {
+    const int tm = tid / (NSTX * 8), k = tid - tm * (NSTX * 8);
+    *reinterpret_cast<f32x4*>(reinterpret_cast<half_t*>(smem_raw) + tm * RING + NSTW * WSLOT + (k >> 3) * XSLOT + BM * BK + (k & 7) * 8) =
+        (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   int tile_m, tile_n, tile_z;
   {
     const int nx = h.ny_shift() >= 0 ? (1 << h.nx_shift()) : (int)gridDim.x, ny = h.ny_shift() >= 0 ? (1 << h.ny_shift()) : (int)gridDim.y;
@@ -81,65 +112,25 @@ __global__ __launch_bounds__(512) void igemm4_kernel(const void* hX, const void*
   const int ks_id = tile_z;                        // nbatch == 1 (launcher)
   const int H = h.H, HW = H * WD;
   const int NC = h.Cin / BK;                       // 64-channel chunks
+  const int NC2 = (int)(h.packed >> 25);           // 64-channel chunks of the folded second source (launcher: K2 / 64)
   const int G = 3 * NC;                            // slab groups (chunk, dy), three K-steps (dx) each
+  // this K slice: groups [g0, g1) of the 3x3 part; the LAST slice also takes the second source
   const int per = (G + h.ksplit - 1) / h.ksplit;
-  const int g0 = ks_id * per, g1 = min(G, g0 + per);
-  const int ns = max(0, g1 - g0) * 3;
+  int g0 = min(G, ks_id * per), g1 = min(G, g0 + per);
+  int c20 = 0, c21 = ks_id == h.ksplit - 1 ? NC2 : 0;
+  int nk_loop = (g1 - g0) * 3 + (c21 - c20);       // barrier count: identical for every wave of the workgroup
+  if (HALVES == 2) {
+    // team 0: the first ~half of the steps as whole groups; team 1: the other groups and the second source
+    const int ga = min(g1 - g0, (nk_loop + 3) / 6);
+    const int n0s = ga * 3, n1s = nk_loop - n0s;
+    nk_loop = max(n0s, n1s);
+    if (team == 0) { g1 = g0 + ga; c21 = c20; }
+    else g0 += ga;
+  }
+  const int ns3 = (g1 - g0) * 3, ns = ns3 + (c21 - c20);
   const int n_img = h.hw_shift() >= 0 ? (m0 >> h.hw_shift()) : m0 / HW;
   const int y0 = (m0 - n_img * HW) / WD;           // first image row of this tile
   __syncthreads();                                 // the zero rows are in place
-
-  // ---- loader state ----
-  const int lrow = lane >> 3, pch = lane & 7;
-  int xyr[XI], xcol[XI], xsc[XI];
-#pragma unroll
-  for (int i = 0; i < XI; ++i) {
-    const int row = (wave * XI + i) * 8 + lrow;    // pixel of the tile = LDS row of the slab
-    xyr[i] = y0 + row / WD;
-    xcol[i] = row % WD;
-    xsc[i] = (pch ^ (row & 7)) * 8;
-  }
-  const half_t* wp[WI];
-#pragma unroll
-  for (int i = 0; i < WI; ++i) {
-    const int row = (wave * WI + i) * 8 + lrow;
-    wp[i] = h.Wt + (long long)(n0 + row) * h.ldw + (pch ^ ((row >> 1) & 7)) * 8;
-  }
-  // issue head: next K-step to stage = (chunk hc, kernel row hdy, column hdx); weight columns (3 hdy + hdx) * Cin + 64 hc
-  int hc = g0 / 3, hdy = g0 - hc * 3, hdx = 0;
-  int hws = 0, hxs = 0;                            // ring slots of the head
-#pragma unroll
-  for (int i = 0; i < WI; ++i) wp[i] += (long long)(3 * hdy) * h.Cin + hc * BK;
-
-  auto issue = [&]() {
-    if (hdx == 0) {                                // a new slab: image rows y + hdy - 1 of chunk hc, staged once for dx = -1, 0, +1
-      half_t* x = sX + hxs * XSLOT;
-      const int dy = hdy - 1;
-#pragma unroll
-      for (int i = 0; i < XI; ++i) {
-        const int yy = xyr[i] + dy;
-        const bool ok = yy >= 0 && yy < H;
-        const int yc = ok ? yy : 0;
-        const long long pix = h.ups() ? ((long long)n_img * (HW >> 2) + (yc >> 1) * (WD >> 1) + (xcol[i] >> 1))
-                                      : ((long long)n_img * HW + yc * WD + xcol[i]);
-        const half_t* src = ok ? h.X + pix * h.ldx + hc * BK + xsc[i] : (const half_t*)g_zero_line4 + xsc[i];
-        __builtin_amdgcn_global_load_lds(src, (lds_void4*)(x + (wave * XI + i) * 8 * BK), 16, 0, 0);
-      }
-      hxs = hxs + 1 == NSTX ? 0 : hxs + 1;
-    }
-    half_t* w = sW + hws * WSLOT;
-#pragma unroll
-    for (int i = 0; i < WI; ++i) __builtin_amdgcn_global_load_lds(wp[i], (lds_void4*)(w + (wave * WI + i) * 8 * BK), 16, 0, 0);
-    hws = hws + 1 == NSTW ? 0 : hws + 1;
-    // advance the head: dx, then dy, then the chunk (taps are consecutive Cin-wide column blocks of the weight row)
-    long long dw = h.Cin;
-    if (++hdx == 3) {
-      hdx = 0;
-      if (++hdy == 3) { hdy = 0; ++hc; dw = BK - 8 * h.Cin; }
-    }
-#pragma unroll
-    for (int i = 0; i < WI; ++i) wp[i] += dw;
-  };
 
   f32x4 acc[NT][MT];
 #pragma unroll
@@ -147,26 +138,95 @@ __global__ __launch_bounds__(512) void igemm4_kernel(const void* hX, const void*
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  IG_STAMP(1, wave8 == 0);
+  IG_STAMP(1, wave_all == 0);
   if (loader) {
+    // ---- loader waves ----
+    const int lrow = lane >> 3, pch = lane & 7;
+    int xyr[XI], xcol[XI], xsc[XI];
 #pragma unroll
-    for (int s = 0; s < DIST; ++s)
-      if (s < ns) issue();
-    int ph = 0;
-    for (int s = 0; s < ns; ++s) {
-      // K-step s has landed when at most the loads issued after its weights are outstanding: steps s+1 .. s+DIST-1,
-      // WI each plus XI for every slab that starts among them
-      if (s + DIST <= ns) {
-        if (ph == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * WI + ig4_slabs_ahead(0, DIST) * XI) : "memory");
-        else if (ph == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * WI + ig4_slabs_ahead(1, DIST) * XI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * WI + ig4_slabs_ahead(2, DIST) * XI) : "memory");
+    for (int i = 0; i < XI; ++i) {
+      const int row = (wave * XI + i) * 8 + lrow;  // pixel of the tile = LDS row of the slab
+      xyr[i] = y0 + row / WD;
+      xcol[i] = row % WD;
+      xsc[i] = (pch ^ (row & 7)) * 8;
+    }
+    const half_t* wrow[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int row = (wave * WI + i) * 8 + lrow;
+      wrow[i] = h.Wt + (long long)(n0 + row) * h.ldw + (pch ^ ((row >> 1) & 7)) * 8;
+    }
+    // issue head: next K-step to stage.  3x3 part: (chunk, kernel row hdy, column hdx), weight columns
+    // (3 hdy + hdx) * Cin + 64 chunk; second source: weight columns 9 Cin + 64 chunk
+    int xch = g0 / 3, hdy = g0 - xch * 3, hdx = 0;  // xch: 64-channel chunk the next slab is cut from (X, then X2)
+    long long wcol = (long long)(3 * hdy) * h.Cin + xch * BK;
+    int hws = 0, hxs = 0;                          // ring slots of the head
+    int issued = 0, tot = 0;                       // K-steps / DMA instructions issued by this wave
+    auto issue = [&]() {
+      if (issued == ns3) { xch = c20; wcol = 9LL * h.Cin + (long long)c20 * BK; }      // the second source begins
+      long long dw;
+      if (issued >= ns3) {                         // a slab of X2 rows (plain rows of the tile, no shift), one K-step
+        half_t* x = sX + hxs * XSLOT;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+          const half_t* src = a.X2 + (long long)(m0 + (wave * XI + i) * 8 + lrow) * a.ldx2 + xch * BK + xsc[i];
+          IG4_DMA(src, x + (wave * XI + i) * 8 * BK);
+        }
+        hxs = hxs + 1 == NSTX ? 0 : hxs + 1;
+        ++xch;
+        dw = BK;
+        tot += XI;
       } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (hdx == 0) {                            // a new slab: image rows y + hdy - 1 of chunk xch, staged once for dx = -1, 0, +1
+          half_t* x = sX + hxs * XSLOT;
+          const int dy = hdy - 1;
+#pragma unroll
+          for (int i = 0; i < XI; ++i) {
+            const int yy = xyr[i] + dy;
+            const bool ok = yy >= 0 && yy < H;
+            const int yc = ok ? yy : 0;
+            const long long pix = h.ups() ? ((long long)n_img * (HW >> 2) + (yc >> 1) * (WD >> 1) + (xcol[i] >> 1))
+                                          : ((long long)n_img * HW + yc * WD + xcol[i]);
+            const half_t* src = ok ? h.X + pix * h.ldx + xch * BK + xsc[i] : (const half_t*)g_zero_line4 + xsc[i];
+            IG4_DMA(src, x + (wave * XI + i) * 8 * BK);
+          }
+          hxs = hxs + 1 == NSTX ? 0 : hxs + 1;
+          tot += XI;
+        }
+        dw = h.Cin;                                // taps are consecutive Cin-wide column blocks of the weight row
+        if (++hdx == 3) {
+          hdx = 0;
+          if (++hdy == 3) { hdy = 0; ++xch; dw = BK - 8LL * h.Cin; }
+        }
+      }
+      half_t* w = sW + hws * WSLOT;
+#pragma unroll
+      for (int i = 0; i < WI; ++i) IG4_DMA(wrow[i] + wcol, w + (wave * WI + i) * 8 * BK);
+      hws = hws + 1 == NSTW ? 0 : hws + 1;
+      wcol += dw;
+      tot += WI;
+      ++issued;
+    };
+    // Everything that may be issued once the reads of K-steps < s are complete (s = -1: the prologue).  Step u needs its
+    // weight slot (u <= s + DIST) and, when it starts a slab, a dead slab slot: always true in the 3x3 part (3 NSTX >= DIST + 3),
+    // u <= s + NSTX - 1 for the one-step slabs of the second source.  The ring is NOT filled at once: a prologue of DIST
+    // stages from every CU at the same moment (HBM-cold weights) comes back at the burst rate of the whole chip and stage 0
+    // lands last-ish (9 800 cycles for 112 KB per CU against 4 400 for igemm2's 96 KB, in-kernel stamps) -- PRO steps first,
+    // then two more per iteration until DIST are in flight.
+    auto issue_after = [&](int s) {
+      while (issued < ns && issued <= s + DIST && issued < PRO + 2 * (s + 1) && (issued < ns3 || issued <= s + NSTX - 1)) issue();
+    };
+    issue_after(-1);
+    for (int s = 0; s < nk_loop; ++s) {
+      if (s < ns) {
+        // K-step s has landed when only the loads issued after its weights are outstanding (loads complete in order):
+        // everything issued so far minus everything up to and including step s
+        const int slabs = s < ns3 ? s / 3 + 1 : ns3 / 3 + (s - ns3 + 1);
+        ig4_wait_vm(tot - ((s + 1) * WI + slabs * XI));
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (s + DIST < ns) issue();
-      ph = ph == 2 ? 0 : ph + 1;
+      issue_after(s);
     }
   } else {
     // ---- MFMA waves: fragment byte addresses within slot 0 of each ring, per 32-deep half; activations per shift ----
@@ -232,9 +292,10 @@ __global__ __launch_bounds__(512) void igemm4_kernel(const void* hX, const void*
 #endif
     };
     using std::integral_constant;
-    // one K-step at shift DX (= dx + 1): second half read under the MFMAs of the first, first half of the next step
-    // (shift (DX + 1) % 3, next weight slot, next slab slot when DX == 2) read right after its barrier
-    auto step = [&](auto DX, int s) {
+    // one K-step at shift DX (= dx + 1): second half read under the MFMAs of the first, first half of the next step read
+    // right after its barrier.  SLAB_ENDS: the step is the last one on its slab (dx = +1, or any step of the second
+    // source).  The next step reads at shift (DX + 1) % 3 inside the 3x3 part and unshifted (1) in the second source.
+    auto step = [&](auto DX, auto SLAB_ENDS, int s) {
       constexpr int d = decltype(DX)::value;
       read_half(DX, 1, sw_off, sx_off, xb, wb);
       wait_frags(integral_constant<int, MT + NT>{}, xa, wa);
@@ -243,38 +304,69 @@ __global__ __launch_bounds__(512) void igemm4_kernel(const void* hX, const void*
       __builtin_amdgcn_sched_barrier(0);
       wait_frags(integral_constant<int, 0>{}, xb, wb);
       sw_off = sw_off + WSLOT * 2 == NSTW * WSLOT * 2 ? 0u : sw_off + WSLOT * 2;
-      if (d == 2) sx_off = sx_off + XSLOT * 2 == NSTX * XSLOT * 2 ? 0u : sx_off + XSLOT * 2;
-      if (s + 1 < ns) {
+      if (decltype(SLAB_ENDS)::value) sx_off = sx_off + XSLOT * 2 == NSTX * XSLOT * 2 ? 0u : sx_off + XSLOT * 2;
+      if (s + 1 < nk_loop) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        read_half(integral_constant<int, (d + 1) % 3>{}, 0, sw_off, sx_off, xa, wa);
+        if (s + 1 < ns) {
+          if (decltype(SLAB_ENDS)::value && s + 1 >= ns3) read_half(integral_constant<int, 1>{}, 0, sw_off, sx_off, xa, wa);
+          else read_half(integral_constant<int, (d + 1) % 3>{}, 0, sw_off, sx_off, xa, wa);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       mfma_half(xb, wb);
     };
-    if (ns > 0) __builtin_amdgcn_s_barrier();      // step 0 has landed (the loader waves pass ns barriers, so do these)
+    if (nk_loop > 0) __builtin_amdgcn_s_barrier();      // step 0 has landed (every wave passes nk_loop barriers)
     asm volatile("" ::: "memory");
-    IG_STAMP(2, wave8 == 0);
-    if (ns > 0) read_half(integral_constant<int, 0>{}, 0, sw_off, sx_off, xa, wa);
-    for (int s = 0; s < ns; s += 3) {
-      step(integral_constant<int, 0>{}, s);
-      step(integral_constant<int, 1>{}, s + 1);
-      step(integral_constant<int, 2>{}, s + 2);
+    IG_STAMP(2, wave_all == 0);
+    if (ns > 0) {
+      if (ns3 > 0) read_half(integral_constant<int, 0>{}, 0, sw_off, sx_off, xa, wa);
+      else read_half(integral_constant<int, 1>{}, 0, sw_off, sx_off, xa, wa);
+    }
+    int s = 0;
+    for (; s < ns3; s += 3) {
+      step(integral_constant<int, 0>{}, std::false_type{}, s);
+      step(integral_constant<int, 1>{}, std::false_type{}, s + 1);
+      step(integral_constant<int, 2>{}, std::true_type{}, s + 2);
+    }
+    for (; s < ns; ++s) step(integral_constant<int, 1>{}, std::true_type{}, s);
+    for (; s < nk_loop; ++s)                       // the shorter team of a two-team workgroup idles through the last barriers
+      if (s + 1 < nk_loop) __builtin_amdgcn_s_barrier();
+  }
+  IG_STAMP(3, wave_all == 0);
+  // two teams on the staged path: both teams' partial tiles go straight into the epilogue, which adds them row by row
+  const bool merge_in_epilogue = HALVES == 2 && igemm_epilogue_is_staged(a, 0);
+  if (HALVES == 2 && !merge_in_epilogue) {
+    // team 1 hands its accumulators to team 0 through (its own, now idle) ring memory
+    f32x4* red = reinterpret_cast<f32x4*>(reinterpret_cast<half_t*>(smem_raw) + RING);
+    __syncthreads();                               // every fragment read of the K loop is done
+    if (!loader && team == 1) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) red[((i * MT + j) * 4 + wave) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (!loader && team == 0) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] += red[((i * MT + j) * 4 + wave) * 64 + lane];
     }
   }
-  IG_STAMP(3, wave8 == 0);
-  IG_STAMP(4, wave8 == 0);
-  igemm_epilogue<MT, NT, TMW, TNW, BN, 512>(a, acc, m0, n0, wm, wn, lane, 0, ks_id, reinterpret_cast<float*>(smem_raw), !loader);
+  IG_STAMP(4, wave_all == 0);
+  igemm_epilogue<MT, NT, TMW, TNW, BN, 512 * HALVES>(a, acc, m0, n0, wm, wn, lane, 0, ks_id, reinterpret_cast<float*>(smem_raw),
+                                                     !loader && (team == 0 || merge_in_epilogue), merge_in_epilogue ? team : -1);
 #endif
 }
 
-template <int BM, int BN, int WD, int NSTW, int NSTX>
+template <int BM, int BN, int WD, int NSTW, int NSTX, int HALVES = 1>
 static int launch4(const IgemmArgs& a, hipStream_t s) {
-  constexpr size_t ring = (size_t)(NSTW * BN * 64 + NSTX * (BM + 8) * 64) * sizeof(half_t);
-  constexpr size_t epi = (size_t)BM * (BN + 4) * 4 + (size_t)BM * (BN + 8) * 2 + 16384;      // staged epilogue: fp32 tile + fp16 tile + partial sums
+  constexpr size_t ring = (size_t)HALVES * (NSTW * BN * 64 + NSTX * (BM + 8) * 64) * sizeof(half_t);
+  constexpr size_t epi = (size_t)HALVES * BM * (BN + 4) * 4 + (size_t)BM * (BN + 8) * 2 + 16384;      // staged epilogue: fp32 tile(s) + fp16 tile + partial sums
   constexpr size_t smem = ring > epi ? ring : epi;
   static_assert(smem <= 163840, "LDS");
-  auto kern = igemm4_kernel<BM, BN, WD, NSTW, NSTX>;
+  auto kern = igemm4_kernel<BM, BN, WD, NSTW, NSTX, HALVES>;
   ISHAP_TRY(ishap_set_max_lds((const void*)kern, (int)smem));
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.ksplit);
   IgemmArgs b = a;
@@ -289,35 +381,54 @@ static int launch4(const IgemmArgs& a, hipStream_t s) {
   h.X = b.X; h.Wt = b.Wt; h.K = b.K; h.Cin = b.Cin; h.ldx = b.ldx; h.ldw = b.ldw; h.H = b.H; h.W = b.W; h.ksplit = b.ksplit;
   h.nwg = (int)(grid.x * grid.y * grid.z);
   h.packed = (unsigned)(b.w_shift & 0x3f) | (unsigned)(b.hw_shift & 0x3f) << 6 | (unsigned)(b.nx_shift & 0x3f) << 12 |
-             (unsigned)(b.ny_shift & 0x3f) << 18 | (b.ups ? 1u << 24 : 0u);
-  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(512), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0,
+             (unsigned)(b.ny_shift & 0x3f) << 18 | (b.ups ? 1u << 24 : 0u) | (unsigned)(b.K2 / 64) << 25;
+  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(512 * HALVES), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0,
                                                 (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, b);
-  else hipLaunchKernelGGL(kern, grid, dim3(512), smem, s,
+  else hipLaunchKernelGGL(kern, grid, dim3(512 * HALVES), smem, s,
                           (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, b);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-// the shapes this kernel takes: plain 3x3 (no folded second source), Cin % 64 == 0, one image per tile, a tile = whole image
-// rows of a map 32 / 64 / 128 pixels wide
+// the shapes this kernel takes: 3x3 (optionally with the folded 1x1 second source), Cin % 64 == 0, one image per tile, a tile =
+// whole image rows of a map 16 / 32 / 64 / 128 pixels wide
 bool igemm4_applicable(const IgemmArgs& a, bool big) {
   const int BM = big ? 128 : 64;
-  if (!a.conv3 || a.nbatch != 1 || a.Cin % 64 != 0 || a.K2 != 0 || a.K != 9 * a.Cin) return false;
-  if (big ? a.W != 128 : (a.W != 32 && a.W != 64)) return false;
+  if (!a.conv3 || a.nbatch != 1 || a.Cin % 64 != 0 || a.K != 9 * a.Cin + a.K2) return false;
+  if (a.K2 && (a.K2 % 64 != 0 || a.K2 / 64 > 127 || !a.X2)) return false;
+  if (big ? a.W != 128 : (a.W != 16 && a.W != 32 && a.W != 64)) return false;
   if (BM % a.W != 0 || (a.H * a.W) % BM != 0 || a.M % BM != 0) return false;
   return true;
 }
 
 #ifndef IG4_BIG_W
-#define IG4_BIG_W 6
+#define IG4_BIG_W 5
 #define IG4_BIG_X 3
 #endif
 #ifndef IG4_SMALL_W
-#define IG4_SMALL_W 8
-#define IG4_SMALL_X 4
+#define IG4_SMALL_W 6
+#define IG4_SMALL_X 3
 #endif
+#ifndef IG4_TEAM_W
+#define IG4_TEAM_W 6
+#define IG4_TEAM_X 3
+#endif
+// two teams: one workgroup per CU at most (<= 256 tiles) and a K slice of at least four chunks (two per team)
+bool igemm4_two_teams(const IgemmArgs& a, bool big) {
+  static const int on = [] { const char* e = getenv("ISHAP_IG4_TEAMS"); return e ? atoi(e) : 2; }();
+  if (big || on != 2) return false;
+  const long long tiles = (long long)(a.M / 64) * ((a.N + 63) / 64) * a.ksplit;
+  const int groups = (3 * (a.Cin / 64) + a.ksplit - 1) / a.ksplit;
+  return tiles <= 256 && 3 * groups + a.K2 / 64 >= 18;
+}
 int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
   if (big) return launch4<128, 128, 128, IG4_BIG_W, IG4_BIG_X>(a, s);
+  if (igemm4_two_teams(a, big)) {
+    if (a.W == 64) return launch4<64, 64, 64, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);
+    if (a.W == 32) return launch4<64, 64, 32, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);
+    return launch4<64, 64, 16, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);
+  }
   if (a.W == 64) return launch4<64, 64, 64, IG4_SMALL_W, IG4_SMALL_X>(a, s);
-  return launch4<64, 64, 32, IG4_SMALL_W, IG4_SMALL_X>(a, s);
+  if (a.W == 32) return launch4<64, 64, 32, IG4_SMALL_W, IG4_SMALL_X>(a, s);
+  return launch4<64, 64, 16, IG4_SMALL_W, IG4_SMALL_X>(a, s);
 }

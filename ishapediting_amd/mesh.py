@@ -342,7 +342,12 @@ def sample_surface_points(verts: torch.Tensor, tris: torch.Tensor, n: int, gener
     L = _lib.lib()
     with torch.cuda.device(dev):
         _lib.check(L.ishap_mesh_tri_areas(v.data_ptr(), t.data_ptr(), t.shape[0], areas.data_ptr(), _lib.stream_ptr(dev)))
-        idx = torch.multinomial(areas.double().cpu(), n, replacement=True, generator=generator).to(device=dev, dtype=torch.int32)
+        if areas.numel() <= (1 << 24):
+            idx = torch.multinomial(areas.double().cpu(), n, replacement=True, generator=generator).to(device=dev, dtype=torch.int32)
+        else:      # torch.multinomial stops at 2^24 categories (a 256^3 noise surface has 3e7 triangles): inverse CDF instead
+            cdf = torch.cumsum(areas.double().cpu(), 0)
+            u = torch.rand(n, generator=generator, dtype=torch.float64) * cdf[-1]
+            idx = torch.searchsorted(cdf, u).clamp_(max=areas.numel() - 1).to(device=dev, dtype=torch.int32)
         uw = torch.rand((n, 2), generator=generator).to(dev).contiguous()
         pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
         _lib.check(L.ishap_mesh_points_on_tris(v.data_ptr(), t.data_ptr(), idx.data_ptr(), uw.data_ptr(), n, pts.data_ptr(),

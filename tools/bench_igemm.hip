@@ -30,7 +30,8 @@ int main(int argc, char** argv) {
   int ksize = argc > 7 ? atoi(argv[7]) : 3;
   int stats = argc > 8 ? atoi(argv[8]) : 0;      // 1: accumulate the per-channel GroupNorm statistics in the epilogue
   int nbuf = argc > 9 ? atoi(argv[9]) : 1;       // weight copies cycled through (> 256 MB in total = HBM-cold weights, as in the network)
-  int M = H * H, K = ksize * ksize * Cin;
+  int k2 = argc > 10 ? atoi(argv[10]) : 0;       // channels of a folded 1x1 second source (3x3 launches): K = 9 Cin + k2
+  int M = H * H, K = ksize * ksize * Cin + k2;
 #ifdef IG_STAMPS
   const int nwg_st = 8192;                         // before ANY launch: the stamped kernels write through this pointer
   unsigned long long* sb; hipMalloc(&sb, (size_t)nwg_st * 16 * 8); hipMemset(sb, 0, (size_t)nwg_st * 16 * 8);
@@ -49,6 +50,13 @@ int main(int argc, char** argv) {
   IgemmArgs a;
   a.X = X; a.Wt = W; a.out = O; a.M = M; a.N = Cout; a.K = K; a.conv3 = ksize == 3; a.Cin = Cin; a.ldx = Cin; a.ldw = K; a.ldo = Cout;
   a.H = H; a.W = H; a.ksplit = ksplit; a.ws = ws;
+  if (k2) {
+    half_t* X2; hipMalloc(&X2, (size_t)M * k2 * 2);
+    std::vector<half_t> hx2((size_t)M * k2);
+    for (auto& v : hx2) v = (half_t)((rand() % 2001 - 1000) / 1000.f);
+    hipMemcpy(X2, hx2.data(), hx2.size() * 2, hipMemcpyHostToDevice);
+    a.X2 = X2; a.ldx2 = k2; a.K2 = k2;
+  }
   long long* st = nullptr;
   if (stats) { hipMalloc(&st, (size_t)Cout * 2 * 8 * 64); hipMemset(st, 0, (size_t)Cout * 2 * 8 * 64); a.stat_out = st; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -1,0 +1,22 @@
+#!/bin/bash
+# igemm2 (gen 2) vs igemm4 (gen 6), second round: generic vmcnt accounting, ramped ring fill, two-team form, folded second source
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+O=gpurun_out/ig4_probe2.txt
+mkdir -p gpurun_out; : > $O
+run() { v=$1; shift; echo -n "$v teams=${ISHAP_IG4_TEAMS:-2} | $@ | " >> $O; timeout -k 5 60 ./build/ig4_$v "$@" 2>&1 | grep -E "^gen|tiled" | tr '\n' ' ' >> $O; echo >> $O; }
+#        H Cin Cout big ks k2
+for shape in "128 256 256 1 1 0" "128 512 256 1 1 0" "128 256 256 1 1 512" "64 256 256 0 1 0" "64 256 256 0 1 512" "64 256 256 0 1 768" "64 512 256 0 1 0" "64 512 512 0 1 0" "64 768 256 0 1 0" \
+             "32 512 512 0 2 0" "32 512 512 0 2 768" "32 512 512 0 2 1024" "32 768 512 0 2 0" "32 256 512 0 2 0" "16 768 768 0 8 0" "16 768 768 0 4 0" "16 1536 768 0 8 0"; do
+  set -- $shape
+  cold=$(( 300 * 256 * 256 / ($2 * $3) + 1 ))
+  run d $1 $2 $3 $4 $5 2 3 1 $cold $6
+  for v in d noramp pro1 pro3 deep shal; do run $v $1 $2 $3 $4 $5 6 3 1 $cold $6; done
+  run noload $1 $2 $3 $4 $5 6 3 1 $cold $6
+  run nomfma $1 $2 $3 $4 $5 6 3 1 $cold $6
+  if [ $4 = 0 ]; then ISHAP_IG4_TEAMS=0 run d $1 $2 $3 $4 $5 6 3 1 $cold $6; fi
+done
+for shape in "128 256 256 1 1" "64 256 256 0 1"; do
+  set -- $shape
+  echo "== stamps gen6 $shape" >> $O; timeout -k 5 60 ./build/ig4_st $1 $2 $3 $4 $5 6 3 1 300 >> $O 2>&1
+done
+tail -3 $O

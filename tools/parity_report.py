@@ -177,6 +177,13 @@ def main():
     # surfaces of millions of vertices the query side is a 200 000-point random subset (unbiased, mesh.chamfer_distance)
     allv = lambda x, y: chamfer_distance(x.to(dev), y.to(dev), None, query_num=200000 if big else None) if min(x.shape[0], y.shape[0]) > 0 else None
     dl, ol = np.array([float(l) for l in ds.last_losses]), np.array(losses)
+
+    def guarded(name, fn):            # a secondary section must not cost the (minutes-long) oracle run its primary numbers
+        try:
+            return fn()
+        except Exception as e:        # noqa: BLE001
+            print(f"section {name} failed: {e!r}", file=sys.stderr, flush=True)
+            return {f"{name}_error": repr(e)}
     rep = {
         "config": {"T": a.T, "guided_steps": a.W, "decode_res": a.res, "handles": 3, "scale": scale, "cof": cof,
                    "weights": "synthetic seed 1234 (421M params)", "feature_range": "+-0.05"},
@@ -196,11 +203,11 @@ def main():
         "NULL_latent_rel_l2_oracle_edit_vs_oracle_unedited": rel(img, final),
         "chamfer_20k_samples_FLOOR_LIMITED": chamfer_distance(va.to(dev), vb.to(dev), 20000) if min(va.shape[0], vb.shape[0]) > 0 else None,
         "chamfer_20k_sampling_floor": chamfer_distance(vb.to(dev), vb.clone().to(dev), 20000, seed=1),
-        **surface_report(vol_gpu, vol_cpu, va, vb, a.res, dev, extract_surface, mesh_chamfer),
-        "shape_like_edit_attenuated": shape_like_report(dec_sd, dev, 128, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices,
-                                                        edit_dev=lat_gpu, edit_cpu=final),
-        "shape_like_edit_full_amplitude": shape_like_report(dec_sd, dev, 128, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices,
-                                                            edit_dev=lat_gpu, edit_cpu=final, amp=0.05, lowpass_k=16),
+        **guarded("surface_report", lambda: surface_report(vol_gpu, vol_cpu, va, vb, a.res, dev, extract_surface, mesh_chamfer)),
+        "shape_like_edit_attenuated": guarded("shape_like_edit_attenuated", lambda: shape_like_report(
+            dec_sd, dev, 128, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices, edit_dev=lat_gpu, edit_cpu=final)),
+        "shape_like_edit_full_amplitude": guarded("shape_like_edit_full_amplitude", lambda: shape_like_report(
+            dec_sd, dev, 128, extract_surface, mesh_chamfer, chamfer_distance, mc_vertices, edit_dev=lat_gpu, edit_cpu=final, amp=0.05, lowpass_k=16)),
         "drag_loss_max_rel_diff": float(np.max(np.abs(dl - ol) / np.maximum(np.abs(ol), 1e-30))) if len(dl) == len(ol) and len(ol) else None,
         "oracle_drag_losses": losses, "device_drag_losses": [float(l) for l in ds.last_losses],
         "seconds_device": round(t_gpu, 2), "seconds_oracle_cpu": round(t_cpu, 1),
