@@ -29,6 +29,13 @@ typedef __attribute__((address_space(3))) void lds_void4;
 
 
 
+// loads a loader wave issues for K-steps a .. b of a slice's 3x3 part (WI weight instructions each, XI more where a slab starts)
+constexpr int ig4_loads(int a, int b, int wi, int xi) {
+  int c = 0;
+  for (int u = a; u <= b; ++u) c += wi + ((u % 3 == 0) ? xi : 0);
+  return c;
+}
+
 #ifndef IG4_PRO
 #define IG4_PRO 2              // K-steps issued before the first wait; the ring then fills two steps per iteration
 #endif
@@ -70,6 +77,8 @@ __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, co
   constexpr int TMW = BM / 2, TNW = BN / 2, MT = TMW / 16, NT = TNW / 16;
   constexpr int DIST = NSTW - 1;                   // K-steps in flight in the steady state
   constexpr int PRO = DIST < IG4_PRO ? DIST : IG4_PRO;
+  constexpr int RAMP = DIST - PRO;                 // iterations that issue two K-steps
+  static_assert(RAMP <= 6, "ramp iterations are peeled by hand");
   static_assert(NSTX * 3 >= DIST + 3, "activation ring too shallow for the prefetch distance");
   static_assert(BM % WD == 0 && WD % 16 == 0, "a tile is whole image rows; a 16-pixel MFMA sub-tile stays inside a row");
   static_assert(DIST * (WI + XI) <= 40, "ig4_wait_vm covers up to 40 outstanding loads");
@@ -140,87 +149,153 @@ __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, co
 
   IG_STAMP(1, wave_all == 0);
   if (loader) {
-    // ---- loader waves ----
+    // ---- loader waves.  They pace the K loop (every step ends at a barrier they reach after their waits and issues), and a
+    // wave retires an instruction every ~5 cycles at best: the per-step path is kept to the DMA instructions, one 64-bit add
+    // per pointer and a few scalar instructions -- a first generic version of this loop (run-time load counts, addresses
+    // rebuilt per slab) cost 10-25 % of the whole launch (profiles/round4_igemm4_probe_v3.txt, column noload). ----
     const int lrow = lane >> 3, pch = lane & 7;
-    int xyr[XI], xcol[XI], xsc[XI];
+    // slab source of the issue head (chunk hc, kernel row hdy): xp = this lane's 16 bytes of pixel (y + hdy - 1, x), advanced by
+    // block-uniform deltas from slab to slab whether or not the row exists; a row outside the image reads zp (a zero line)
+    int hc = g0 / 3, hdy = g0 - hc * 3, hdx = 0;   // issue head of the 3x3 part: chunk, kernel row, column
+    const half_t* xp[XI];
+    const half_t* zp[XI];
+    int yr[XI], xc[XI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int row = (wave * XI + i) * 8 + lrow;  // pixel of the tile = LDS row of the slab
-      xyr[i] = y0 + row / WD;
-      xcol[i] = row % WD;
-      xsc[i] = (pch ^ (row & 7)) * 8;
+      yr[i] = y0 + row / WD;
+      xc[i] = row % WD;
+      const int sc = (pch ^ (row & 7)) * 8;
+      zp[i] = (const half_t*)g_zero_line4 + sc;
+      xp[i] = h.X + ((long long)n_img * HW + (long long)(yr[i] + hdy - 1) * WD + xc[i]) * h.ldx + hc * BK + sc;
     }
-    const half_t* wrow[WI];
+    const long long x_row = (long long)WD * h.ldx;          // one image row down
+    const half_t* wp[WI];
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       const int row = (wave * WI + i) * 8 + lrow;
-      wrow[i] = h.Wt + (long long)(n0 + row) * h.ldw + (pch ^ ((row >> 1) & 7)) * 8;
+      wp[i] = h.Wt + (long long)(n0 + row) * h.ldw + (pch ^ ((row >> 1) & 7)) * 8 + (long long)(3 * hdy) * h.Cin + hc * BK;
     }
-    // issue head: next K-step to stage.  3x3 part: (chunk, kernel row hdy, column hdx), weight columns
-    // (3 hdy + hdx) * Cin + 64 chunk; second source: weight columns 9 Cin + 64 chunk
-    int xch = g0 / 3, hdy = g0 - xch * 3, hdx = 0;  // xch: 64-channel chunk the next slab is cut from (X, then X2)
-    long long wcol = (long long)(3 * hdy) * h.Cin + xch * BK;
     int hws = 0, hxs = 0;                          // ring slots of the head
     int issued = 0, tot = 0;                       // K-steps / DMA instructions issued by this wave
-    auto issue = [&]() {
-      if (issued == ns3) { xch = c20; wcol = 9LL * h.Cin + (long long)c20 * BK; }      // the second source begins
-      long long dw;
-      if (issued >= ns3) {                         // a slab of X2 rows (plain rows of the tile, no shift), one K-step
+    auto issue3 = [&]() __attribute__((always_inline)) {      // one K-step of the 3x3 part
+      if (hdx == 0) {                              // a new slab: image rows y + hdy - 1 of chunk hc, staged once for dx = -1, 0, +1
         half_t* x = sX + hxs * XSLOT;
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-          const half_t* src = a.X2 + (long long)(m0 + (wave * XI + i) * 8 + lrow) * a.ldx2 + xch * BK + xsc[i];
-          IG4_DMA(src, x + (wave * XI + i) * 8 * BK);
-        }
-        hxs = hxs + 1 == NSTX ? 0 : hxs + 1;
-        ++xch;
-        dw = BK;
-        tot += XI;
-      } else {
-        if (hdx == 0) {                            // a new slab: image rows y + hdy - 1 of chunk xch, staged once for dx = -1, 0, +1
-          half_t* x = sX + hxs * XSLOT;
-          const int dy = hdy - 1;
+        const int dy = hdy - 1;
+        if (h.ups()) {                             // nearest-x2 upsampled source (4 launches per forward): addresses from scratch
 #pragma unroll
           for (int i = 0; i < XI; ++i) {
-            const int yy = xyr[i] + dy;
+            const int yy = yr[i] + dy;
             const bool ok = yy >= 0 && yy < H;
             const int yc = ok ? yy : 0;
-            const long long pix = h.ups() ? ((long long)n_img * (HW >> 2) + (yc >> 1) * (WD >> 1) + (xcol[i] >> 1))
-                                          : ((long long)n_img * HW + yc * WD + xcol[i]);
-            const half_t* src = ok ? h.X + pix * h.ldx + xch * BK + xsc[i] : (const half_t*)g_zero_line4 + xsc[i];
+            const long long pix = (long long)n_img * (HW >> 2) + (yc >> 1) * (WD >> 1) + (xc[i] >> 1);
+            const half_t* src = ok ? h.X + pix * h.ldx + hc * BK + (zp[i] - (const half_t*)g_zero_line4) : zp[i];
             IG4_DMA(src, x + (wave * XI + i) * 8 * BK);
           }
-          hxs = hxs + 1 == NSTX ? 0 : hxs + 1;
-          tot += XI;
+        } else {
+          const long long dxp = hdy == 2 ? BK - 2 * x_row : x_row;      // to the next slab: a row down, or up two and a chunk on
+#pragma unroll
+          for (int i = 0; i < XI; ++i) {
+            const half_t* src = (unsigned)(yr[i] + dy) < (unsigned)H ? xp[i] : zp[i];
+            IG4_DMA(src, x + (wave * XI + i) * 8 * BK);
+            xp[i] += dxp;
+          }
         }
-        dw = h.Cin;                                // taps are consecutive Cin-wide column blocks of the weight row
-        if (++hdx == 3) {
-          hdx = 0;
-          if (++hdy == 3) { hdy = 0; ++xch; dw = BK - 8LL * h.Cin; }
-        }
+        hxs = hxs + 1 == NSTX ? 0 : hxs + 1;
+        tot += XI;
       }
       half_t* w = sW + hws * WSLOT;
 #pragma unroll
-      for (int i = 0; i < WI; ++i) IG4_DMA(wrow[i] + wcol, w + (wave * WI + i) * 8 * BK);
+      for (int i = 0; i < WI; ++i) IG4_DMA(wp[i], w + (wave * WI + i) * 8 * BK);
       hws = hws + 1 == NSTW ? 0 : hws + 1;
-      wcol += dw;
+      long long dw = h.Cin;                        // taps are consecutive Cin-wide column blocks of the weight row
+      if (++hdx == 3) {
+        hdx = 0;
+        if (++hdy == 3) { hdy = 0; ++hc; dw = BK - 8LL * h.Cin; }
+      }
+#pragma unroll
+      for (int i = 0; i < WI; ++i) wp[i] += dw;
       tot += WI;
       ++issued;
     };
+    auto issue2 = [&]() __attribute__((always_inline)) {      // one K-step of the folded second source: its own slab of X2 rows, unshifted
+      if (issued == ns3) {                         // entering it: re-aim the pointers (X2 rows; the last columns of the weight rows)
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+          const int row = (wave * XI + i) * 8 + lrow;
+          xp[i] = a.X2 + (long long)(m0 + row) * a.ldx2 + c20 * BK + (pch ^ (row & 7)) * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+          const int row = (wave * WI + i) * 8 + lrow;
+          wp[i] = h.Wt + (long long)(n0 + row) * h.ldw + (pch ^ ((row >> 1) & 7)) * 8 + 9LL * h.Cin + (long long)c20 * BK;
+        }
+      }
+      half_t* x = sX + hxs * XSLOT;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) { IG4_DMA(xp[i], x + (wave * XI + i) * 8 * BK); xp[i] += BK; }
+      hxs = hxs + 1 == NSTX ? 0 : hxs + 1;
+      half_t* w = sW + hws * WSLOT;
+#pragma unroll
+      for (int i = 0; i < WI; ++i) { IG4_DMA(wp[i], w + (wave * WI + i) * 8 * BK); wp[i] += BK; }
+      hws = hws + 1 == NSTW ? 0 : hws + 1;
+      tot += XI + WI;
+      ++issued;
+    };
+    using std::integral_constant;
     // Everything that may be issued once the reads of K-steps < s are complete (s = -1: the prologue).  Step u needs its
     // weight slot (u <= s + DIST) and, when it starts a slab, a dead slab slot: always true in the 3x3 part (3 NSTX >= DIST + 3),
     // u <= s + NSTX - 1 for the one-step slabs of the second source.  The ring is NOT filled at once: a prologue of DIST
     // stages from every CU at the same moment (HBM-cold weights) comes back at the burst rate of the whole chip and stage 0
     // lands last-ish (9 800 cycles for 112 KB per CU against 4 400 for igemm2's 96 KB, in-kernel stamps) -- PRO steps first,
     // then two more per iteration until DIST are in flight.
-    auto issue_after = [&](int s) {
-      while (issued < ns && issued <= s + DIST && issued < PRO + 2 * (s + 1) && (issued < ns3 || issued <= s + NSTX - 1)) issue();
+    auto issue_after = [&](int s) __attribute__((always_inline)) {
+      while (issued < ns && issued <= s + DIST && issued < PRO + 2 * (s + 1) && (issued < ns3 || issued <= s + NSTX - 1)) {
+        if (issued < ns3) issue3();
+        else issue2();
+      }
     };
-    issue_after(-1);
-    for (int s = 0; s < nk_loop; ++s) {
+    int s = 0;
+    if (ns3 >= 2 * DIST + 3) {
+      // the common case, with compile-time load counts: PRO steps, RAMP peeled iterations that issue two steps each, then
+      // the steady loop (one step per iteration, DIST in flight) for as long as the step it issues is a 3x3 step
+#pragma unroll
+      for (int u = 0; u < PRO; ++u) issue3();
+      auto ramp_iter = [&](auto S) __attribute__((always_inline)) {
+        constexpr int s0 = decltype(S)::value;
+        constexpr int hd = PRO + 2 * s0;           // K-steps issued before barrier s0
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ig4_loads(s0 + 1, hd - 1, WI, XI)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        constexpr int upto = s0 + 1 + DIST < PRO + 2 * (s0 + 1) ? s0 + 1 + DIST : PRO + 2 * (s0 + 1);
+#pragma unroll
+        for (int u = hd; u < upto; ++u) issue3();
+      };
+      if constexpr (RAMP > 0) ramp_iter(integral_constant<int, 0>{});
+      if constexpr (RAMP > 1) ramp_iter(integral_constant<int, 1>{});
+      if constexpr (RAMP > 2) ramp_iter(integral_constant<int, 2>{});
+      if constexpr (RAMP > 3) ramp_iter(integral_constant<int, 3>{});
+      if constexpr (RAMP > 4) ramp_iter(integral_constant<int, 4>{});
+      if constexpr (RAMP > 5) ramp_iter(integral_constant<int, 5>{});
+      int ph = RAMP % 3;
+      for (s = RAMP; s + DIST < ns3; ++s) {
+        // K-step s has landed when at most the loads issued after its weights are outstanding: steps s+1 .. s+DIST-1
+        if (ph == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ig4_loads(1, DIST - 1, WI, XI)) : "memory");          // s = 0 (mod 3)
+        else if (ph == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ig4_loads(2, DIST, WI, XI)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ig4_loads(3, DIST + 1, WI, XI)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue3();
+        ph = ph == 2 ? 0 : ph + 1;
+      }
+    } else {
+      issue_after(-1);
+    }
+    // the rest -- the tail of the 3x3 part, the second source, a slice too short for the loop above, the idle barriers of the
+    // shorter team -- with run-time counts: K-step s has landed when only the loads issued after its weights are outstanding
+    // (loads complete in order), i.e. everything issued so far minus everything up to and including step s
+    for (; s < nk_loop; ++s) {
       if (s < ns) {
-        // K-step s has landed when only the loads issued after its weights are outstanding (loads complete in order):
-        // everything issued so far minus everything up to and including step s
         const int slabs = s < ns3 ? s / 3 + 1 : ns3 / 3 + (s - ns3 + 1);
         ig4_wait_vm(tot - ((s + 1) * WI + slabs * XI));
       }
@@ -396,6 +471,9 @@ bool igemm4_applicable(const IgemmArgs& a, bool big) {
   const int BM = big ? 128 : 64;
   if (!a.conv3 || a.nbatch != 1 || a.Cin % 64 != 0 || a.K != 9 * a.Cin + a.K2) return false;
   if (a.K2 && (a.K2 % 64 != 0 || a.K2 / 64 > 127 || !a.X2)) return false;
+  // the folded second source runs with a short lookahead (one slab per step, NSTX - 1 ahead): worth it on the 128-tiles
+  // (-11 %), a loss on the 64-tiles (+4..18 %, profiles/round4_igemm4_probe_v4.txt) -- those stay with igemm2
+  if (a.K2 && !big) return false;
   if (big ? a.W != 128 : (a.W != 16 && a.W != 32 && a.W != 64)) return false;
   if (BM % a.W != 0 || (a.H * a.W) % BM != 0 || a.M % BM != 0) return false;
   return true;
@@ -413,13 +491,14 @@ bool igemm4_applicable(const IgemmArgs& a, bool big) {
 #define IG4_TEAM_W 6
 #define IG4_TEAM_X 3
 #endif
-// two teams: one workgroup per CU at most (<= 256 tiles) and a K slice of at least four chunks (two per team)
+// two teams: one workgroup per CU at most (<= 256 tiles) and a K slice long enough to halve (measured break-even: ~40 steps)
 bool igemm4_two_teams(const IgemmArgs& a, bool big) {
   static const int on = [] { const char* e = getenv("ISHAP_IG4_TEAMS"); return e ? atoi(e) : 2; }();
   if (big || on != 2) return false;
   const long long tiles = (long long)(a.M / 64) * ((a.N + 63) / 64) * a.ksplit;
   const int groups = (3 * (a.Cin / 64) + a.ksplit - 1) / a.ksplit;
-  return tiles <= 256 && 3 * groups + a.K2 / 64 >= 18;
+  static const int min_steps = [] { const char* e = getenv("ISHAP_IG4_TEAM_STEPS"); return e ? atoi(e) : 48; }();
+  return tiles <= 256 && 3 * groups + a.K2 / 64 >= min_steps;
 }
 int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
   if (big) return launch4<128, 128, 128, IG4_BIG_W, IG4_BIG_X>(a, s);
