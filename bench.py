@@ -475,12 +475,15 @@ def main():
         traffic_source = None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            k = pj["kernels"][names[v]]
-            traffic = k["FETCH_SIZE"]["bytes_per_launch"] + k["WRITE_SIZE"]["bytes_per_launch"]
+            import re as _re
+            pat = _re.compile("^" + _re.escape(names[v]).replace("\\*", "[0-9]+") + "$")
+            ks = [k for key, k in pj["kernels"].items() if pat.match(key)]        # a '*' stands for the map-width template argument
+            nd = sum(k["FETCH_SIZE"]["dispatches"] for k in ks)
+            traffic = int(sum((k["FETCH_SIZE"]["bytes_per_launch"] + k["WRITE_SIZE"]["bytes_per_launch"]) * k["FETCH_SIZE"]["dispatches"] for k in ks) / nd)
             traffic_source = ("committed profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                               "tools/pmc_step.py (" + str(pj.get("source", "tools/pmc_only.sh")) + "), FETCH_SIZE doubled per "
                               "MI355X_MICROARCH.md; not collected live (counters cannot be read from inside this process)")
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass
         roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,

@@ -1,0 +1,20 @@
+// Activation arithmetic shared by every GroupNorm route (norm.hip, norm_local.hip, norm_bwd.hip via gn_bwd_terms.h, the
+// implicit-GEMM epilogues): one definition, so that the routes round identically.
+// Reference: GroupNorm32 output cast back to half (gd/nn.py:16-18), FiLM `h * (1 + scale) + shift` and SiLU on half tensors
+// (gd/unet.py:245-252).  Round 4: these kernels turned out VALU-bound, not HBM-bound (a 128x128x256 apply pass: ~27
+// instructions per element, 7.6 us of issue time per SIMD against 3.4 us of HBM time): the IEEE division of the sigmoid
+// (v_div_scale / v_rcp / 4 v_fma / v_div_fmas / v_div_fixup) became v_rcp_f32 (1 ulp in fp32, far below the fp16 rounding that
+// follows), and FiLM runs in fp16 arithmetic -- a correctly rounded fp16 product IS fp16(fp32 product) (22-bit exact
+// product), and the fp16 sum rounds once where fp16(fp32 sum) rounds twice: equal except on rare ties, both orders are
+// what half tensors do on one backend or another.
+#pragma once
+#include "common.h"
+
+__device__ __forceinline__ float gn_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+__device__ __forceinline__ float gn_silu(float v) { return v * gn_sigmoid(v); }
+// fp16(fp16(y * sc) + sh) on fp16 operands (sc = fp16(1 + fp16(scale)), sh = fp16(shift), prepared by the caller)
+__device__ __forceinline__ half_t gn_film(half_t y, half_t sc, half_t sh) {
+#pragma clang fp contract(off)
+  const half_t t = y * sc;
+  return t + sh;
+}

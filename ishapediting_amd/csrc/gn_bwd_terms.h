@@ -4,6 +4,7 @@
 // in registers.  Rounding points mirror the forward kernel (norm.hip) so the recomputed pre-activation is the forward's.
 #pragma once
 #include "common.h"
+#include "gn_act.h"
 
 __device__ __forceinline__ float gnb_rh(float v) { return (float)(half_t)v; }
 // fp contract(off) in these helpers: they are inlined at several call sites of one kernel (a thread's first unit keeps dyh /
@@ -11,7 +12,7 @@ __device__ __forceinline__ float gnb_rh(float v) { return (float)(half_t)v; }
 // would fuse around them -- the group-local kernels' results must not depend on how many units a thread owns (parts = 1 vs > 1).
 __device__ __forceinline__ float gnb_silu_grad(float v) {
 #pragma clang fp contract(off)
-  float sg = 1.f / (1.f + __expf(-v));
+  const float sg = gn_sigmoid(v);
   return sg * (1.f + v * (1.f - sg));
 }
 // emb_sc / emb_sh: the raw FiLM row entries (only read when film)
@@ -21,14 +22,13 @@ __device__ __forceinline__ void gn_bwd_term(float up, float x, float mu, float r
   xhat = (x - mu) * rs;
   float u = up, mult = gam;
   if (film || act) {
-    float pre = gnb_rh(xhat * gam + bet);
+    half_t preh = (half_t)(xhat * gam + bet);
     if (film) {
-      const float sc = gnb_rh(1.f + gnb_rh(emb_sc));
-      const float sh = gnb_rh(emb_sh);
-      pre = gnb_rh(gnb_rh(pre * sc) + sh);
-      mult *= sc;
+      const half_t sc = (half_t)(1.f + gnb_rh(emb_sc));
+      preh = gn_film(preh, sc, (half_t)emb_sh);
+      mult *= (float)sc;
     }
-    if (act) u *= gnb_silu_grad(pre);
+    if (act) u *= gnb_silu_grad((float)preh);
   }
   dyh = u * mult;
 }

@@ -17,6 +17,7 @@
 // A folded 1x1 skip convolution (K2 columns from X2, unet.py:222,256) rides along as extra one-tap chunks.
 #include "common.h"
 #include "gn_bwd_terms.h"
+#include "igemm_epilogue.h"      // IG_STAMP (diagnostic builds of the harness only)
 
 #include <algorithm>
 #include <type_traits>
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(S3_THREADS) void conv3_small_kernel(const void* hX,
   char* ring = smem_raw;
   const int zero_off = S3_SLOTS * hslot_bytes;                  // 64 zero bytes behind the ring
 
+  IG_STAMP(0, wave == 0);
   f32x4 acc[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -227,10 +229,12 @@ __global__ __launch_bounds__(S3_THREADS) void conv3_small_kernel(const void* hX,
         load9(c + UNR, sub, ringw[R0 + sub]);          // refill the same registers, eight K-steps ahead
       }
     };
+    IG_STAMP(1, wave == 0);
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
 #pragma unroll
       for (int sub = 0; sub < SPC; ++sub) load9(c_lo + u, sub, ringw[u * SPC + sub]);
+    IG_STAMP(2, wave == 0);
     for (int c = c_lo; c < c9_hi; c += UNR) {
       chunk9(c, std::integral_constant<int, 0>{});
       if constexpr (UNR > 1) { if (c + 1 < c9_hi) chunk9(c + 1, std::integral_constant<int, SPC>{}); }
@@ -273,13 +277,16 @@ __global__ __launch_bounds__(S3_THREADS) void conv3_small_kernel(const void* hX,
   }
 
   // ---- the 9 partial tiles meet in LDS, over the ring: every wave must be past its last read of it first ----
+  IG_STAMP(3, wave == 0);
   __syncthreads();
+  IG_STAMP(4, wave == 0);
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                 // [S3_CONS][MT][64]
   if (!loader) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) red[(wave * MT + j) * 64 + lane] = acc[j];
   }
   __syncthreads();
+  IG_STAMP(5, wave == 0);
   if (wave >= MT) return;
 
   // ---- wave j finishes sub-tile j: lane = (pixel m, channels n .. n+3) ----
@@ -292,6 +299,7 @@ __global__ __launch_bounds__(S3_THREADS) void conv3_small_kernel(const void* hX,
   const bool ok = n < a.N;
   if (geo.nslice > 1) {          // a partial tile: the consumer adds the slices (bias, residual, statistics happen there)
     if (ok) *reinterpret_cast<f32x4*>(a.ws + ((long long)slice * a.M + m) * a.N + n) = v;
+    IG_STAMP(6, wave == 0);
     return;
   }
   const int p = m - n_img * HW;

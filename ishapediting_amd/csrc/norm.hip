@@ -8,6 +8,7 @@
 // two-stage deterministic reduction (per-row-chunk partial sums per channel, then one block per
 // (image, group) combining them in double) -- no float atomics, bitwise reproducible.
 #include "norm.h"
+#include "gn_act.h"
 #include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------
@@ -105,7 +106,6 @@ int gn_stats_launch(const half_t* x, float* partial, float* stats, int N, int HW
 // ---------------------------------------------------------------------------------------------
 // apply
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
 __device__ __forceinline__ float rh(float v) { return (float)(half_t)v; }   // round through fp16
 
 // One thread = 8 channels of one OUTPUT pixel.
@@ -164,17 +164,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(int h_main_blocks, int h_
   }
   // The launcher makes the thread count a multiple of CV, so a thread keeps ONE 8-channel vector for all its pixels:
   // gamma/beta are loaded once, the per-image values (mean, rstd, FiLM) only when the image changes.
-  const long long tg = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long nth = (long long)h_main_blocks * blockDim.x;
-  const int cv = (int)(tg % CV), c0 = cv * 8;
-  const long long pstep = nth / CV, npix = (long long)h_N * HWo;
-  float gam[8], bet[8], mu[8], rs[8], sc[8], sh[8];
+  // 32-bit index arithmetic (N * H * W <= 16 * 128 * 128 pixels): a 64-bit division per pixel cost more than the arithmetic
+  const int tg = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nth = h_main_blocks * blockDim.x;
+  const int cv = tg % CV, c0 = cv * 8;
+  const int pstep = nth / CV, npix = h_N * HWo;
+  float gam[8], bet[8], mu[8], rs[8];
+  half_t sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { gam[i] = a.gamma[c0 + i]; bet[i] = a.beta[c0 + i]; }
   int cur_n = -1;
-  for (long long pix = tg / CV; pix < npix; pix += pstep) {
-    const int n = (int)(pix / HWo);
-    const int p = (int)(pix % HWo);
+  for (int pix = tg / CV; pix < npix; pix += pstep) {
+    const int n = h_N == 1 ? 0 : pix / HWo;
+    const int p = pix - n * HWo;
     if (n != cur_n) {
       cur_n = n;
 #pragma unroll
@@ -183,8 +185,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(int h_main_blocks, int h_
         mu[i] = stats[(n * 32 + g) * 2];
         rs[i] = stats[(n * 32 + g) * 2 + 1];
         if (FILM) {
-          sc[i] = rh(1.f + rh(a.emb[(long long)n * a.emb_ld + c]));
-          sh[i] = rh(a.emb[(long long)n * a.emb_ld + h_C + c]);
+          sc[i] = (half_t)(1.f + rh(a.emb[(long long)n * a.emb_ld + c]));
+          sh[i] = (half_t)a.emb[(long long)n * a.emb_ld + h_C + c];
         }
       }
     }
@@ -192,9 +194,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(int h_main_blocks, int h_
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float y = ((float)v[i] - mu[i]) * rs[i] * gam[i] + bet[i];
-        if (!SPLIT) y = rh(y);
-        if (FILM) y = rh(rh(y * sc[i]) + sh[i]);
-        if (ACT) { y = silu_f(y); if (!SPLIT) y = rh(y); }
+        if (SPLIT) {                                  // fp32 head: no fp16 rounding points
+          if (ACT) y = gn_silu(y);
+        } else {
+          half_t yh = (half_t)y;
+          if (FILM) yh = gn_film(yh, sc[i], sh[i]);
+          y = (float)yh;
+          if (ACT) y = rh(gn_silu(y));
+        }
         o[i] = y;
       }
     };
@@ -217,23 +224,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(int h_main_blocks, int h_
       half8 ov, xv;
 #pragma unroll
       for (int i = 0; i < 8; ++i) { ov[i] = (half_t)(acc[i] * 0.25f); xv[i] = (half_t)(xacc[i] * 0.25f); }
-      *reinterpret_cast<half8*>(a.out + pix * h_C + c0) = ov;
-      if (a.xpool) *reinterpret_cast<half8*>(a.xpool + pix * h_C + c0) = xv;
+      *reinterpret_cast<half8*>(a.out + (long long)pix * h_C + c0) = ov;
+      if (a.xpool) *reinterpret_cast<half8*>(a.xpool + (long long)pix * h_C + c0) = xv;
     } else {
       half8 v;
       if (a.x2) {                                   // two-source input (skip concatenation); also emit the raw copy
-        v = c0 < a.csplit ? *reinterpret_cast<const half8*>(a.x + pix * a.csplit + c0)
-                          : *reinterpret_cast<const half8*>(a.x2 + pix * (h_C - a.csplit) + (c0 - a.csplit));
-        *reinterpret_cast<half8*>(a.xcopy + pix * h_C + c0) = v;
+        v = c0 < a.csplit ? *reinterpret_cast<const half8*>(a.x + (long long)pix * a.csplit + c0)
+                          : *reinterpret_cast<const half8*>(a.x2 + (long long)pix * (h_C - a.csplit) + (c0 - a.csplit));
+        *reinterpret_cast<half8*>(a.xcopy + (long long)pix * h_C + c0) = v;
       } else {
-        v = *reinterpret_cast<const half8*>(a.x + pix * h_C + c0);
+        v = *reinterpret_cast<const half8*>(a.x + (long long)pix * h_C + c0);
       }
       one(v, o);
       if (SPLIT) {
         half8 hi, lo;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { hi[i] = (half_t)o[i]; lo[i] = (half_t)(o[i] - (float)hi[i]); }
-        half_t* dst = a.out + pix * (3LL * h_C);
+        half_t* dst = a.out + (long long)pix * (3LL * h_C);
         *reinterpret_cast<half8*>(dst + c0) = hi;
         *reinterpret_cast<half8*>(dst + h_C + c0) = lo;
         *reinterpret_cast<half8*>(dst + 2 * h_C + c0) = hi;
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(int h_main_blocks, int h_
         half8 ov;
 #pragma unroll
         for (int i = 0; i < 8; ++i) ov[i] = (half_t)o[i];
-        *reinterpret_cast<half8*>(a.out + pix * h_C + c0) = ov;
+        *reinterpret_cast<half8*>(a.out + (long long)pix * h_C + c0) = ov;
       }
     }
   }

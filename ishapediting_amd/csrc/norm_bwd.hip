@@ -113,17 +113,21 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const long long* h_cs
     __syncthreads();
   }
   // thread count is a multiple of CV (launcher): one 8-channel vector per thread, parameters loaded once per image
-  const long long tg = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long nth = (long long)h_main_blocks * blockDim.x;
-  const int cv = (int)(tg % CV), c0 = cv * 8;
-  const long long pstep = nth / CV, npix = (long long)h_N * HW;
+  // 32-bit index arithmetic (N * H * W <= 16 * 128 * 128 pixels; shifts for the power-of-two maps of the UNet): the 64-bit
+  // divisions per pixel cost more issue time than the gradient arithmetic
+  const int tg = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nth = h_main_blocks * blockDim.x;
+  const int cv = tg % CV, c0 = cv * 8;
+  const int pstep = nth / CV, npix = h_N * HW;
+  const bool wpow2 = (h_W & (h_W - 1)) == 0;
+  const int wsh = 31 - __builtin_clz(h_W);
   float gam[8], bet[8], mu[8], rs[8], esc[8], esh[8], m1[8], m2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { gam[i] = a.gamma[c0 + i]; bet[i] = (FILM || ACT) ? a.beta[c0 + i] : 0.f; esc[i] = 0.f; esh[i] = 0.f; }
   int cur_n = -1;
-  for (long long pix = tg / CV; pix < npix; pix += pstep) {
-    const int n = (int)(pix / HW), p = (int)(pix % HW);
-    const int y = p / h_W, x = p % h_W;
+  for (int pix = tg / CV; pix < npix; pix += pstep) {
+    const int n = h_N == 1 ? 0 : pix / HW, p = pix - n * HW;
+    const int y = wpow2 ? p >> wsh : p / h_W, x = p - y * h_W;
     if (n != cur_n) {
       cur_n = n;
 #pragma unroll
@@ -138,10 +142,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const long long* h_cs
     }
     float up[8], ad[8];
     load_upstream(a.g, a.gmode, n, y, x, h_H, h_W, h_C, c0, up);
-    const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * h_C + c0);
+    const half8 xv = *reinterpret_cast<const half8*>(a.x + (long long)pix * h_C + c0);
     if (a.add) load_upstream(a.add, a.gmode, n, y, x, h_H, h_W, h_C, c0, ad);
     half8 a2 = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (a.add2) a2 = *reinterpret_cast<const half8*>(a.add2 + pix * h_C + c0);
+    if (a.add2) a2 = *reinterpret_cast<const half8*>(a.add2 + (long long)pix * h_C + c0);
     half8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -152,9 +156,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const long long* h_cs
       if (a.add2) v = (float)(half_t)v + (float)a2[i];      // same rounding as a separate fp16 add of the two gradient maps
       o[i] = (half_t)v;
     }
-    if (a.csplit == 0) *reinterpret_cast<half8*>(a.dx + pix * h_C + c0) = o;
-    else if (c0 < a.csplit) *reinterpret_cast<half8*>(a.dx + pix * a.csplit + c0) = o;
-    else *reinterpret_cast<half8*>(a.dx2 + pix * (h_C - a.csplit) + (c0 - a.csplit)) = o;
+    if (a.csplit == 0) *reinterpret_cast<half8*>(a.dx + (long long)pix * h_C + c0) = o;
+    else if (c0 < a.csplit) *reinterpret_cast<half8*>(a.dx + (long long)pix * a.csplit + c0) = o;
+    else *reinterpret_cast<half8*>(a.dx2 + (long long)pix * (h_C - a.csplit) + (c0 - a.csplit)) = o;
   }
 }
 

@@ -12,6 +12,7 @@
 // Rounding points are those of norm.hip / norm_bwd.hip, so both routes give the same values.
 #include "norm.h"
 #include "gn_bwd_terms.h"
+#include "gn_act.h"
 
 #ifdef GN_STAMPS          // diagnostic build (tools/persist_chain.hip -DGN_STAMPS): s_memtime of thread 0 at the phase boundaries
 extern __device__ unsigned long long* g_gn_stamps;      // [workgroup][8]
@@ -121,7 +122,6 @@ __device__ __forceinline__ void slab_sum(const SlabSrc& s, long long row, int ld
   }
 }
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
 __device__ __forceinline__ float rh(float v) { return (float)(half_t)v; }
 
 // block-wide sums of two doubles (every thread gets them); `scratch` = 2 * 16 doubles of LDS
@@ -298,13 +298,14 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(int h_parts, int h_C, in
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const float gm = first ? pg[i] : a.gamma[c + i], bt = first ? pb[i] : a.beta[c + i];
-      float y = rh((x[i] - mean) * rstd * gm + bt);
+      half_t yh = (half_t)((x[i] - mean) * rstd * gm + bt);
       if (FILM) {
-        const float sc = rh(1.f + rh(first ? psc[i] : a.emb[(long long)n * a.emb_ld + c + i]));
-        const float sh = rh(first ? psh[i] : a.emb[(long long)n * a.emb_ld + C + c + i]);
-        y = rh(rh(y * sc) + sh);
+        const half_t sc = (half_t)(1.f + rh(first ? psc[i] : a.emb[(long long)n * a.emb_ld + c + i]));
+        const half_t sh = (half_t)(first ? psh[i] : a.emb[(long long)n * a.emb_ld + C + c + i]);
+        yh = gn_film(yh, sc, sh);
       }
-      if (ACT) y = rh(silu_f(y));
+      float y = (float)yh;
+      if (ACT) y = rh(gn_silu(y));
       o[i] = y;
     }
   };
