@@ -4,9 +4,9 @@
 // (gd/unet.py:245-252).  Round 4: these kernels turned out VALU-bound, not HBM-bound (a 128x128x256 apply pass: ~27
 // instructions per element, 7.6 us of issue time per SIMD against 3.4 us of HBM time): the IEEE division of the sigmoid
 // (v_div_scale / v_rcp / 4 v_fma / v_div_fmas / v_div_fixup) became v_rcp_f32 (1 ulp in fp32, far below the fp16 rounding that
-// follows), and FiLM runs in fp16 arithmetic -- a correctly rounded fp16 product IS fp16(fp32 product) (22-bit exact
-// product), and the fp16 sum rounds once where fp16(fp32 sum) rounds twice: equal except on rare ties, both orders are
-// what half tensors do on one backend or another.
+// follows), and FiLM's product runs in fp16 arithmetic -- a correctly rounded fp16 product IS fp16(fp32 product) (the
+// 22-bit product is exact in fp32).  The sum stays fp16(fp32 sum), the order the reference's half tensors take on the CPU
+// the golden fixtures were generated on (an fp16 add would round once instead of twice: a different value on rare ties).
 #pragma once
 #include "common.h"
 
@@ -16,5 +16,5 @@ __device__ __forceinline__ float gn_silu(float v) { return v * gn_sigmoid(v); }
 __device__ __forceinline__ half_t gn_film(half_t y, half_t sc, half_t sh) {
 #pragma clang fp contract(off)
   const half_t t = y * sc;
-  return t + sh;
+  return (half_t)((float)t + (float)sh);
 }
