@@ -271,6 +271,20 @@ struct IgemmArgs {
   int gb_emb_ld = 0;
   int gb_film = 0, gb_act = 0;
   long long* gb_csums = nullptr;
+  // Fused GroupNorm(32) (+FiLM) + SiLU of THIS launch's output (round 4; forward launches with stat_out, staged epilogue):
+  // once its tile's channel sums are out, a workgroup announces itself on a per-(image, n-tile) counter, waits until every
+  // m-tile of that image has done so (the launcher only allows it when the whole grid is co-resident), reads the group
+  // totals, and writes act(film(GN(out))) of its own tile -- still in LDS -- to gn_out; the raw output goes to `out` as
+  // always (the backward pass re-reads it).  Replaces a gn_apply launch (a ResBlock's out_layers norm, gd/unet.py:245-252).
+  half_t* gn_out = nullptr;          // [M][N] dense
+  const float* gn_gamma = nullptr;
+  const float* gn_beta = nullptr;
+  const float* gn_emb = nullptr;     // FiLM rows (scale at c, shift at N + c), per image stride gn_emb_ld
+  int gn_emb_ld = 0, gn_film = 0;
+  float* gn_stats_out = nullptr;     // [N_img][32][2] (mean, rstd) for the backward pass
+  unsigned* gn_counter = nullptr;    // [N_img][n-tiles], zeroed before the launch
+  unsigned* gn_status = nullptr;     // device status word (common.h): a wait that gives up raises ISHAP_DEV_GN_RENDEZVOUS
+  int gn_spin_limit = 0;
 };
 // set (non-null) by igemm.hip around a launch while ishap_profile_begin/end is active: the kernel launchers then attach
 // these events to the dispatch itself (hipExtLaunchKernelGGL), so their elapsed time is the kernel's own duration
@@ -281,3 +295,4 @@ bool igemm_small3_wanted(const IgemmArgs& a);
 int igemm_small3_slices(const IgemmArgs& a);      // K slices that fill the chip (consumer must be able to add them up)    // the one-launch small-map 3x3 kernel takes this shape (then no split-K)
 // picks a split so the grid fills the chip; returns workspace floats needed
 int igemm_pick_ksplit(int M, int N, int K, int nbatch);
+int igemm_stat_launch_workgroups(const IgemmArgs& a);

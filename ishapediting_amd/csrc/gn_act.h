@@ -10,6 +10,13 @@
 #pragma once
 #include "common.h"
 
+// fp16((x - mean) * rstd * gamma + beta): ONE rounding sequence (no contraction) for every route -- the apply kernels, the
+// group-local kernels, the convolution epilogue that applies the norm itself and the backward pass's recomputation agree bitwise
+__device__ __forceinline__ half_t gn_affine(float x, float mean, float rstd, float gamma, float beta) {
+#pragma clang fp contract(off)
+  const float xh = (x - mean) * rstd;
+  return (half_t)(xh * gamma + beta);
+}
 __device__ __forceinline__ float gn_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 __device__ __forceinline__ float gn_silu(float v) { return v * gn_sigmoid(v); }
 // fp16(fp16(y * sc) + sh) on fp16 operands (sc = fp16(1 + fp16(scale)), sh = fp16(shift), prepared by the caller)

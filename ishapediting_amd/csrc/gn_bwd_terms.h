@@ -22,7 +22,7 @@ __device__ __forceinline__ void gn_bwd_term(float up, float x, float mu, float r
   xhat = (x - mu) * rs;
   float u = up, mult = gam;
   if (film || act) {
-    half_t preh = (half_t)(xhat * gam + bet);
+    half_t preh = gn_affine(x, mu, rs, gam, bet);
     if (film) {
       const half_t sc = (half_t)(1.f + gnb_rh(emb_sc));
       preh = gn_film(preh, sc, (half_t)emb_sh);

@@ -388,6 +388,17 @@ static bool igemm_use_big(int M, int N, int nbatch) {
   static const int big_min = [] { const char* e = getenv("ISHAP_BIG_MIN"); return e ? atoi(e) : 192; }();
   return blocks >= big_min;
 }
+// workgroups of the main launch of a statistics-carrying conv / GEMM (the tile the dispatcher below will pick), or 0 when the
+// shape does not take the LDS-DMA kernels with the staged epilogue (the fused GroupNorm of IgemmArgs::gn_out needs them)
+int igemm_stat_launch_workgroups(const IgemmArgs& a) {
+  const bool k64 = a.conv3 ? (a.Cin % 64 == 0) : (a.K % 64 == 0);
+  const int hw = a.H * a.W;
+  if (!k64 || hw <= 0 || hw % 64 != 0 || a.M % 64 != 0 || a.nbatch != 1) return 0;
+  bool big = igemm_use_big(a.M, a.N, a.nbatch);
+  if (hw % 128 != 0) big = false;
+  const int bm = big ? 128 : 64;
+  return (a.M / bm) * ceil_div(a.N, bm) * a.ksplit;
+}
 int igemm_pick_ksplit(int M, int N, int K, int nbatch) {
   const bool big = igemm_use_big(M, N, nbatch);
   const int bm = big ? 128 : 64, bn = big ? 128 : 64;

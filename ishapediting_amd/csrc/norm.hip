@@ -193,11 +193,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(int h_main_blocks, int h_
     auto one = [&](const half8& v, float* o) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float y = ((float)v[i] - mu[i]) * rs[i] * gam[i] + bet[i];
+        float y;
         if (SPLIT) {                                  // fp32 head: no fp16 rounding points
+          y = ((float)v[i] - mu[i]) * rs[i] * gam[i] + bet[i];
           if (ACT) y = gn_silu(y);
         } else {
-          half_t yh = (half_t)y;
+          half_t yh = gn_affine((float)v[i], mu[i], rs[i], gam[i], bet[i]);
           if (FILM) yh = gn_film(yh, sc[i], sh[i]);
           y = (float)yh;
           if (ACT) y = rh(gn_silu(y));

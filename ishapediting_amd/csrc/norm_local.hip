@@ -298,7 +298,7 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(int h_parts, int h_C, in
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const float gm = first ? pg[i] : a.gamma[c + i], bt = first ? pb[i] : a.beta[c + i];
-      half_t yh = (half_t)((x[i] - mean) * rstd * gm + bt);
+      half_t yh = gn_affine(x[i], mean, rstd, gm, bt);
       if (FILM) {
         const half_t sc = (half_t)(1.f + rh(first ? psc[i] : a.emb[(long long)n * a.emb_ld + c + i]));
         const half_t sh = (half_t)(first ? psh[i] : a.emb[(long long)n * a.emb_ld + C + c + i]);

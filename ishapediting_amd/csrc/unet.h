@@ -213,13 +213,24 @@ static inline int aalloc_checked(Exec& e, size_t count, T** out) {
     (ptr) = salloc((e), (size_t)(count));                                                             \
     ISHAP_REQUIRE((ptr) != nullptr, "GroupNorm statistics arena exhausted");                          \
   } while (0)
+// GroupNorm (+FiLM) + SiLU of a convolution's output applied in that convolution's own epilogue (IgemmArgs::gn_out): what the
+// caller would otherwise run as a gn_apply launch on the result.  conv_op sets *fused when the launch could take it.
+struct GnFuse {
+  half_t* out = nullptr;           // act(film(GN(conv output))), dense [N*H*W][cout]
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  const float* emb = nullptr;      // FiLM rows or null
+  int emb_ld = 0;
+  float* stats_out = nullptr;      // (mean, rstd) [N][32][2] for the backward pass
+  bool* fused = nullptr;
+};
 // X [N,H,W,ldx] (*) Wt -> out; taps 9 (3x3, pad 1) or 1; picks split-K and uses the context workspace
 // pend_out: the caller's consumer can read split-K slices (a group-local GroupNorm pass): when the launch splits K, the
 // slices stay in an arena buffer described by *pend_out and no reduce kernel runs (fp16 dense outputs only)
 int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps, int cout,
             const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups, int res_ups,
             long long* stat_out = nullptr, const struct GnBwdArgs* gb = nullptr, const half_t* X2 = nullptr, int ldx2 = 0,
-            int K2 = 0, const float* bias2 = nullptr, int ldw = 0, SlabSrc* pend_out = nullptr);
+            int K2 = 0, const float* bias2 = nullptr, int ldw = 0, SlabSrc* pend_out = nullptr, const GnFuse* gf = nullptr);
 // small maps (<= 32 x 32): GroupNorm passes run group-local (norm_local.hip), producers gather no statistics
 int unet_join_tail(ishap_unet* u, hipStream_t s);
 bool small_map(int HW);

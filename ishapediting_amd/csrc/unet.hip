@@ -270,8 +270,9 @@ bool local_gn(int HW, int C) { return small_map(HW) && gn_local_fits(HW, C); }
 int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps,
                    int cout, const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups,
                    int res_ups, long long* stat_out, const GnBwdArgs* gb, const half_t* X2, int ldx2, int K2,
-                   const float* bias2, int ldw, SlabSrc* pend_out) {
+                   const float* bias2, int ldw, SlabSrc* pend_out, const GnFuse* gf) {
   IgemmArgs a;
+  if (gf && gf->fused) *gf->fused = false;
   a.stat_out = stat_out;
   if (gb) {       // this launch produces the gradient arriving at act(film(GN(x))): accumulate the GN-backward sums in its epilogue
     a.gb_x = gb->x; a.gb_stats = gb->stats; a.gb_gamma = gb->gamma; a.gb_beta = gb->beta; a.gb_emb = gb->emb;
@@ -302,9 +303,37 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
     return igemm_launch(a, e.s);
   }
   size_t need = a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N : 0;
+  // Fused GroupNorm of the output (IgemmArgs::gn_out): an unsplit launch with the staged epilogue whose whole grid is resident at
+  // once (at most one workgroup per CU of this device), on the context's only launch sequence (the in-launch wait: exec_is_solo)
+  // OFF by default: measured a LOSS (profiles/round4_ab_fused_groupnorm.txt: 0.1845 -> 0.1879 s/shape; a fused 128-tile launch
+  // takes +16.7 us -- every workgroup waits for the slowest tile of the grid, then the acknowledged atomics, the counter and the
+  // totals each cost a memory round trip -- against the 6.7-9.2 us gn_apply launch + 1.5 us boundary it removes).  ISHAP_FUSE_GN=1
+  // switches it on; tests/test_gpu_fullsize.py holds it bitwise against the separate launches.
+  static const int fuse_on = [] { const char* v = getenv("ISHAP_FUSE_GN"); return v ? atoi(v) : 0; }();
+  unsigned* gn_counter = nullptr;
+  bool fuse = false;
+  if (gf && fuse_on && stat_out && !gb && a.ksplit == 1 && out_mode == IG_OUT_F16 && ldo == cout && cout % 32 == 0 && (cout / 32) % 8 == 0 &&
+      (res == nullptr || ldr % 8 == 0) && H * W >= 4096 && exec_is_solo(e)) {
+    const int wgs = igemm_stat_launch_workgroups(a);
+    if (wgs > 0 && wgs <= ishap_cu_count()) {
+      long long* c64 = salloc(e, 128);              // [N_img][n-tiles] arrival counters, zeroed with the statistics arena
+      ISHAP_REQUIRE(c64 != nullptr, "GroupNorm statistics arena exhausted");
+      gn_counter = reinterpret_cast<unsigned*>(c64);
+      fuse = N * ceil_div(cout, 64) <= 256;
+    }
+  }
   if (e.dry) {
     if (need > e.u->ws_floats) e.u->ws_floats = need;
+    if (gf && gf->fused) *gf->fused = fuse;
     return 0;
+  }
+  if (fuse) {
+    a.gn_out = gf->out; a.gn_gamma = gf->gamma; a.gn_beta = gf->beta; a.gn_emb = gf->emb; a.gn_emb_ld = gf->emb_ld; a.gn_film = gf->emb != nullptr;
+    a.gn_stats_out = gf->stats_out; a.gn_counter = gn_counter; a.gn_status = ishap_status_word();
+    ISHAP_REQUIRE(a.gn_status != nullptr, "device status word");
+    static const int spin = [] { const char* v = getenv("ISHAP_GN_SPIN_LIMIT"); const int n = v ? atoi(v) : 0; return n > 0 ? n : (1 << 22); }();
+    a.gn_spin_limit = spin;
+    if (gf->fused) *gf->fused = true;
   }
   ISHAP_REQUIRE(need <= e.u->ws_floats, "split-K workspace too small");
   a.ws = e.ws ? e.ws : e.u->ws;
@@ -397,12 +426,20 @@ static int res_forward(Exec& e, ResL& L, Tensor x, Tensor& y) {
   Tensor h1{nullptr, N, Ho, Wo, L.cout};
   ISHAP_ALLOC(h1.p, e, h1.numel());
   if (!nosum_out) ISHAP_SALLOC(h1.sums, e, (size_t)N * L.cout * 2);
-  ISHAP_TRY(conv_op(e, a.p, N, Ho, Wo, L.cin, L.c1.w, L.c1.kpad, 9, L.cout, L.c1.bias, nullptr, 0, h1.p, L.cout, IG_OUT_F16,
-                    L.up, 0, h1.sums, nullptr, nullptr, 0, 0, nullptr, 0, loc_out ? &h1.pend : nullptr));
   Tensor c = h1;
   c.pend = SlabSrc{};
   ISHAP_ALLOC(c.p, e, h1.numel());
-  if (loc_out) {
+  // on the big maps the second norm (+FiLM +SiLU) runs in conv1's own epilogue when the launch can take it (conv_op, GnFuse)
+  bool fused2 = false;
+  GnFuse gf;
+  gf.out = c.p; gf.gamma = L.n2.gamma; gf.beta = L.n2.beta; gf.emb = u->film_cur + L.emb_off; gf.emb_ld = u->film_cur_ld;
+  gf.stats_out = st2; gf.fused = &fused2;
+  ISHAP_TRY(conv_op(e, a.p, N, Ho, Wo, L.cin, L.c1.w, L.c1.kpad, 9, L.cout, L.c1.bias, nullptr, 0, h1.p, L.cout, IG_OUT_F16,
+                    L.up, 0, h1.sums, nullptr, nullptr, 0, 0, nullptr, 0, loc_out ? &h1.pend : nullptr,
+                    (!loc_out && h1.sums) ? &gf : nullptr));
+  if (fused2) {
+    // nothing to launch
+  } else if (loc_out) {
     ISHAP_TRY(gn_local_op(e, h1, L.n2, c.p, nullptr, st2, u->film_cur + L.emb_off, u->film_cur_ld, 1, 1, 0, pf_fwd(L.c2)));
   } else {
     if (!h1.sums) ISHAP_TRY(gn_stats_op(e, h1, st2));

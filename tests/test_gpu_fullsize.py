@@ -435,3 +435,48 @@ def test_shortened_c2_generate_against_the_oracle():
             flips = int(((vols[b] > 0) != (vol_ref > 0)).sum())
             print(f"short C2 sample {b}: triplane rel {r:.2e}, logit RMS err / RMS {r_vol:.2e}, sign flips {flips} / {vol_ref.numel()}")
             assert r <= 5e-3 and r_vol <= 1e-2 and flips <= 0.005 * vol_ref.numel()
+
+
+_FUSE_WORKER = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from ishapediting_amd import synthetic
+from ishapediting_amd.unet import UNetModel
+from ishapediting_amd.unet_spec import full_config
+cfg = full_config()
+dev = torch.device("cuda", 0)
+m = UNetModel(cfg, dev)
+m.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 1234)))
+x = torch.from_numpy(synthetic.latent(2)).to(dev)
+k = 8
+ch, sz = m.tap_shape(k)
+cot = (torch.randn(1, sz * sz, ch, generator=torch.Generator().manual_seed(3)) * 1e-2).half().to(dev)
+out, tap = m(x, [617.0], feat_layer=k, keep_for_backward=True)
+gx = m.backward_input(cot)
+torch.cuda.synchronize()
+from ishapediting_amd import _lib
+assert int(_lib.lib().ishap_device_status()) == 0
+np.savez({out!r}, out=out.cpu().numpy(), tap=tap.float().cpu().numpy(), gx=gx.cpu().numpy())
+"""
+
+
+def test_groupnorm_fused_into_the_conv_epilogue_changes_no_bit(tmp_path):
+    """ISHAP_FUSE_GN=1 (csrc/unet.hip conv_op, IgemmArgs::gn_out): on the 128^2 / 64^2 maps a ResBlock's second norm (+FiLM +SiLU,
+    gd/unet.py:245-252) is applied in conv1's own epilogue behind an in-launch rendezvous on the group sums instead of a
+    gn_apply launch.  Off by default (slower); when switched on the full-size model's output, tap and input
+    gradient must be BITWISE those of the separate launches -- same sums, same rounding sequence (csrc/gn_act.h)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for name, env in (("default", {}), ("fused", {"ISHAP_FUSE_GN": "1"})):
+        path = str(tmp_path / (name + ".npz"))
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", _FUSE_WORKER.format(root=root, out=path)], env=e, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        res[name] = np.load(path)
+    for key in ("out", "tap", "gx"):
+        assert np.array_equal(res["default"][key], res["fused"][key]), key
