@@ -320,9 +320,7 @@ extern "C" int ishap_profile_shapes(char* buf, int cap) {
 
 int igemm2_launch_main(const IgemmArgs& a, bool big, hipStream_t s);   // igemm2.hip (LDS-DMA ring, BK = 64)
 bool igemm2_two_teams(const IgemmArgs& a, bool big);
-bool igemm3_applicable(const IgemmArgs& a, bool big);                  // igemm3.hip (3x3 with activation reuse across dx)
-int igemm3_launch_main(const IgemmArgs& a, bool big, hipStream_t s);
-bool igemm4_applicable(const IgemmArgs& a, bool big);                  // igemm4.hip (round 4: the same reuse, done properly)
+bool igemm4_applicable(const IgemmArgs& a, bool big);                  // igemm4.hip (3x3 with each activation slab staged once for dx = -1, 0, +1)
 bool igemm4_two_teams(const IgemmArgs& a, bool big);
 int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s);
 // ISHAP_IGEMM4: 0 = never, 1 = 128x128 tiles only, 2 (default) = every shape igemm4 takes
@@ -339,8 +337,6 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
   int prof_slot = -1;
   auto fire = [&]() -> int {
-    static const int use3 = [] { const char* e = getenv("ISHAP_IGEMM3"); return e ? atoi(e) : 0; }();   // 1 = big tiles, 2 = all
-    if (BK == 64 && CONV3 && use3 && (use3 > 1 || BM == 128) && igemm3_applicable(a, BM == 128)) return igemm3_launch_main(a, BM == 128, s);
     if (BK == 64 && CONV3 && igemm4_wanted(a, BM == 128)) return igemm4_launch_main(a, BM == 128, s);
     if (BK == 64) return igemm2_launch_main(a, BM == 128, s);
     if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(256), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a);

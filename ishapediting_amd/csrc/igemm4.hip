@@ -7,7 +7,7 @@
 // so the lever is staged bytes per FLOP.  igemm2 stages a BM x 64 activation slab per K-step, i.e. nine times per
 // (pixel, channel); here K runs (chunk, dy, dx) with dx innermost and the slab of (chunk, dy) is staged once and read at
 // three pixel shifts: activation traffic / 3, operand traffic / 1.5.
-// What igemm3.hip (round 1-3, the same idea) got wrong and this kernel does differently:
+// What igemm3.hip (rounds 1-3, the same idea, never faster than igemm2; removed in round 4) got wrong and this kernel does differently:
 //   * no halo columns or padded pitch: the slab is exactly the BM pixels of the tile (BM / 8 DMA instructions, as in igemm2);
 //     a lane whose shifted pixel falls off the image row reads a zero row kept at the end of every slab slot;
 //   * every fragment address (3 shifts x 2 K halves) is precomputed once per lane; a K-step costs one v_add per ds_read

@@ -578,7 +578,7 @@ def test_runtime_switches_keep_the_results(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    runs = {"default": {}, "ISHAP_IGEMM3=1": {"ISHAP_IGEMM3": "1"}, "ISHAP_HALVES=1": {"ISHAP_HALVES": "1"},
+    runs = {"default": {}, "ISHAP_HALVES=1": {"ISHAP_HALVES": "1"},
             "ISHAP_LOCAL_GN=0": {"ISHAP_LOCAL_GN": "0"}, "ISHAP_SKINNY=0": {"ISHAP_SKINNY": "0"},
             "ISHAP_SMALL3=0": {"ISHAP_SMALL3": "0"}, "ISHAP_GN_PARTS=1": {"ISHAP_GN_PARTS": "1"},
             "ISHAP_PREFETCH=1": {"ISHAP_PREFETCH": "1"}, "ISHAP_IGEMM4=0": {"ISHAP_IGEMM4": "0"},

@@ -5,7 +5,6 @@
 #include <cmath>
 #include <vector>
 #include "../ishapediting_amd/csrc/igemm2.hip"
-#include "../ishapediting_amd/csrc/igemm3.hip"
 #include "../ishapediting_amd/csrc/igemm4.hip"
 #include "../ishapediting_amd/csrc/igemm_skinny.hip"
 #include "../ishapediting_amd/csrc/igemm_small3.hip"
@@ -67,7 +66,6 @@ int main(int argc, char** argv) {
     a.Wt = W + (size_t)(turn++ % nbuf) * wel;
     if (gen == 5) { IgemmArgs b = a; b.ksplit = ksplit; b.ws = ws; igemm_small3_launch(b, 0, 0); }
     else if (gen == 4) igemm_skinny_launch(a, mt, 0);
-    else if (gen == 3 && igemm3_applicable(a, big)) igemm3_launch_main(a, big, 0);
     else if (gen == 6 && igemm4_applicable(a, big)) igemm4_launch_main(a, big, 0);
     else igemm2_launch_main(a, big, 0);
   };
