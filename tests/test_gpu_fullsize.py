@@ -460,23 +460,40 @@ np.savez({out!r}, out=out.cpu().numpy(), tap=tap.float().cpu().numpy(), gx=gx.cp
 """
 
 
+def _run_fullsize_worker(tmp_path, name, env):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / (name + ".npz"))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _FUSE_WORKER.format(root=root, out=path)], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (name, r.stderr[-2000:])
+    return np.load(path)
+
+
 def test_groupnorm_fused_into_the_conv_epilogue_changes_no_bit(tmp_path):
     """ISHAP_FUSE_GN=1 (csrc/unet.hip conv_op, IgemmArgs::gn_out): on the 128^2 / 64^2 maps a ResBlock's second norm (+FiLM +SiLU,
     gd/unet.py:245-252) is applied in conv1's own epilogue behind an in-launch rendezvous on the group sums instead of a
     gn_apply launch.  Off by default (slower); when switched on the full-size model's output, tap and input
     gradient must be BITWISE those of the separate launches -- same sums, same rounding sequence (csrc/gn_act.h)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = {}
-    for name, env in (("default", {}), ("fused", {"ISHAP_FUSE_GN": "1"})):
-        path = str(tmp_path / (name + ".npz"))
-        e = dict(os.environ)
-        e.update(env)
-        r = subprocess.run([sys.executable, "-c", _FUSE_WORKER.format(root=root, out=path)], env=e, capture_output=True, text=True,
-                           timeout=600)
-        assert r.returncode == 0, (name, r.stderr[-2000:])
-        res[name] = np.load(path)
+    ref = _run_fullsize_worker(tmp_path, "default", {})
+    got = _run_fullsize_worker(tmp_path, "fused", {"ISHAP_FUSE_GN": "1"})
     for key in ("out", "tap", "gx"):
-        assert np.array_equal(res["default"][key], res["fused"][key]), key
+        assert np.array_equal(ref[key], got[key]), key
+
+
+def test_igemm4_against_igemm2_on_every_full_size_shape(tmp_path):
+    """The dx-reuse 3x3 kernel (csrc/igemm4.hip: 128x128 tiles incl. the folded 1x1 source and the upsampled source, 64x64 tiles
+    in one- and two-team form, maps 16 .. 128 wide) against the kernel it replaces (ISHAP_IGEMM4=0 -> igemm2.hip) on every
+    conv of the 421M-parameter model: forward output, the 64^2 x 512 tap, and the input gradient of a guided step.  Same
+    products, another summation order inside fp32 accumulators: relative L2 <= 2e-3 forward, 5e-3 gradient (fp16 maps; measured 0.9e-3 / 1.1e-3 / 1.9e-3 -- the two-team form alone moves them by 0.5-1.4e-3); the two-team
+    form off (ISHAP_IG4_TEAMS=0) likewise."""
+    ref = _run_fullsize_worker(tmp_path, "default", {})
+    for name, env in (("igemm2", {"ISHAP_IGEMM4": "0"}), ("oneteam", {"ISHAP_IG4_TEAMS": "0"})):
+        got = _run_fullsize_worker(tmp_path, name, env)
+        errs = {k: rel(torch.from_numpy(got[k]), torch.from_numpy(ref[k])) for k in ("out", "tap", "gx")}
+        print(f"{name}: " + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+        assert errs["out"] < 2e-3 and errs["tap"] < 2e-3 and errs["gx"] < 5e-3, (name, errs)
+        assert errs["out"] > 0 or name == "oneteam"          # the switch did select another kernel
