@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
-timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
+timeout -k 10 700 python bench.py --c4-shape-profile $O/shapes_c4.csv > $O/bench.json 2> $O/bench.err || exit 1
 tail -c 400 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
 # per-shape table from live events around each conv launch (its own run: the event records open gaps in the timeline)
@@ -17,5 +17,6 @@ python3 $R/tools/step_timeline.py $f > $O/step_timeline.txt
 rm -f $f
 cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
 python3 $R/tools/shape_table.py $O/shapes.csv > $O/shapes.txt
+grep -v '^#' $O/shapes_c4.csv > $O/shapes_c4_plain.csv; python3 $R/tools/shape_table.py $O/shapes_c4_plain.csv > $O/shapes_c4.txt
 echo trace done
 rm -rf $O/trace
