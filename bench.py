@@ -318,12 +318,14 @@ def spawn_workers(a):
     port = s.getsockname()[1]
     s.close()
     have = visible_gpu_count()                                 # sysfs / environment only: this parent never loads HIP
-    if have is not None and a.gpus > have:
+    if have is not None and a.gpus > have and not a.rehearse:
         sys.exit(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) are visible")
     procs = []
     for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if a.rehearse else str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if a.rehearse:
+            env["ISHAP_GN_PARTS"] = "1"      # several PROCESSES share the GPU: no in-launch rendezvous (include/ishap.h, Tenancy)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     live = list(procs)
@@ -351,6 +353,9 @@ def main():
     ap.add_argument("--c2-steps", type=int, default=1000)
     ap.add_argument("--no-c2-batch8", action="store_true", help="skip the batch-8 generate leg (generate.py's default batch)")
     ap.add_argument("--no-c4", action="store_true", help="skip the real-shape leg (BASELINE configs[3]) after the headline")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on ONE GPU: every rank uses cuda:0 and the collectives run over gloo on host copies -- a rehearsal of "
+                         "the multi-rank control flow (spawn, rendezvous, barriers, gather, per-rank report), NOT a measurement")
     ap.add_argument("--c4-shape-profile", default=None, help="write the per-shape conv/GEMM CSV of the reconstruction step here")
     ap.add_argument("--shape-profile", default=None, help="write the per-shape conv/GEMM timing CSV of one edit here")
     a = ap.parse_args()
@@ -363,9 +368,14 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    comm_dev = device                                          # where collective operands live: the GPU under RCCL
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if a.rehearse:
+            comm_dev = torch.device("cpu")
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from ishapediting_amd import synthetic, _lib
     ds = make_dragstuff(device, 1234 + rank % 3)           # three weight sets stand for chair / car / plane
@@ -383,7 +393,7 @@ def main():
         torch.cuda.synchronize()
 
     from ishapediting_amd.parallel import gather_volumes
-    recv = [torch.empty((RES, RES, RES), dtype=torch.float32, device=device) for _ in range(world)] \
+    recv = [torch.empty((RES, RES, RES), dtype=torch.float32, device=comm_dev) for _ in range(world)] \
         if (world > 1 and rank == 0) else None
 
     # per-rank diagnostics of the N > 1 run (no host synchronisation inside the timed region): events on this rank's
@@ -398,7 +408,7 @@ def main():
         vol = one_edit(ds, src, tgt)
         e1.record()
         if world > 1:     # the path's only collective: every rank's occupancy volume to rank 0 (RCCL gather, 67 MB per rank)
-            gather_volumes([vol], world, dst=0, full_shape=(RES, RES, RES), recv=recv)
+            gather_volumes([vol.to(comm_dev)], world, dst=0, full_shape=(RES, RES, RES), recv=recv)
         e2.record()
         return vol
 
@@ -410,7 +420,7 @@ def main():
         vol = step()
     barrier()
     dt = time.time() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -418,7 +428,7 @@ def main():
     sec_per_shape = dt / shapes
     torch.cuda.synchronize()
     mine = torch.tensor([sum(e[0].elapsed_time(e[1]) for e in ev[a.warmup:]) / a.steps,
-                         sum(e[1].elapsed_time(e[2]) for e in ev[a.warmup:]) / a.steps, t_setup * 1e3], dtype=torch.float64, device=device)
+                         sum(e[1].elapsed_time(e[2]) for e in ev[a.warmup:]) / a.steps, t_setup * 1e3], dtype=torch.float64, device=comm_dev)
     per_rank = [mine.clone() for _ in range(world)]
     if world > 1:
         dist.all_gather(per_rank, mine)
@@ -537,6 +547,8 @@ def main():
             "roofline": roofline, "roofline_small_maps": small_maps, "cpu_baseline": cpu,
             "per_rank": per_rank,
         }
+        if a.rehearse:
+            line["data"] = "synthetic; REHEARSAL (all ranks on one GPU, gloo on host copies): not a measurement"
         if cpu:
             line["speedup_vs_cpu_baseline"] = round(cpu["value"] / sec_per_shape, 1)
         if world == 1 and not (a.no_c2 and a.no_c4):
