@@ -207,6 +207,55 @@ def c2_generate_leg(device, steps=1000, batch=1):
                        "(a shape-like 256^3 volume takes surface_extract_ms_sphere256)"}
 
 
+def concurrent_edits_leg(device, ds, src, tgt, seed, reps=2):
+    """Two and three INDEPENDENT C3 edits at once on one GPU: more model contexts (each its own weights, latent, guidance cache) on
+    their own streams, each driven from its own host thread -- what a server with more queued edits than GPUs would do (BASELINE
+    configs[4] shards 8 edits over 8 GPUs; with 24 queued it would run three per GPU).  Reported NEXT to the headline, never as
+    it: the headline is one edit per GPU, as the reference's DragStuff handles one shape at a time (drag_utils.py:303-304).
+    The latency-bound chains fill each other's idle compute units (a guided step is 408 dependent launches, most of them
+    far from filling 256 CUs); the library's rendezvous tenancy (include/ishap.h) lets one context at a time use the in-launch
+    GroupNorm rendezvous, the others run the same kernels with one workgroup per group.  tools/concurrent_probe.py: 1 / 2 / 3 / 4
+    concurrent edits -> 0.1835 / 0.137 / 0.120 / 0.139 s per shape."""
+    import threading
+    from ishapediting_amd import synthetic
+    ctxs = [(ds, src, tgt, torch.cuda.Stream(device))]
+    for k in (1, 2):
+        d = make_dragstuff(device, seed + k)
+        d.update_latent_params(img=synthetic.latent(4 + k))
+        ctxs.append((d, *synthetic.handles(HANDLES, seed=23 + k), torch.cuda.Stream(device)))
+    torch.cuda.synchronize()
+    out = {}
+    for n in (2, 3):
+        errs = []
+
+        def run(c):
+            d, s_, t_, stream = c
+            try:
+                with torch.cuda.stream(stream):
+                    for _ in range(reps):
+                        one_edit(d, s_, t_)
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+        for _warm in (True, False):
+            ths = [threading.Thread(target=run, args=(c,)) for c in ctxs[:n]]
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            if errs:
+                raise errs[0]
+        out[f"concurrent{n}_edits_s_per_shape"] = round(dt / (n * reps), 4)
+        out[f"concurrent{n}_edits_latency_s"] = round(dt / reps, 4)
+    out["concurrent_edits_note"] = ("throughput of 2 / 3 independent C3 edits sharing one GPU (one context, stream and host thread each); "
+                                    "each edit then takes concurrent<n>_edits_latency_s; not the headline, which is one edit per GPU")
+    del ctxs[1:]
+    return out
+
+
 def airplane_like_mesh(device, res=128):
     """SURVEY 8(d) C4 input: a synthetic watertight "airplane-like" mesh -- the union of four ellipsoids (fuselage, wing,
     tail plane, fin) -- extracted on the device from its implicit function (csrc/surface.hip), vertices in [-1, 1]^3."""
@@ -353,6 +402,7 @@ def main():
     ap.add_argument("--c2-steps", type=int, default=1000)
     ap.add_argument("--no-c2-batch8", action="store_true", help="skip the batch-8 generate leg (generate.py's default batch)")
     ap.add_argument("--no-c4", action="store_true", help="skip the real-shape leg (BASELINE configs[3]) after the headline")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the two-concurrent-edits leg")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on ONE GPU: every rank uses cuda:0 and the collectives run over gloo on host copies -- a rehearsal of "
                          "the multi-rank control flow (spawn, rendezvous, barriers, gather, per-rank report), NOT a measurement")
@@ -551,6 +601,8 @@ def main():
             line["data"] = "synthetic; REHEARSAL (all ranks on one GPU, gloo on host copies): not a measurement"
         if cpu:
             line["speedup_vs_cpu_baseline"] = round(cpu["value"] / sec_per_shape, 1)
+        if world == 1 and not a.no_concurrent:
+            line.update(concurrent_edits_leg(device, ds, src, tgt, 1235))
         if world == 1 and not (a.no_c2 and a.no_c4):
             del ds                                                   # the edit context's arena + guidance cache
             torch.cuda.empty_cache()

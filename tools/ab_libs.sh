@@ -9,7 +9,7 @@ cd $R
 for round in 1 2; do
   for lib in "$@"; do
     cp $lib ishapediting_amd/libishap_hip.so
-    v=$(timeout -k 10 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-c2 --no-c4 2> $O/bench.err | python -c "import json,sys;print(json.loads(sys.stdin.read())['value'])") || exit 1
+    v=$(timeout -k 10 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-c2 --no-c4 --no-concurrent 2> $O/bench.err | python -c "import json,sys;print(json.loads(sys.stdin.read())['value'])") || exit 1
     echo "round $round $(basename $lib) s/shape $v"
   done
 done
@@ -17,7 +17,7 @@ cd /tmp && export TMPDIR=/tmp
 for lib in "$@"; do
   n=$(basename $lib .so)
   cp $R/$lib $R/ishapediting_amd/libishap_hip.so
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$n -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-c2 --no-c4 > $O/trace_$n.json 2> $O/trace_$n.err || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$n -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-c2 --no-c4 --no-concurrent > $O/trace_$n.json 2> $O/trace_$n.err || exit 1
   f=$(find $O/trace_$n -name "*kernel_trace.csv")
   python3 $R/tools/step_timeline.py $f > $O/step_$n.txt
   rm -rf $O/trace_$n
