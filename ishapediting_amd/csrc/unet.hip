@@ -259,7 +259,14 @@ long long* salloc(Exec& e, size_t count) {
   return u->stat_off <= u->stat_cap ? u->stat_base + o : nullptr;
 }
 
-bool exec_is_solo(const Exec& e) { return e.dry || (e.tenant && !e.u->tail_pending && (e.u->side == nullptr || e.s != e.u->side)); }
+// In-launch rendezvous (several workgroups per GroupNorm group) is allowed on a sequence that holds the device's tenancy and is
+// not the overlapped forward tail itself.  A tail still running on the side stream does not forbid it (round 4; it used to):
+// the tail never launches rendezvous grids (exec_is_solo is false for it), and kernels that wait for nobody cannot starve a
+// grid that does -- they finish and free their compute units (the same argument as for tenants, common.h).
+bool exec_is_solo(const Exec& e) {
+  static const int strict = [] { const char* v = getenv("ISHAP_SOLO_STRICT"); return v ? atoi(v) : 0; }();
+  return e.dry || (e.tenant && (!strict || !e.u->tail_pending) && (e.u->side == nullptr || e.s != e.u->side));
+}
 
 bool small_map(int HW) {
   static const int on = [] { const char* v = getenv("ISHAP_LOCAL_GN"); return v ? atoi(v) : 1; }();
