@@ -500,8 +500,17 @@ bool igemm4_two_teams(const IgemmArgs& a, bool big) {
   static const int min_steps = [] { const char* e = getenv("ISHAP_IG4_TEAM_STEPS"); return e ? atoi(e) : 48; }();
   return tiles <= 256 && 3 * groups + a.K2 / 64 >= min_steps;
 }
+// 128-pixel x 64-channel tiles (two image rows of a 64-wide map): for the 64^2 layers with >= 512 output channels the grid still
+// fills the chip (32 x 8 = 256 workgroups) and a K-step stages 13.3 KB for twice the FLOPs of a 64x64 tile's 10.7 KB
+bool igemm4_tall_tiles(const IgemmArgs& a, bool big) {
+  static const int on = [] { const char* e = getenv("ISHAP_IG4_TALL"); return e ? atoi(e) : 1; }();
+  if (big || !on || a.W != 64 || a.K2 != 0 || a.ksplit != 1 || a.M % 128 != 0 || (a.H * a.W) % 128 != 0) return false;
+  const long long tiles = (long long)(a.M / 128) * ((a.N + 63) / 64);
+  return tiles >= 224 && tiles <= 512;
+}
 int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
   if (big) return launch4<128, 128, 128, IG4_BIG_W, IG4_BIG_X>(a, s);
+  if (igemm4_tall_tiles(a, big)) return launch4<128, 64, 64, IG4_SMALL_W, IG4_SMALL_X>(a, s);
   if (igemm4_two_teams(a, big)) {
     if (a.W == 64) return launch4<64, 64, 64, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);
     if (a.W == 32) return launch4<64, 64, 32, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);

@@ -491,7 +491,7 @@ def test_igemm4_against_igemm2_on_every_full_size_shape(tmp_path):
     products, another summation order inside fp32 accumulators: relative L2 <= 2e-3 forward, 5e-3 gradient (fp16 maps; measured 0.9e-3 / 1.1e-3 / 1.9e-3 -- the two-team form alone moves them by 0.5-1.4e-3); the two-team
     form off (ISHAP_IG4_TEAMS=0) likewise."""
     ref = _run_fullsize_worker(tmp_path, "default", {})
-    for name, env in (("igemm2", {"ISHAP_IGEMM4": "0"}), ("oneteam", {"ISHAP_IG4_TEAMS": "0"})):
+    for name, env in (("igemm2", {"ISHAP_IGEMM4": "0"}), ("oneteam", {"ISHAP_IG4_TEAMS": "0", "ISHAP_IG4_TALL": "0"})):
         got = _run_fullsize_worker(tmp_path, name, env)
         errs = {k: rel(torch.from_numpy(got[k]), torch.from_numpy(ref[k])) for k in ("out", "tap", "gx")}
         print(f"{name}: " + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
