@@ -18,16 +18,14 @@
 // row under the lane grouping of MI355X_MICROARCH.md (LDS table), which the shifted reads need; the weight slab keeps
 // igemm2's chunk ^ ((row >> 1) & 7).
 // Reference arithmetic: conv2d 3x3, padding 1 (gd/unet.py ResBlock in_layers / out_layers, :236-256) and its input
-// gradient (flipped, transposed weights); results are bit-identical to igemm2's (same products, same fp32 MFMA order of K
-// within a 64-channel chunk is NOT the same -- the K order differs, so values agree to fp32 summation order only).
+// gradient (flipped, transposed weights).  Same products as igemm2, another order of the K sum inside the fp32
+// accumulators: the two kernels agree to summation order (tests/test_gpu_fullsize.py: <= 2e-3 relative over the full model).
 #include "common.h"
 #include "igemm_epilogue.h"
 #include <type_traits>
 
 __device__ __attribute__((aligned(128))) half_t g_zero_line4[64];   // zero-initialised: source of out-of-image rows
 typedef __attribute__((address_space(3))) void lds_void4;
-
-
 
 // loads a loader wave issues for K-steps a .. b of a slice's 3x3 part (WI weight instructions each, XI more where a slab starts)
 constexpr int ig4_loads(int a, int b, int wi, int xi) {
