@@ -427,6 +427,7 @@ bool igemm_small3_wanted(const IgemmArgs& a) {
   // wins, tools/s3_probe.sh), 2: every map up to 32x32, 0: off
   static const int mode = [] { const char* e = getenv("ISHAP_SMALL3"); return e ? atoi(e) : 1; }();
   if (!mode || !a.conv3 || a.H * a.W > (mode == 2 ? 1024 : 64)) return false;
+  if (a.defer_reduce && a.ksplit > 1 && igemm4_small_map_slices(a) == a.ksplit && igemm4_wanted(a, false)) return false;   // conv_op chose igemm4's sliced launch
   IgemmArgs t = a;
   t.ksplit = 1;
   return igemm_small3_applicable(t);

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, co
   constexpr int RAMP = DIST - PRO;                 // iterations that issue two K-steps
   static_assert(RAMP <= 6, "ramp iterations are peeled by hand");
   static_assert(NSTX * 3 >= DIST + 3, "activation ring too shallow for the prefetch distance");
-  static_assert(BM % WD == 0 && WD % 16 == 0, "a tile is whole image rows; a 16-pixel MFMA sub-tile stays inside a row");
+  static_assert(BM % WD == 0, "a tile is whole image rows (fragment addresses are per lane, so a 16-pixel MFMA sub-tile may span rows)");
   static_assert(DIST * (WI + XI) <= 40, "ig4_wait_vm covers up to 40 outstanding loads");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
@@ -472,9 +472,30 @@ bool igemm4_applicable(const IgemmArgs& a, bool big) {
   // the folded second source runs with a short lookahead (one slab per step, NSTX - 1 ahead): worth it on the 128-tiles
   // (-11 %), a loss on the 64-tiles (+4..18 %, profiles/round4_igemm4_probe_v4.txt) -- those stay with igemm2
   if (a.K2 && !big) return false;
-  if (big ? a.W != 128 : (a.W != 16 && a.W != 32 && a.W != 64)) return false;
+  if (big ? a.W != 128 : (a.W != 16 && a.W != 32 && a.W != 64 && !(a.W == 8 && a.H == 8 && a.ksplit > 1))) return false;
   if (BM % a.W != 0 || (a.H * a.W) % BM != 0 || a.M % BM != 0) return false;
   return true;
+}
+
+// The 8x8 maps (one tile = one image): K slices for a sliced launch whose consumer adds the slices up, 0 = leave the shape to
+// conv3_small (igemm_small3.hip).  Enough slices for ~one workgroup per CU: the harness has 16 x 16 workgroups at 8.1 us against
+// conv3_small's 9.1 (1024 -> 1024), 11.3 against 15.1 (2048 -> 1024), 11.1 against 16.4 (1024 -> 2048)
+// (profiles/round4_igemm4_w8_probe.txt).  ISHAP_IG4_W8=0 switches it off, ISHAP_IG4_W8_WGS sets the workgroup target.
+int igemm4_small_map_slices(const IgemmArgs& a) {
+  static const int on = [] {
+    const char* e = getenv("ISHAP_IG4_W8");
+    const char* all = getenv("ISHAP_IGEMM4");      // igemm.hip: 2 (default) = every shape igemm4 takes
+    return (e ? atoi(e) : 1) && (all ? atoi(all) : 2) > 1;
+  }();
+  static const int target = [] { const char* e = getenv("ISHAP_IG4_W8_WGS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 256; }();
+  if (!on || !a.conv3 || a.W != 8 || a.H != 8 || a.nbatch != 1 || a.K2 != 0 || a.Cin % 64 != 0 || a.M % 64 != 0 || a.K != 9 * a.Cin) return 0;
+  const int tiles = (a.M / 64) * ((a.N + 63) / 64), G = 3 * (a.Cin / 64);
+  int ks = (target + tiles / 2) / tiles;
+  if (ks > 16) ks = 16;
+  if (ks > G) ks = G;
+  if (ks < 2) return 0;
+  const int per = (G + ks - 1) / ks;
+  return (G + per - 1) / per;                      // no empty slice
 }
 
 #ifndef IG4_BIG_W
@@ -512,9 +533,11 @@ int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
   if (igemm4_two_teams(a, big)) {
     if (a.W == 64) return launch4<64, 64, 64, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);
     if (a.W == 32) return launch4<64, 64, 32, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);
+    if (a.W == 8) return launch4<64, 64, 8, IG4_SMALL_W, IG4_SMALL_X>(a, s);
     return launch4<64, 64, 16, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);
   }
   if (a.W == 64) return launch4<64, 64, 64, IG4_SMALL_W, IG4_SMALL_X>(a, s);
   if (a.W == 32) return launch4<64, 64, 32, IG4_SMALL_W, IG4_SMALL_X>(a, s);
+  if (a.W == 8) return launch4<64, 64, 8, IG4_SMALL_W, IG4_SMALL_X>(a, s);
   return launch4<64, 64, 16, IG4_SMALL_W, IG4_SMALL_X>(a, s);
 }

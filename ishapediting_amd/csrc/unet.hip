@@ -295,7 +295,12 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
   a.flops_scale = (Wt == e.u->head.w) ? 1.f / 3.f : 1.f;
   a.ksplit = igemm_pick_ksplit(a.M, a.N, a.K, 1);
   if (!a.conv3 && a.M <= 64 && a.K % 64 == 0) a.ksplit = 1;   // 1x1 GEMMs on the 8x8 maps: the one-launch small-map kernel (10.7 vs 16.2 us at K = 3072)
-  if (igemm_small3_wanted(a)) a.ksplit = pend_out ? igemm_small3_slices(a) : 1;   // 3x3 on maps <= 32x32: igemm_small3.hip, K sliced over workgroups only when the consumer adds slices up
+  if (igemm_small3_wanted(a)) {
+    // 3x3 on the 8x8 maps: K sliced over workgroups only when the consumer adds the slices up -- then igemm4's 64x64 tiles with
+    // ~16 slices (igemm4_small_map_slices), else conv3_small (igemm_small3.hip) in one launch
+    const int s4 = pend_out ? igemm4_small_map_slices(a) : 0;
+    a.ksplit = s4 > 1 ? s4 : pend_out ? igemm_small3_slices(a) : 1;
+  }
   if (pend_out) *pend_out = SlabSrc{};
   if (pend_out && a.ksplit > 1) {
     // the consumer adds the slices up itself: they live in the arena until it has run
