@@ -121,10 +121,10 @@ __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, co
   const int NC = h.Cin / BK;                       // 64-channel chunks
   const int NC2 = (int)(h.packed >> 25);           // 64-channel chunks of the folded second source (launcher: K2 / 64)
   const int G = 3 * NC;                            // slab groups (chunk, dy), three K-steps (dx) each
-  // this K slice: groups [g0, g1) of the 3x3 part; the LAST slice also takes the second source
-  const int per = (G + h.ksplit - 1) / h.ksplit;
+  // this K slice: groups [g0, g1) of the 3x3 part and chunks [c20, c21) of the second source, both dealt out evenly
+  const int per = (G + h.ksplit - 1) / h.ksplit, per2 = (NC2 + h.ksplit - 1) / h.ksplit;
   int g0 = min(G, ks_id * per), g1 = min(G, g0 + per);
-  int c20 = 0, c21 = ks_id == h.ksplit - 1 ? NC2 : 0;
+  int c20 = min(NC2, ks_id * per2), c21 = min(NC2, c20 + per2);
   int nk_loop = (g1 - g0) * 3 + (c21 - c20);       // barrier count: identical for every wave of the workgroup
   if (HALVES == 2) {
     // team 0: the first ~half of the steps as whole groups; team 1: the other groups and the second source
@@ -471,8 +471,10 @@ bool igemm4_applicable(const IgemmArgs& a, bool big) {
   if (a.K2 && (a.K2 % 64 != 0 || a.K2 / 64 > 127 || !a.X2)) return false;
   // the folded second source runs with a short lookahead (one slab per step, NSTX - 1 ahead): worth it on the 128-tiles
   // (-11 %), a loss on the 64-tiles (+4..18 %, profiles/round4_igemm4_probe_v4.txt) -- those stay with igemm2
-  if (a.K2 && !big) return false;
-  if (big ? a.W != 128 : (a.W != 16 && a.W != 32 && a.W != 64 && !(a.W == 8 && a.H == 8 && a.ksplit > 1))) return false;
+  // (the sliced launches on the 8x8 maps excepted: there the alternative is conv3_small, at 26 us for K = 9216 + 2048)
+  const bool w8 = !big && a.W == 8 && a.H == 8 && a.ksplit > 1;
+  if (a.K2 && !big && !w8) return false;
+  if (big ? a.W != 128 : (a.W != 16 && a.W != 32 && a.W != 64 && !w8)) return false;
   if (BM % a.W != 0 || (a.H * a.W) % BM != 0 || a.M % BM != 0) return false;
   return true;
 }
@@ -488,14 +490,16 @@ int igemm4_small_map_slices(const IgemmArgs& a) {
     return (e ? atoi(e) : 1) && (all ? atoi(all) : 2) > 1;
   }();
   static const int target = [] { const char* e = getenv("ISHAP_IG4_W8_WGS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 256; }();
-  if (!on || !a.conv3 || a.W != 8 || a.H != 8 || a.nbatch != 1 || a.K2 != 0 || a.Cin % 64 != 0 || a.M % 64 != 0 || a.K != 9 * a.Cin) return 0;
+  static const int k2on = [] { const char* e = getenv("ISHAP_IG4_W8_K2"); return e ? atoi(e) : 1; }();
+  if (!on || !a.conv3 || a.W != 8 || a.H != 8 || a.nbatch != 1 || a.Cin % 64 != 0 || a.M % 64 != 0 || a.K != 9 * a.Cin + a.K2) return 0;
+  if (a.K2 && (!k2on || a.K2 % 64 != 0 || a.K2 / 64 > 127 || !a.X2)) return 0;
   const int tiles = (a.M / 64) * ((a.N + 63) / 64), G = 3 * (a.Cin / 64);
   int ks = (target + tiles / 2) / tiles;
   if (ks > 16) ks = 16;
   if (ks > G) ks = G;
   if (ks < 2) return 0;
   const int per = (G + ks - 1) / ks;
-  return (G + per - 1) / per;                      // no empty slice
+  return (G + per - 1) / per;                      // no slice without 3x3 groups (the second source's chunks are dealt out likewise)
 }
 
 #ifndef IG4_BIG_W
