@@ -260,7 +260,9 @@ int ishap_surface_emit(const float* volume, int res, float level, int method, vo
 /* in place: v <- (v + sum of neighbours) / (1 + number of neighbours), `iterations` Jacobi sweeps (each neighbour once:
  * Open3D's filter_smooth_simple).  box_max > 0: the vertices are in grid coordinates of a [0, box_max]^3 volume and the
  * mesh may be open where the surface leaves the box (edges lying in a box face belong to one triangle); box_max <= 0: the
- * mesh is closed.  scratch: 32*nverts bytes */
+ * mesh is closed.  scratch: ishap_mesh_smooth_scratch_bytes(nverts, ntris) device bytes (the vertex adjacency, built once per
+ * call, and a second vertex buffer; ~28 bytes per vertex + 24 per triangle).  Vertex indices and 6*ntris must fit 32 bits. */
+long long ishap_mesh_smooth_scratch_bytes(long long nverts, long long ntris);
 int ishap_mesh_smooth(float* verts, long long nverts, const int* tris, long long ntris, int iterations, float box_max,
                       void* scratch, void* stream);
 /* out2[0] = mean over a of min_b |a-b|^2, out2[1] = mean over b of min_a |a-b|^2 (device floats; their sum is the

@@ -473,7 +473,8 @@ bool igemm4_applicable(const IgemmArgs& a, bool big) {
   // (-11 %), a loss on the 64-tiles (+4..18 %, profiles/round4_igemm4_probe_v4.txt) -- those stay with igemm2
   // (the sliced launches on the 8x8 maps excepted: there the alternative is conv3_small, at 26 us for K = 9216 + 2048)
   const bool w8 = !big && a.W == 8 && a.H == 8 && a.ksplit > 1;
-  if (a.K2 && !big && !w8) return false;
+  static const int k2_small = [] { const char* e = getenv("ISHAP_IG4_K2_SMALL"); return e ? atoi(e) : 0; }();
+  if (a.K2 && !big && !w8 && !k2_small) return false;
   if (big ? a.W != 128 : (a.W != 16 && a.W != 32 && a.W != 64 && !w8)) return false;
   if (BM % a.W != 0 || (a.H * a.W) % BM != 0 || a.M % BM != 0) return false;
   return true;

@@ -240,9 +240,14 @@ __global__ __launch_bounds__(SB_THREADS) void surf_emit_triangles_kernel(SurfArg
 }
 
 // ---- filter_smooth_simple: v <- (v + sum of neighbours) / (1 + #neighbours) -------------------------------------
-// Neighbours are gathered face by face (each directed edge of a face adds its head to its tail).  Inside a closed
-// surface every undirected edge lies in exactly two faces, so each neighbour arrives twice: v <- (v + acc/2) / (1 + cnt/2).
-// Accumulation in 64-bit fixed point keeps the result independent of the atomic order.
+// Neighbours are listed face by face (each directed edge of a face lists its head under its tail).  Inside a closed
+// surface every undirected edge lies in exactly two faces, so each neighbour is listed twice: v <- (v + acc/2) / (1 + cnt/2).
+// The lists are built ONCE per call as a CSR adjacency (count -> exclusive scan -> fill; 9 32-bit atomics per triangle in
+// total) and every sweep is a gather, one thread per vertex, from the previous sweep's positions -- no atomics in the sweeps
+// (round 4; the earlier form added every head to its tail with 64-bit atomics in every sweep: 18 ms per sweep on the 26 M
+// triangles of a noise volume, 0.2 ms on a 300 k-triangle sphere).  The order of a vertex's list depends on the fill's
+// atomics; the sum does not: it is formed in 64-bit fixed point (integer adds commute), so the result is bitwise
+// reproducible and identical to the atomic form's.
 constexpr float SMOOTH_SCALE = 1048576.f;     // 2^20: coordinates < 2^11, valence sums < 2^20 -> < 2^51
 
 // which of the six faces of the grid box [0, bmax]^3 a vertex lies on (bit 2*axis: coordinate 0, bit 2*axis+1: bmax)
@@ -258,11 +263,78 @@ __global__ void smooth_boundary_mask_kernel(const float* __restrict__ v, long lo
   }
   mask[i] = m;
 }
+// list lengths: every face lists two heads under each of its corners
+__global__ void smooth_degree_kernel(const int* __restrict__ tris, long long ntris, unsigned* __restrict__ deg) {
+  const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= ntris) return;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) atomicAdd(deg + tris[3 * f + e], 2u);
+}
+// exclusive scan of `x` in place, three launches: per-block scan (SCAN_ITEMS per thread) + block totals, scan of the totals
+// by one workgroup, add-back; x[n] receives the grand total
+constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 8, SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* lds, unsigned& total) {
+  // wave-level inclusive scan, then the wave totals through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  unsigned inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned t = __shfl_up(inc, d);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+  for (int w = 0; w < nw; ++w) {
+    const unsigned t = lds[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  total = tot;
+  return base + inc - v;
+}
+__global__ __launch_bounds__(SCAN_THREADS) void scan_blocks_kernel(unsigned* __restrict__ x, long long n, unsigned* __restrict__ totals) {
+  __shared__ unsigned lds[16];
+  const long long i0 = (long long)blockIdx.x * SCAN_BLOCK + (long long)threadIdx.x * SCAN_ITEMS;
+  unsigned v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = i0 + k < n ? x[i0 + k] : 0u; sum += v[k]; }
+  unsigned total;
+  unsigned run = block_exclusive_scan(sum, lds, total);
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    if (i0 + k < n) x[i0 + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void scan_totals_kernel(unsigned* __restrict__ totals, long long nb, unsigned* __restrict__ grand) {
+  __shared__ unsigned lds[16];
+  unsigned carry = 0;
+  for (long long b0 = 0; b0 < nb; b0 += 1024) {
+    const long long i = b0 + threadIdx.x;
+    const unsigned v = i < nb ? totals[i] : 0u;
+    unsigned total;
+    const unsigned ex = block_exclusive_scan(v, lds, total);
+    if (i < nb) totals[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) *grand = carry;
+}
+__global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(unsigned* __restrict__ x, long long n, const unsigned* __restrict__ totals) {
+  const unsigned add = totals[blockIdx.x];
+  const long long i0 = (long long)blockIdx.x * SCAN_BLOCK + (long long)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k)
+    if (i0 + k < n) x[i0 + k] += add;
+}
 // An edge of a level-set mesh that lies IN a face of the grid box belongs to one triangle only (there is no cell on the
-// other side), every other edge to two; the lone occurrence of a boundary edge therefore counts double, so that after the
-// halving in smooth_apply each neighbour has weight one -- Open3D's unique-adjacency rule -- on open meshes too.
-__global__ void smooth_accumulate_kernel(const float* __restrict__ v, const int* __restrict__ tris, long long ntris,
-                                         long long* __restrict__ acc, unsigned* __restrict__ cnt, const unsigned* __restrict__ bmask) {
+// other side), every other edge to two; the lone occurrence of a boundary edge therefore counts double (bit 31 of its list
+// entry), so that after the halving in the sweep each neighbour has weight one -- Open3D's unique-adjacency rule -- on open
+// meshes too.
+__global__ void smooth_fill_kernel(const int* __restrict__ tris, long long ntris, const unsigned* __restrict__ off,
+                                   unsigned* __restrict__ cursor, unsigned* __restrict__ adj, const unsigned* __restrict__ bmask) {
   const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= ntris) return;
   const int i[3] = {tris[3 * f], tris[3 * f + 1], tris[3 * f + 2]};
@@ -270,32 +342,34 @@ __global__ void smooth_accumulate_kernel(const float* __restrict__ v, const int*
   if (bmask) { bm[0] = bmask[i[0]]; bm[1] = bmask[i[1]]; bm[2] = bmask[i[2]]; }
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
-    const int tail = i[e];
-    unsigned n = 0;
-#pragma unroll
-    for (int o = 1; o < 3; ++o) {
-      const int head = i[(e + o) % 3];
-      const float w = (bm[e] & bm[(e + o) % 3]) ? 2.f : 1.f;
-      n += (bm[e] & bm[(e + o) % 3]) ? 2u : 1u;
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        atomicAdd(reinterpret_cast<unsigned long long*>(acc + 3LL * tail + c),
-                  (unsigned long long)__float2ll_rn(v[3LL * head + c] * (w * SMOOTH_SCALE)));
-    }
-    atomicAdd(cnt + tail, n);
+    const int h1 = (e + 1) % 3, h2 = (e + 2) % 3;
+    const unsigned slot = off[i[e]] + atomicAdd(cursor + i[e], 2u);
+    adj[slot] = (unsigned)i[h1] | ((bm[e] & bm[h1]) ? 0x80000000u : 0u);
+    adj[slot + 1] = (unsigned)i[h2] | ((bm[e] & bm[h2]) ? 0x80000000u : 0u);
   }
 }
-__global__ void smooth_apply_kernel(float* __restrict__ v, long long nverts, long long* __restrict__ acc, unsigned* __restrict__ cnt) {
+__global__ void smooth_sweep_kernel(const float* __restrict__ vin, float* __restrict__ vout, long long nverts,
+                                    const unsigned* __restrict__ off, const unsigned* __restrict__ adj) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nverts) return;
-  const float half_n = 0.5f * (float)cnt[i];
+  const unsigned lo = off[i], hi = off[i + 1];
+  long long acc[3] = {0, 0, 0};
+  unsigned cnt = 0;
+  for (unsigned k = lo; k < hi; ++k) {
+    const unsigned e = adj[k];
+    const long long h = (long long)(e & 0x7fffffffu);
+    const bool dbl = (e >> 31) != 0u;
+    const float w = (dbl ? 2.f : 1.f) * SMOOTH_SCALE;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] += __float2ll_rn(vin[3 * h + c] * w);
+    cnt += dbl ? 2u : 1u;
+  }
+  const float half_n = 0.5f * (float)cnt;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float s = (float)acc[3 * i + c] * (1.f / SMOOTH_SCALE);
-    v[3 * i + c] = (v[3 * i + c] + 0.5f * s) / (1.f + half_n);
-    acc[3 * i + c] = 0;
+    const float sm = (float)acc[c] * (1.f / SMOOTH_SCALE);
+    vout[3 * i + c] = (vin[3 * i + c] + 0.5f * sm) / (1.f + half_n);
   }
-  cnt[i] = 0;
 }
 
 // ---- Chamfer: for every point of A the squared distance to its nearest point of B (exact differences) ------------
@@ -446,20 +520,57 @@ extern "C" int ishap_surface_emit(const float* volume, int res, float level, int
   return 0;
 }
 
+// scratch layout: off[nverts + 1] | cursor[nverts] | block totals | boundary mask[nverts] | second vertex buffer | adj[6 ntris]
+namespace {
+struct SmoothLayout { long long off, cursor, totals, bmask, vtmp, adj, bytes, nblocks; };
+SmoothLayout smooth_layout(long long nverts, long long ntris) {
+  auto up = [](long long b) { return (b + 255) / 256 * 256; };
+  SmoothLayout L;
+  L.nblocks = (nverts + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  L.off = 0;
+  L.cursor = up(L.off + 4 * (nverts + 1));
+  L.totals = up(L.cursor + 4 * nverts);
+  L.bmask = up(L.totals + 4 * (L.nblocks + 1));
+  L.vtmp = up(L.bmask + 4 * nverts);
+  L.adj = up(L.vtmp + 12 * nverts);
+  L.bytes = up(L.adj + 24 * ntris);
+  return L;
+}
+}  // namespace
+
+extern "C" long long ishap_mesh_smooth_scratch_bytes(long long nverts, long long ntris) {
+  if (nverts < 0 || ntris < 0) return -1;
+  return smooth_layout(nverts, ntris).bytes;
+}
+
 extern "C" int ishap_mesh_smooth(float* verts, long long nverts, const int* tris, long long ntris, int iterations, float box_max,
                                  void* scratch, void* stream) {
   ISHAP_REQUIRE(verts && tris && scratch && nverts >= 0 && ntris >= 0 && iterations >= 0, "mesh_smooth arguments");
-  if (nverts == 0 || ntris == 0) return 0;
+  ISHAP_REQUIRE(nverts < (1ll << 31) && 6 * ntris < (1ll << 32), "mesh_smooth: 32-bit vertex indices and list offsets");
+  if (nverts == 0 || ntris == 0 || iterations == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  long long* acc = (long long*)scratch;
-  unsigned* cnt = (unsigned*)(acc + 3 * nverts);
-  unsigned* bmask = box_max > 0.f ? cnt + nverts : nullptr;
-  ISHAP_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)nverts * 28, s));
-  if (bmask) hipLaunchKernelGGL(smooth_boundary_mask_kernel, dim3((unsigned)((nverts + 255) / 256)), dim3(256), 0, s, verts, nverts, box_max, bmask);
+  const SmoothLayout L = smooth_layout(nverts, ntris);
+  char* base = (char*)scratch;
+  unsigned* off = (unsigned*)(base + L.off);
+  unsigned* cursor = (unsigned*)(base + L.cursor);
+  unsigned* totals = (unsigned*)(base + L.totals);
+  unsigned* bmask = box_max > 0.f ? (unsigned*)(base + L.bmask) : nullptr;
+  float* vtmp = (float*)(base + L.vtmp);
+  unsigned* adj = (unsigned*)(base + L.adj);
+  const unsigned tb = (unsigned)((ntris + 255) / 256), vb = (unsigned)((nverts + 255) / 256);
+  ISHAP_CHECK_HIP(hipMemsetAsync(base, 0, (size_t)L.totals, s));              // list lengths and fill cursors
+  if (bmask) hipLaunchKernelGGL(smooth_boundary_mask_kernel, dim3(vb), dim3(256), 0, s, verts, nverts, box_max, bmask);
+  hipLaunchKernelGGL(smooth_degree_kernel, dim3(tb), dim3(256), 0, s, tris, ntris, off);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)L.nblocks), dim3(SCAN_THREADS), 0, s, off, nverts + 1, totals);
+  hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, s, totals, L.nblocks, totals + L.nblocks);
+  hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)L.nblocks), dim3(SCAN_THREADS), 0, s, off, nverts + 1, totals);
+  hipLaunchKernelGGL(smooth_fill_kernel, dim3(tb), dim3(256), 0, s, tris, ntris, off, cursor, adj, bmask);
   for (int it = 0; it < iterations; ++it) {
-    hipLaunchKernelGGL(smooth_accumulate_kernel, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, s, verts, tris, ntris, acc, cnt, bmask);
-    hipLaunchKernelGGL(smooth_apply_kernel, dim3((unsigned)((nverts + 255) / 256)), dim3(256), 0, s, verts, nverts, acc, cnt);
+    const float* src = (it & 1) ? vtmp : verts;
+    float* dst = (it & 1) ? verts : vtmp;
+    hipLaunchKernelGGL(smooth_sweep_kernel, dim3(vb), dim3(256), 0, s, src, dst, nverts, off, adj);
   }
+  if (iterations & 1) ISHAP_CHECK_HIP(hipMemcpyAsync(verts, vtmp, (size_t)nverts * 12, hipMemcpyDeviceToDevice, s));
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

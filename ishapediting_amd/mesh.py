@@ -77,7 +77,10 @@ def smooth_mesh(verts: torch.Tensor, tris: torch.Tensor, iterations: int = 10, b
     tris = tris.detach().to(torch.int32).contiguous()
     if out.shape[0] == 0 or tris.shape[0] == 0 or iterations <= 0:
         return out
-    scratch = torch.empty(out.shape[0] * 32, dtype=torch.uint8, device=out.device)
+    nbytes = int(_lib.lib().ishap_mesh_smooth_scratch_bytes(out.shape[0], tris.shape[0]))
+    if nbytes < 0:
+        raise RuntimeError("ishap_mesh_smooth_scratch_bytes: invalid sizes")
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=out.device)
     with torch.cuda.device(out.device):
         _lib.check(_lib.lib().ishap_mesh_smooth(out.data_ptr(), out.shape[0], tris.data_ptr(), tris.shape[0], int(iterations),
                                                 float(box_max), scratch.data_ptr(), _lib.stream_ptr(out.device)))
