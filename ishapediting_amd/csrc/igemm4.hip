@@ -530,7 +530,8 @@ bool igemm4_tall_tiles(const IgemmArgs& a, bool big) {
   static const int on = [] { const char* e = getenv("ISHAP_IG4_TALL"); return e ? atoi(e) : 1; }();
   if (big || !on || a.W != 64 || a.K2 != 0 || a.ksplit != 1 || a.M % 128 != 0 || (a.H * a.W) % 128 != 0) return false;
   const long long tiles = (long long)(a.M / 128) * ((a.N + 63) / 64);
-  return tiles >= 224 && tiles <= 512;
+  static const int tmin = [] { const char* e = getenv("ISHAP_IG4_TALL_MIN"); return e ? atoi(e) : 224; }();
+  return tiles >= tmin && tiles <= 512;
 }
 int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
   if (big) return launch4<128, 128, 128, IG4_BIG_W, IG4_BIG_X>(a, s);
