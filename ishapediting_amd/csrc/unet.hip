@@ -294,7 +294,13 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
   a.out_mode = out_mode;
   a.flops_scale = (Wt == e.u->head.w) ? 1.f / 3.f : 1.f;
   a.ksplit = igemm_pick_ksplit(a.M, a.N, a.K, 1);
-  if (!a.conv3 && a.M <= 64 && a.K % 64 == 0) a.ksplit = 1;   // 1x1 GEMMs on the 8x8 maps: the one-launch small-map kernel (10.7 vs 16.2 us at K = 3072)
+  if (!a.conv3 && a.M <= 64 && a.K % 64 == 0) {
+    // 1x1 GEMMs on the 8x8 maps: the one-launch small-map kernel (10.7 vs 16.2 us at K = 3072) -- unless the consumer adds K
+    // slices up and K is long: then the tiled kernel with 8-16 slices left pending (harness, K = 3072 -> 1024: 5.0 us against
+    // the skinny kernel's 8.1; at K = 1024 the two tie, profiles/round4_gemm1x1_slices_probe.txt).  ISHAP_G1_SLICES=0: off
+    static const int sliced = [] { const char* v = getenv("ISHAP_G1_SLICES"); return v ? atoi(v) : 1; }();
+    a.ksplit = (sliced && pend_out && a.K >= 2048) ? (a.K >= 3072 ? 16 : 8) : 1;
+  }
   if (igemm_small3_wanted(a)) {
     // 3x3 on the 8x8 maps: K sliced over workgroups only when the consumer adds the slices up -- then igemm4's 64x64 tiles with
     // ~16 slices (igemm4_small_map_slices), else conv3_small (igemm_small3.hip) in one launch
