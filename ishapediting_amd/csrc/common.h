@@ -295,5 +295,5 @@ bool igemm_small3_wanted(const IgemmArgs& a);
 int igemm_small3_slices(const IgemmArgs& a);      // K slices that fill the chip (consumer must be able to add them up)    // the one-launch small-map 3x3 kernel takes this shape (then no split-K)
 int igemm4_small_map_slices(const IgemmArgs& a);  // igemm4.hip: K slices of its sliced launch on an 8x8 map (consumer adds them up), 0 = not taken
 // picks a split so the grid fills the chip; returns workspace floats needed
-int igemm_pick_ksplit(int M, int N, int K, int nbatch);
+int igemm_pick_ksplit(int M, int N, int K, int nbatch, bool pending = false);   // pending: the consumer adds the slices up (no reduce launch)
 int igemm_stat_launch_workgroups(const IgemmArgs& a);

@@ -395,17 +395,21 @@ int igemm_stat_launch_workgroups(const IgemmArgs& a) {
   const int bm = big ? 128 : 64;
   return (a.M / bm) * ceil_div(a.N, bm) * a.ksplit;
 }
-int igemm_pick_ksplit(int M, int N, int K, int nbatch) {
+int igemm_pick_ksplit(int M, int N, int K, int nbatch, bool pending) {
   const bool big = igemm_use_big(M, N, nbatch);
   const int bm = big ? 128 : 64, bn = big ? 128 : 64;
   long long blocks = (long long)(M / bm) * ceil_div(N, bn) * nbatch;
   int ks = K / 64;
   static const int nosplit = [] { const char* e = getenv("ISHAP_NOSPLIT_STEPS"); return e ? atoi(e) : 36; }();   // in situ: 36 beats 24 / 48 by ~0.5 %
-  if (ks < nosplit) return 1;        // below ~36 K-steps the extra reduce launch (~5.5 us) costs more than the split saves (harness sweep: ~48; in situ: 36)
-  int split = 1;
   static const int fill = [] { const char* e = getenv("ISHAP_SPLIT_FILL"); return e ? atoi(e) : 224; }();   // in-situ sweep (tools/sweep_split_policy.sh): plateau 208..256, 1 % better than 160
   static const int minsteps = [] { const char* e = getenv("ISHAP_SPLIT_MINSTEPS"); return e ? atoi(e) : 6; }();
-  while (blocks * split < fill && ks / (split * 2) >= minsteps && split < 32) split *= 2;
+  // slices whose consumer adds them up cost no reduce launch: thresholds of their own (ISHAP_PEND_NOSPLIT / ISHAP_PEND_MINSTEPS)
+  // in situ 12 / 3 against 36 / 6: 0.1783 -> 0.1777 s/shape (profiles/round4_env_ab_pending_split.txt)
+  static const int p_nosplit = [] { const char* e = getenv("ISHAP_PEND_NOSPLIT"); return e ? atoi(e) : 12; }();
+  static const int p_minsteps = [] { const char* e = getenv("ISHAP_PEND_MINSTEPS"); return e ? atoi(e) : 3; }();
+  if (ks < (pending ? p_nosplit : nosplit)) return 1;        // below ~36 K-steps the extra reduce launch (~5.5 us) costs more than the split saves (harness sweep: ~48; in situ: 36)
+  int split = 1;
+  while (blocks * split < fill && ks / (split * 2) >= (pending ? p_minsteps : minsteps) && split < 32) split *= 2;
   return split;
 }
 

@@ -293,7 +293,7 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
   a.H = H; a.W = W; a.ups = ups; a.res_ups = res_ups;
   a.out_mode = out_mode;
   a.flops_scale = (Wt == e.u->head.w) ? 1.f / 3.f : 1.f;
-  a.ksplit = igemm_pick_ksplit(a.M, a.N, a.K, 1);
+  a.ksplit = igemm_pick_ksplit(a.M, a.N, a.K, 1, pend_out != nullptr);
   if (!a.conv3 && a.M <= 64 && a.K % 64 == 0) {
     // 1x1 GEMMs on the 8x8 maps: the one-launch small-map kernel (10.7 vs 16.2 us at K = 3072) -- unless the consumer adds K
     // slices up and K is long: then the tiled kernel with 8-16 slices left pending (harness, K = 3072 -> 1024: 5.0 us against
