@@ -498,6 +498,7 @@ def test_igemm4_against_igemm2_on_every_full_size_shape(tmp_path):
         errs = {k: rel(torch.from_numpy(got[k]), torch.from_numpy(ref[k])) for k in ("out", "tap", "gx")}
         print(f"{name}: " + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
         assert errs["out"] < 2e-3 and errs["tap"] < 2e-3 and errs["gx"] < 5e-3, (name, errs)
-        # the switch did select another kernel ("skinny": the sliced 1x1 GEMMs only occur in the 8x8 level's attention backward,
-        # where this worker's 1e-2 cotangent has left the fp16 range -- the same bits either way, tools/g1_debug.py)
+        # the switch did select another kernel ("skinny": the six sliced 1x1 GEMMs are the qkv input gradients of the 8x8 level's
+        # attention blocks; their fp32 summation-order differences survive neither the fp16 rounding of that gradient nor its
+        # addition to the much larger residual-path gradient -- the same bits either way here, tools/g1_debug.py)
         assert errs["out"] > 0 or errs["gx"] > 0 or name in ("oneteam", "skinny"), name
