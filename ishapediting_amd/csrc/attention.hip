@@ -201,7 +201,37 @@ __global__ __launch_bounds__(256 * TEAMS) void attn_fwd_kernel(const void* h_qkv
 // Same transposed arrangement as the forward: S^T = K Q^T and dP^T = V dA^T put one query in a lane (lse and D_q are
 // per-lane scalars), dS^T is packed in registers as the B operand of dQ^T = K^T dS^T, and K^T comes from the row-major
 // K tile through the transposed LDS read.  Nothing is staged transposed and nothing round-trips through LDS.
-template <int D>
+// team merge of the backward bodies: NA accumulator quads per thread, TEAMS = 2: team 1 -> team 0; TEAMS = 4: teams 2, 3 ->
+// teams 0, 1, then team 1 -> team 0 (fixed order (t0 + t2) + (t1 + t3): bitwise reproducible).  mrg: (TEAMS / 2) * NA * 256 quads.
+// Returns false for the teams that are done (they have passed every barrier of the merge).
+template <int NA, int TEAMS>
+__device__ __forceinline__ bool attn_bwd_merge(f32x4 (&acc)[NA], int team, int tid, float* mrg) {
+  if (blockDim.x == 256) return true;          // a single tile is launched with one team
+  f32x4* m4 = reinterpret_cast<f32x4*>(mrg);   // [slot][NA][256] 16-byte entries
+  if (TEAMS == 4) {
+    if (team >= 2) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) m4[((team - 2) * NA + i) * 256 + tid] = acc[i];
+    }
+    __syncthreads();
+    if (team < 2) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) acc[i] += m4[(team * NA + i) * 256 + tid];
+    }
+    __syncthreads();
+  }
+  if (team == 1) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) m4[i * 256 + tid] = acc[i];
+  }
+  __syncthreads();
+  if (team != 0) return false;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) acc[i] += m4[i * 256 + tid];
+  return true;
+}
+
+template <int D, int TEAMS>
 __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int n, int team, half_t* sK, half_t* sV, float* mrg) {
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
@@ -231,21 +261,21 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int n, int t
 #pragma unroll
   for (int i = 0; i < DS; ++i) dqt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   TileRegs<D> rk, rv;
-  const int ntile = a.T / 64, niter = (ntile + 1) / 2;       // two teams on alternating key tiles, as in the forward
+  const int ntile = a.T / 64, niter = (ntile + TEAMS - 1) / TEAMS;       // the teams take alternating key tiles, as in the forward
   if (team < ntile) {
     load_tile<D>(base + (long long)(team * 64) * ld + D, ld, rk, tid);
     load_tile<D>(base + (long long)(team * 64) * ld + 2 * D, ld, rv, tid);
   }
   for (int it = 0; it < niter; ++it) {
-    const int kt = (2 * it + team) * 64;
+    const int kt = (TEAMS * it + team) * 64;
     const bool live = kt < a.T;
     __syncthreads();
     if (live) {
       store_tile<D>(rk, sK, tid);
       store_tile<D>(rv, sV, tid);
-      if (kt + 128 < a.T) {
-        load_tile<D>(base + (long long)(kt + 128) * ld + D, ld, rk, tid);
-        load_tile<D>(base + (long long)(kt + 128) * ld + 2 * D, ld, rv, tid);
+      if (kt + 64 * TEAMS < a.T) {
+        load_tile<D>(base + (long long)(kt + 64 * TEAMS) * ld + D, ld, rk, tid);
+        load_tile<D>(base + (long long)(kt + 64 * TEAMS) * ld + 2 * D, ld, rv, tid);
       }
     }
     __syncthreads();
@@ -276,20 +306,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int n, int t
         dqt[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, sb[pr], dqt[i], 0, 0, 0);
       }
   }
-  // team 1 hands its sums to team 0 (fixed order: team 0 + team 1)
-  if (team == 1) {
-#pragma unroll
-    for (int i = 0; i < DS; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mrg[(i * 4 + r) * 256 + tid] = dqt[i][r];
-  }
-  __syncthreads();
-  if (team == 1) return;
+  // the other teams hand their sums to team 0 (fixed order, attn_bwd_merge)
+  if (!attn_bwd_merge<DS, TEAMS>(dqt, team, tid, mrg)) return;
 #pragma unroll
   for (int i = 0; i < DS; ++i) {
-    if (blockDim.x == 512)                   // (a single tile is launched with one team)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dqt[i][r] += mrg[(i * 4 + r) * 256 + tid];
     const half4 o4 = {(half_t)dqt[i][0], (half_t)dqt[i][1], (half_t)dqt[i][2], (half_t)dqt[i][3]};
     *reinterpret_cast<half4*>(a.dqkv + ((long long)n * a.T + q) * ld + h * 3 * D + i * 16 + 4 * g) = o4;
   }
@@ -300,7 +320,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int n, int t
 // Here the scores are produced UN-transposed (S = Q K^T, dP = dA V^T: accumulator row = query, column = key) so a lane
 // owns one key and 16 queries of the tile: P and dS are packed in registers as the B operands of dV^T = dA^T P and
 // dK^T = Q^T dS, whose A operands come from the row-major dA / Q tiles through the transposed LDS read.
-template <int D>
+template <int D, int TEAMS>
 __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, int team, half_t* sQ, half_t* sA, float* sD,
                                                   float* mrg) {
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
@@ -320,28 +340,27 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, int 
     kf[kk] = *reinterpret_cast<const half8*>(row + D);
     vf[kk] = *reinterpret_cast<const half8*>(row + 2 * D);
   }
-  f32x4 dkt[DS], dvt[DS];                    // dK^T / dV^T: row d = i*16 + 4g + r, column = this lane's key
+  f32x4 acc[2 * DS];                         // dK^T (acc[i]) / dV^T (acc[DS + i]): row d = i*16 + 4g + r, column = this lane's key
 #pragma unroll
-  for (int i = 0; i < DS; ++i) { dkt[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvt[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < 2 * DS; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // D_q = sum_d dA[q][d] * A[q][d] of the tile's 64 queries is recomputed here from the dA tile this workgroup stages
   // anyway plus the matching rows of the forward output: the dQ and dK/dV passes then share no data and run as ONE
   // launch (256 instead of 128 workgroups at T = 1024, one launch floor instead of two).
   TileRegs<D> rq, ra, ro;
-  f32x4 lse_n[4];                            // lse of the prefetched tile's queries sub*16 + 4g + (0..3)
+  float lse_n = 0.f;                         // lse of query `tid` of the prefetched tile (threads 0..63; staged in sD[64..127] with the tile)
   const half_t* abase = a.dout + (long long)n * a.T * a.C + h * D;
   const half_t* obase = a.out + (long long)n * a.T * a.C + h * D;
-  const float* lsep = a.lse + bh * a.T + 4 * g;
-  const int ntile = a.T / 64, niter = (ntile + 1) / 2;       // two teams on alternating query tiles
+  const float* lsep = a.lse + bh * a.T + (tid & 63);
+  const int ntile = a.T / 64, niter = (ntile + TEAMS - 1) / TEAMS;       // the teams take alternating query tiles
   if (team < ntile) {
     const long long q0r = (long long)team * 64;
     load_tile<D>(base + q0r * ld, ld, rq, tid);
     load_tile<D>(abase + q0r * a.C, a.C, ra, tid);
     load_tile<D>(obase + q0r * a.C, a.C, ro, tid);
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub) lse_n[sub] = *reinterpret_cast<const f32x4*>(lsep + q0r + sub * 16);
+    if (tid < 64) lse_n = lsep[q0r];
   }
   for (int it = 0; it < niter; ++it) {
-    const int qt = (2 * it + team) * 64;
+    const int qt = (TEAMS * it + team) * 64;
     const bool live = qt < a.T;
     __syncthreads();
     if (live) {
@@ -358,21 +377,16 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, int 
       const int c = tid + i * 256;
       if (c < 64 * CPR && c % CPR == 0) sD[c / CPR] = dot;
     }
+    if (tid < 64) sD[64 + tid] = lse_n;
     }
-    f32x4 lse_c[4], dq_c[4];
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub) lse_c[sub] = lse_n[sub];
-    if (live && qt + 128 < a.T) {
-      load_tile<D>(base + (long long)(qt + 128) * ld, ld, rq, tid);
-      load_tile<D>(abase + (long long)(qt + 128) * a.C, a.C, ra, tid);
-      load_tile<D>(obase + (long long)(qt + 128) * a.C, a.C, ro, tid);
-#pragma unroll
-      for (int sub = 0; sub < 4; ++sub) lse_n[sub] = *reinterpret_cast<const f32x4*>(lsep + qt + 128 + sub * 16);
+    if (live && qt + 64 * TEAMS < a.T) {
+      load_tile<D>(base + (long long)(qt + 64 * TEAMS) * ld, ld, rq, tid);
+      load_tile<D>(abase + (long long)(qt + 64 * TEAMS) * a.C, a.C, ra, tid);
+      load_tile<D>(obase + (long long)(qt + 64 * TEAMS) * a.C, a.C, ro, tid);
+      if (tid < 64) lse_n = lsep[qt + 64 * TEAMS];
     }
     __syncthreads();
     if (!live) continue;
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub) dq_c[sub] = *reinterpret_cast<const f32x4*>(sD + sub * 16 + 4 * g);
     half8 pb[2], sb[2];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
@@ -382,11 +396,13 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, int 
         sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sQ, RS, sub * 16, kk * 32, lane), kf[kk], sc, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(sA, RS, sub * 16, kk * 32, lane), vf[kk], dp, 0, 0, 0);
       }
+      const f32x4 dq4 = *reinterpret_cast<const f32x4*>(sD + sub * 16 + 4 * g);         // D_q and lse of queries sub*16 + 4g + (0..3)
+      const f32x4 ls4 = *reinterpret_cast<const f32x4*>(sD + 64 + sub * 16 + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = __expf(sc[r] * a.alpha - lse_c[sub][r]);
+        const float pv = __expf(sc[r] * a.alpha - ls4[r]);
         pb[sub >> 1][(sub & 1) * 4 + r] = (half_t)pv;
-        sb[sub >> 1][(sub & 1) * 4 + r] = (half_t)(a.alpha * pv * (dp[r] - dq_c[sub][r]));
+        sb[sub >> 1][(sub & 1) * 4 + r] = (half_t)(a.alpha * pv * (dp[r] - dq4[r]));
       }
     }
 #pragma unroll
@@ -398,56 +414,41 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, int 
         const half4 qlo = lds_read_tr4(sQ + off + (2 * pr) * 16 * RS), qhi = lds_read_tr4(sQ + off + (2 * pr + 1) * 16 * RS);
         const half8 aa = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
         const half8 qa = {qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
-        dvt[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aa, pb[pr], dvt[i], 0, 0, 0);
-        dkt[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, sb[pr], dkt[i], 0, 0, 0);
+        acc[DS + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aa, pb[pr], acc[DS + i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, sb[pr], acc[i], 0, 0, 0);
       }
   }
-  if (team == 1) {
-#pragma unroll
-    for (int i = 0; i < DS; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        mrg[(i * 4 + r) * 256 + tid] = dkt[i][r];
-        mrg[(DS * 4 + i * 4 + r) * 256 + tid] = dvt[i][r];
-      }
-  }
-  __syncthreads();
-  if (team == 1) return;
-  if (blockDim.x == 512)
-#pragma unroll
-    for (int i = 0; i < DS; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dkt[i][r] += mrg[(i * 4 + r) * 256 + tid];
-        dvt[i][r] += mrg[(DS * 4 + i * 4 + r) * 256 + tid];
-      }
+  if (!attn_bwd_merge<2 * DS, TEAMS>(acc, team, tid, mrg)) return;
   half_t* row = a.dqkv + ((long long)n * a.T + key) * ld + h * 3 * D;
 #pragma unroll
   for (int i = 0; i < DS; ++i) {
-    const half4 k4 = {(half_t)dkt[i][0], (half_t)dkt[i][1], (half_t)dkt[i][2], (half_t)dkt[i][3]};
-    const half4 v4 = {(half_t)dvt[i][0], (half_t)dvt[i][1], (half_t)dvt[i][2], (half_t)dvt[i][3]};
+    const half4 k4 = {(half_t)acc[i][0], (half_t)acc[i][1], (half_t)acc[i][2], (half_t)acc[i][3]};
+    const half4 v4 = {(half_t)acc[DS + i][0], (half_t)acc[DS + i][1], (half_t)acc[DS + i][2], (half_t)acc[DS + i][3]};
     *reinterpret_cast<half4*>(row + D + i * 16 + 4 * g) = k4;
     *reinterpret_cast<half4*>(row + 2 * D + i * 16 + 4 * g) = v4;
   }
 }
 
 // blockIdx.z = 2 n + role: role 0 = dQ of 64 queries, role 1 = dK/dV of 64 keys (independent of each other, see above)
-// Each workgroup is two teams of four waves on alternating tiles (own staging buffers, shared barriers), merged at the end.
-template <int D>
-__global__ __launch_bounds__(512) void attn_bwd_kernel(const void* h_qkv, const void* h_out, const void* h_dout, void* h_dqkv, float* h_lse,
-                                                       float* h_Dbuf, int h_T, int h_C, AttnArgs a0) {
+// Each workgroup is TEAMS (2 or 4) teams of four waves on alternating tiles (own staging buffers, shared barriers), merged at the
+// end.  Two teams by default; the four-team form is a measured loss (attn_backward_launch).
+// dynamic LDS: [TEAMS] tile A, [TEAMS] tile B, [TEAMS][64 D_q | 64 lse], merge area (TEAMS / 2) * 2 * DS * 4 * 256 floats
+template <int D, int TEAMS>
+__global__ __launch_bounds__(256 * TEAMS) void attn_bwd_kernel(const void* h_qkv, const void* h_out, const void* h_dout, void* h_dqkv, float* h_lse,
+                                                               float* h_Dbuf, int h_T, int h_C, AttnArgs a0) {
   AttnArgs a = a0;                           // preloaded leading parameters, as in attn_fwd_kernel
   a.qkv = reinterpret_cast<const half_t*>(h_qkv); a.out = const_cast<half_t*>(reinterpret_cast<const half_t*>(h_out));
   a.dout = reinterpret_cast<const half_t*>(h_dout); a.dqkv = reinterpret_cast<half_t*>(h_dqkv); a.lse = h_lse; a.Dbuf = h_Dbuf;
   a.T = h_T; a.C = h_C;
-  constexpr int RS = D + 8, DS = D / 16;
-  __shared__ __attribute__((aligned(16))) half_t s0[2][64 * RS];
-  __shared__ __attribute__((aligned(16))) half_t s1[2][64 * RS];
-  __shared__ __attribute__((aligned(16))) float sD[2][64];
-  __shared__ float mrg[2 * DS * 4 * 256];
+  constexpr int RS = D + 8;
+  extern __shared__ __attribute__((aligned(16))) char attn_bwd_smem[];
+  half_t* s0 = reinterpret_cast<half_t*>(attn_bwd_smem);
+  half_t* s1 = s0 + TEAMS * 64 * RS;
+  float* sD = reinterpret_cast<float*>(s1 + TEAMS * 64 * RS);
+  float* mrg = sD + TEAMS * 128;
   const int n = blockIdx.z >> 1, team = threadIdx.x >> 8;
-  if ((blockIdx.z & 1) == 0) attn_bwd_dq_body<D>(a, n, team, s0[team], s1[team], mrg);
-  else attn_bwd_dkv_body<D>(a, n, team, s0[team], s1[team], sD[team], mrg);
+  if ((blockIdx.z & 1) == 0) attn_bwd_dq_body<D, TEAMS>(a, n, team, s0 + team * 64 * RS, s1 + team * 64 * RS, mrg);
+  else attn_bwd_dkv_body<D, TEAMS>(a, n, team, s0 + team * 64 * RS, s1 + team * 64 * RS, sD + team * 128, mrg);
 }
 
 static int check_attn(const AttnArgs& a) {
@@ -480,9 +481,23 @@ int attn_forward_launch(const AttnArgs& a, hipStream_t s) {
 int attn_backward_launch(const AttnArgs& a, hipStream_t s) {
   ISHAP_TRY(check_attn(a));
   dim3 g(a.T / 64, a.heads, a.N * 2);
-  const dim3 blk(a.T > 64 ? 512 : 256);      // one tile: the second team would have nothing to do
-  if (a.d == 64) hipLaunchKernelGGL(attn_bwd_kernel<64>, g, blk, 0, s, (const void*)a.qkv, (const void*)a.out, (const void*)a.dout, (void*)a.dqkv, a.lse, a.Dbuf, a.T, a.C, a);
-  else hipLaunchKernelGGL(attn_bwd_kernel<32>, g, blk, 0, s, (const void*)a.qkv, (const void*)a.out, (const void*)a.dout, (void*)a.dqkv, a.lse, a.Dbuf, a.T, a.C, a);
+  // one tile: a second team would have nothing to do.  Four teams (ISHAP_ATTN_BWD_TEAMS=4: from 4 tiles on) are built and tested
+  // but NOT the default: at 1024 threads the kernel is held to 128 registers (20 bytes of spills) and in situ the step is slower
+  // than with two teams (0.1772 vs 0.1779-0.1782 s/shape, profiles/round4_env_ab_attention_bwd_teams.txt)
+  static const int teams_env = [] { const char* e = getenv("ISHAP_ATTN_BWD_TEAMS"); return e ? atoi(e) : 0; }();
+  const int ntile = a.T / 64;
+  const bool four = teams_env == 4 && ntile >= 4;
+#define ATTN_BWD(Dv, TM, THREADS)                                                                                              \
+  do {                                                                                                                         \
+    auto kern = attn_bwd_kernel<Dv, TM>;                                                                                       \
+    const int smem = TM * 2 * 64 * (Dv + 8) * (int)sizeof(half_t) + TM * 128 * 4 + (TM / 2) * 2 * (Dv / 16) * 4 * 256 * 4;       \
+    ISHAP_TRY(ishap_set_max_lds((const void*)kern, smem));                                                                     \
+    hipLaunchKernelGGL(kern, g, dim3(THREADS), smem, s, (const void*)a.qkv, (const void*)a.out, (const void*)a.dout,           \
+                       (void*)a.dqkv, a.lse, a.Dbuf, a.T, a.C, a);                                                             \
+  } while (0)
+  if (a.d == 64) { if (four) ATTN_BWD(64, 4, 1024); else ATTN_BWD(64, 2, a.T > 64 ? 512 : 256); }
+  else { if (four) ATTN_BWD(32, 4, 1024); else ATTN_BWD(32, 2, a.T > 64 ? 512 : 256); }
+#undef ATTN_BWD
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
