@@ -364,10 +364,57 @@ __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, co
       for (int j = 0; j < MT; ++j) acc[0][j][1] += (float)xf[j][0];
 #endif
     };
+#ifdef IG4_INTERLEAVE
+    // MFMAs of one 32-deep half with the fragment reads of the NEXT half in their gaps (one read behind each of the first MT + NT
+    // MFMAs, pinned by scheduling barriers): issued in a burst the eight reads and their address adds kept the MFMA pipe idle for
+    // ~100 cycles twice per K-step (the wave issues in order, the reads sat behind the sixteenth MFMA)
+    auto read_one = [&](const unsigned (&xs)[2][MT], int kk, unsigned swo, unsigned sxo, half8 (&xf)[MT], half8 (&wf)[NT], int r) __attribute__((always_inline)) {
+      if (r < MT) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[r]) : "v"(xs[kk][r] + sxo) : "memory");
+      else asm volatile("ds_read_b128 %0, %1" : "=v"(wf[r - MT]) : "v"(wo[kk][r - MT] + swo) : "memory");
+    };
+    auto mfma_reads = [&](half8 (&xf)[MT], half8 (&wf)[NT], const unsigned (&xs)[2][MT], int kk, unsigned swo, unsigned sxo, half8 (&xn)[MT],
+                          half8 (&wn)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          const int r = i * MT + j;
+          if (r < MT + NT) {
+            read_one(xs, kk, swo, sxo, xn, wn, r);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    };
+#endif
     using std::integral_constant;
     // one K-step at shift DX (= dx + 1): second half read under the MFMAs of the first, first half of the next step read
     // right after its barrier.  SLAB_ENDS: the step is the last one on its slab (dx = +1, or any step of the second
     // source).  The next step reads at shift (DX + 1) % 3 inside the 3x3 part and unshifted (1) in the second source.
+#ifdef IG4_INTERLEAVE
+    auto step = [&](auto DX, auto SLAB_ENDS, int s) {
+      constexpr int d = decltype(DX)::value;
+      wait_frags(integral_constant<int, 0>{}, xa, wa);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_reads(xa, wa, xo[d], 1, sw_off, sx_off, xb, wb);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_frags(integral_constant<int, 0>{}, xb, wb);
+      sw_off = sw_off + WSLOT * 2 == NSTW * WSLOT * 2 ? 0u : sw_off + WSLOT * 2;
+      if (decltype(SLAB_ENDS)::value) sx_off = sx_off + XSLOT * 2 == NSTX * XSLOT * 2 ? 0u : sx_off + XSLOT * 2;
+      if (s + 1 < nk_loop) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 1 < ns) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (decltype(SLAB_ENDS)::value && s + 1 >= ns3) mfma_reads(xb, wb, xo[1], 0, sw_off, sx_off, xa, wa);
+          else mfma_reads(xb, wb, xo[(d + 1) % 3], 0, sw_off, sx_off, xa, wa);
+          __builtin_amdgcn_sched_barrier(0);
+          return;
+        }
+      }
+      mfma_half(xb, wb);
+    };
+#else
     auto step = [&](auto DX, auto SLAB_ENDS, int s) {
       constexpr int d = decltype(DX)::value;
       read_half(DX, 1, sw_off, sx_off, xb, wb);
@@ -389,6 +436,7 @@ __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, co
       }
       mfma_half(xb, wb);
     };
+#endif
     if (nk_loop > 0) __builtin_amdgcn_s_barrier();      // step 0 has landed (every wave passes nk_loop barriers)
     asm volatile("" ::: "memory");
     IG_STAMP(2, wave_all == 0);
