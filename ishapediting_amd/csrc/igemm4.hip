@@ -364,7 +364,6 @@ __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, co
       for (int j = 0; j < MT; ++j) acc[0][j][1] += (float)xf[j][0];
 #endif
     };
-#ifdef IG4_INTERLEAVE
     // MFMAs of one 32-deep half with the fragment reads of the NEXT half in their gaps (one read behind each of the first MT + NT
     // MFMAs, pinned by scheduling barriers): issued in a burst the eight reads and their address adds kept the MFMA pipe idle for
     // ~100 cycles twice per K-step (the wave issues in order, the reads sat behind the sixteenth MFMA)
@@ -386,13 +385,14 @@ __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, co
           }
         }
     };
-#endif
     using std::integral_constant;
     // one K-step at shift DX (= dx + 1): second half read under the MFMAs of the first, first half of the next step read
     // right after its barrier.  SLAB_ENDS: the step is the last one on its slab (dx = +1, or any step of the second
     // source).  The next step reads at shift (DX + 1) % 3 inside the 3x3 part and unshifted (1) in the second source.
-#ifdef IG4_INTERLEAVE
-    auto step = [&](auto DX, auto SLAB_ENDS, int s) {
+    // 128x128 tiles (MFMA-paced K loop): the interleaved form, -1.5 / -2.2 % per launch (128^2: 256->256 26.2 -> 25.8 us, 512->256
+    // 43.2 -> 42.2; profiles/round4_igemm4_interleave_probe.txt); on the 64x64 tiles (paced by the staging) it is 1-3 % slower in situ
+    constexpr bool INTERLEAVE = BM == 128 && BN == 128;
+    auto step_il = [&](auto DX, auto SLAB_ENDS, int s) {
       constexpr int d = decltype(DX)::value;
       wait_frags(integral_constant<int, 0>{}, xa, wa);
       __builtin_amdgcn_sched_barrier(0);
@@ -414,8 +414,7 @@ __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, co
       }
       mfma_half(xb, wb);
     };
-#else
-    auto step = [&](auto DX, auto SLAB_ENDS, int s) {
+    auto step_burst = [&](auto DX, auto SLAB_ENDS, int s) {
       constexpr int d = decltype(DX)::value;
       read_half(DX, 1, sw_off, sx_off, xb, wb);
       wait_frags(integral_constant<int, MT + NT>{}, xa, wa);
@@ -436,7 +435,10 @@ __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, co
       }
       mfma_half(xb, wb);
     };
-#endif
+    auto step = [&](auto DX, auto SLAB_ENDS, int s) __attribute__((always_inline)) {
+      if constexpr (INTERLEAVE) step_il(DX, SLAB_ENDS, s);
+      else step_burst(DX, SLAB_ENDS, s);
+    };
     if (nk_loop > 0) __builtin_amdgcn_s_barrier();      // step 0 has landed (every wave passes nk_loop barriers)
     asm volatile("" ::: "memory");
     IG_STAMP(2, wave_all == 0);
@@ -523,7 +525,9 @@ bool igemm4_applicable(const IgemmArgs& a, bool big) {
   const bool w8 = !big && a.W == 8 && a.H == 8 && a.ksplit > 1;
   static const int k2_small = [] { const char* e = getenv("ISHAP_IG4_K2_SMALL"); return e ? atoi(e) : 0; }();
   if (a.K2 && !big && !w8 && !k2_small) return false;
-  if (big ? a.W != 128 : (a.W != 16 && a.W != 32 && a.W != 64 && !w8)) return false;
+  // (128-pixel tiles on maps narrower than 128: several image rows per tile -- the batched generate path, where M = batch * H * W
+  // fills the chip with 128x128 tiles on the 64^2 ... 16^2 maps)
+  if (big ? (a.W != 128 && a.W != 64 && a.W != 32 && a.W != 16) : (a.W != 16 && a.W != 32 && a.W != 64 && !w8)) return false;
   if (BM % a.W != 0 || (a.H * a.W) % BM != 0 || a.M % BM != 0) return false;
   return true;
 }
@@ -582,7 +586,12 @@ bool igemm4_tall_tiles(const IgemmArgs& a, bool big) {
   return tiles >= tmin && tiles <= 512;
 }
 int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
-  if (big) return launch4<128, 128, 128, IG4_BIG_W, IG4_BIG_X>(a, s);
+  if (big) {
+    if (a.W == 128) return launch4<128, 128, 128, IG4_BIG_W, IG4_BIG_X>(a, s);
+    if (a.W == 64) return launch4<128, 128, 64, IG4_BIG_W, IG4_BIG_X>(a, s);
+    if (a.W == 32) return launch4<128, 128, 32, IG4_BIG_W, IG4_BIG_X>(a, s);
+    return launch4<128, 128, 16, IG4_BIG_W, IG4_BIG_X>(a, s);
+  }
   if (igemm4_tall_tiles(a, big)) return launch4<128, 64, 64, IG4_SMALL_W, IG4_SMALL_X>(a, s);
   if (igemm4_two_teams(a, big)) {
     if (a.W == 64) return launch4<64, 64, 64, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);

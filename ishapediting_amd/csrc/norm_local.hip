@@ -87,22 +87,24 @@ __device__ __forceinline__ void add_f32(const float* p, float* acc) {
   }
 }
 
-// sum of the pending slices at (row, c .. c+VEC-1) in slice order.  Every slice load is issued before the first add
+// sum of the pending slices at (row, c .. c+VEC-1) in slice order.  Every slice load of a batch is issued before the first add
 // (NB loads in flight per lane: these kernels run on 32 CUs per image and are bound by load latency, not bandwidth);
 // NB = the slice count rounded up to a power of two, the surplus loads re-read the last slice and are not added.
+// At most 64 floats of slices are held at once (VEC = 8: batches of 8 slices -- sixteen at once spilled 300-420 bytes of
+// scratch per lane in the batch-8 generate path, profiles/round4_c2_trace_before.txt); the adds stay in slice order.
 template <int VEC, int NB>
-__device__ __forceinline__ void slab_sum_nb(const SlabSrc& s, const float* p, float* v) {
+__device__ __forceinline__ void slab_sum_nb(const float* p, long long zstride, int count, float* v) {
   float t[NB][VEC];
 #pragma unroll
   for (int z = 0; z < NB; ++z) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) t[z][i] = 0.f;
-    const int zz = z < s.nslab ? z : s.nslab - 1;
-    add_f32<VEC>(p + zz * s.zstride, t[z]);
+    const int zz = z < count ? z : count - 1;
+    add_f32<VEC>(p + zz * zstride, t[z]);
   }
 #pragma unroll
   for (int z = 0; z < NB; ++z) {
-    if (z < s.nslab) {
+    if (z < count) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) v[i] += t[z][i];
     }
@@ -113,12 +115,15 @@ __device__ __forceinline__ void slab_sum(const SlabSrc& s, long long row, int ld
 #pragma unroll
   for (int i = 0; i < VEC; ++i) v[i] = 0.f;
   const float* p = s.ws + row * ld + c;
-  if (s.nslab <= 2) slab_sum_nb<VEC, 2>(s, p, v);
-  else if (s.nslab <= 4) slab_sum_nb<VEC, 4>(s, p, v);
-  else if (s.nslab <= 8) slab_sum_nb<VEC, 8>(s, p, v);
-  else if (s.nslab <= 16) slab_sum_nb<VEC, 16>(s, p, v);
+  constexpr int MAXNB = VEC == 8 ? 8 : 16;
+  if (s.nslab <= 2) slab_sum_nb<VEC, 2>(p, s.zstride, s.nslab, v);
+  else if (s.nslab <= 4) slab_sum_nb<VEC, 4>(p, s.zstride, s.nslab, v);
+  else if (s.nslab <= 8) slab_sum_nb<VEC, 8>(p, s.zstride, s.nslab, v);
   else {
-    for (int z = 0; z < s.nslab; ++z) add_f32<VEC>(p + z * s.zstride, v);
+    for (int z0 = 0; z0 < s.nslab; z0 += MAXNB) {
+      const int cnt = s.nslab - z0 < MAXNB ? s.nslab - z0 : MAXNB;
+      slab_sum_nb<VEC, MAXNB>(p + z0 * s.zstride, s.zstride, cnt, v);
+    }
   }
 }
 
