@@ -55,6 +55,18 @@ __device__ __forceinline__ half4 lds_read_tr4(const half_t* p) {
   return __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
 }
 
+// XCD-aware workgroup -> work mapping.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), and every
+// XCD has an L2 of its own: with the plain (tile, head) grid the 16 query tiles of a head at T = 1024 sat on all 8 XCDs and
+// each L2 fetched the head's K and V (and Q / dA in the backward) for itself -- 17.9 MB fetched per forward launch for 3.1 MB of
+// qkv (profiles/round4_pmc_FETCH_SIZE.txt).  Work item w of `total` goes to the workgroup with linear id (w % P) * 8 + w / P
+// ... i.e. workgroup `lin` takes item (lin % 8) * P + lin / 8 with P = total / 8: XCD c owns the contiguous items [c P, (c+1) P),
+// and the items are ordered so that everything that reads one head's tensors is contiguous.  ISHAP_ATTN_XCD=0: identity.
+__device__ __forceinline__ int attn_xcd_item(int lin, int total, int on) {
+  if (!on || (total & 7) != 0) return lin;
+  const int P = total >> 3;
+  return (lin & 7) * P + (lin >> 3);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Forward.  Scores are produced TRANSPOSED (S^T = K Q^T: accumulator row = key, column = query), so a lane owns ONE
 // query (column l&15) and 16 of the tile's 64 keys: the running max / sum are per-lane scalars finished with two
@@ -84,7 +96,9 @@ __global__ __launch_bounds__(256 * TEAMS) void attn_fwd_kernel(const void* h_qkv
   const int team = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   half_t* const sK = sK2 + team * 64 * RS;
   half_t* const sV = sV2 + team * 64 * VS;
-  const int q0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+  // item = tile + ntile * (head + heads * image)
+  const int item = attn_xcd_item(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z, a0.xcd_map);
+  const int q0 = (item % (int)gridDim.x) * 64, h = (item / (int)gridDim.x) % (int)gridDim.y, n = item / (int)(gridDim.x * gridDim.y);
   const int ld = 3 * a.C;
   const int g = lane >> 4, col = lane & 15;
   const half_t* base = a.qkv + (long long)n * a.T * ld + h * 3 * D;
@@ -232,10 +246,10 @@ __device__ __forceinline__ bool attn_bwd_merge(f32x4 (&acc)[NA], int team, int t
 }
 
 template <int D, int TEAMS>
-__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int n, int team, half_t* sK, half_t* sV, float* mrg) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int n, int tile, int h, int team, half_t* sK, half_t* sV, float* mrg) {
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-  const int q0 = blockIdx.x * 64, h = blockIdx.y;
+  const int q0 = tile * 64;
   const int ld = 3 * a.C;
   const int g = lane >> 4, col = lane & 15;
   const half_t* base = a.qkv + (long long)n * a.T * ld + h * 3 * D;
@@ -321,13 +335,13 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int n, int t
 // owns one key and 16 queries of the tile: P and dS are packed in registers as the B operands of dV^T = dA^T P and
 // dK^T = Q^T dS, whose A operands come from the row-major dA / Q tiles through the transposed LDS read.
 template <int D, int TEAMS>
-__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, int team, half_t* sQ, half_t* sA, float* sD,
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, int tile, int h, int team, half_t* sQ, half_t* sA, float* sD,
                                                   float* mrg) {
   constexpr int RS = D + 8, KK = D / 32, DS = D / 16;
   constexpr int CPR = D / 8, NCH = (64 * CPR + 255) / 256;
   static_assert(CPR == 8 || CPR == 4, "row sums below reduce over CPR consecutive lanes");
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-  const int k0 = blockIdx.x * 64, h = blockIdx.y;
+  const int k0 = tile * 64;
   const int ld = 3 * a.C;
   const int g = lane >> 4, col = lane & 15;
   const half_t* base = a.qkv + (long long)n * a.T * ld + h * 3 * D;
@@ -429,7 +443,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, int 
   }
 }
 
-// blockIdx.z = 2 n + role: role 0 = dQ of 64 queries, role 1 = dK/dV of 64 keys (independent of each other, see above)
+// role 0 = dQ of 64 queries, role 1 = dK/dV of 64 keys (independent of each other, see above); grid (tiles, heads, 2 * images)
 // Each workgroup is TEAMS (2 or 4) teams of four waves on alternating tiles (own staging buffers, shared barriers), merged at the
 // end.  Two teams by default; the four-team form is a measured loss (attn_backward_launch).
 // dynamic LDS: [TEAMS] tile A, [TEAMS] tile B, [TEAMS][64 D_q | 64 lse], merge area (TEAMS / 2) * 2 * DS * 4 * 256 floats
@@ -446,9 +460,13 @@ __global__ __launch_bounds__(256 * TEAMS) void attn_bwd_kernel(const void* h_qkv
   half_t* s1 = s0 + TEAMS * 64 * RS;
   float* sD = reinterpret_cast<float*>(s1 + TEAMS * 64 * RS);
   float* mrg = sD + TEAMS * 128;
-  const int n = blockIdx.z >> 1, team = threadIdx.x >> 8;
-  if ((blockIdx.z & 1) == 0) attn_bwd_dq_body<D, TEAMS>(a, n, team, s0 + team * 64 * RS, s1 + team * 64 * RS, mrg);
-  else attn_bwd_dkv_body<D, TEAMS>(a, n, team, s0 + team * 64 * RS, s1 + team * 64 * RS, sD + team * 128, mrg);
+  // item = tile + ntile * (role + 2 * (head + heads * image)): both roles of a head next to each other (they read the same q, k, v, dA)
+  const int ntile = gridDim.x, heads = gridDim.y;
+  const int item = attn_xcd_item(blockIdx.x + ntile * (blockIdx.y + heads * blockIdx.z), ntile * heads * (int)gridDim.z, a0.xcd_map);
+  const int tile = item % ntile, role = (item / ntile) & 1, h = (item / (2 * ntile)) % heads, n = item / (2 * ntile * heads);
+  const int team = threadIdx.x >> 8;
+  if (role == 0) attn_bwd_dq_body<D, TEAMS>(a, n, tile, h, team, s0 + team * 64 * RS, s1 + team * 64 * RS, mrg);
+  else attn_bwd_dkv_body<D, TEAMS>(a, n, tile, h, team, s0 + team * 64 * RS, s1 + team * 64 * RS, sD + team * 128, mrg);
 }
 
 static int check_attn(const AttnArgs& a) {
@@ -457,7 +475,14 @@ static int check_attn(const AttnArgs& a) {
   return 0;
 }
 
-int attn_forward_launch(const AttnArgs& a, hipStream_t s) {
+static int attn_xcd_on() {
+  static const int on = [] { const char* e = getenv("ISHAP_ATTN_XCD"); return e ? atoi(e) : 1; }();
+  return on;
+}
+
+int attn_forward_launch(const AttnArgs& a_in, hipStream_t s) {
+  AttnArgs a = a_in;
+  a.xcd_map = attn_xcd_on();
   ISHAP_TRY(check_attn(a));
   dim3 g(a.T / 64, a.heads, a.N);
   // four teams once a team of two would walk >= 4 key tiles (ISHAP_ATTN_TEAMS=2 keeps two; =4 forces four from 4 tiles on)
@@ -478,7 +503,9 @@ int attn_forward_launch(const AttnArgs& a, hipStream_t s) {
   return 0;
 }
 
-int attn_backward_launch(const AttnArgs& a, hipStream_t s) {
+int attn_backward_launch(const AttnArgs& a_in, hipStream_t s) {
+  AttnArgs a = a_in;
+  a.xcd_map = attn_xcd_on();
   ISHAP_TRY(check_attn(a));
   dim3 g(a.T / 64, a.heads, a.N * 2);
   // one tile: a second team would have nothing to do.  Four teams (ISHAP_ATTN_BWD_TEAMS=4: from 4 tiles on) are built and tested
