@@ -332,7 +332,7 @@ def c4_real_shape_leg(device, shape_profile=None):
     ds.reconstruct(pts, occ, steps=steps)
     sync()
     tp = time.time() - tp0
-    NV = 11
+    NV = 13
     buf3 = (C.c_double * (NV * 3))()
     L.ishap_profile_end(buf3, NV)
     buf = C.create_string_buffer(1 << 17)
@@ -494,7 +494,7 @@ def main():
         L.ishap_profile_begin()
         one_edit(ds, src, tgt)
         torch.cuda.synchronize()
-        NV = 11
+        NV = 13
         out = (C.c_double * (NV * 3))()
         L.ishap_profile_end(out, NV)
         buf = C.create_string_buffer(1 << 17)
@@ -525,7 +525,9 @@ def main():
                  "igemm2_kernel<128, 128, 4, false, 1>", "igemm2_kernel<64, 64, 4, false, 1>",
                  "igemm2_kernel<64, 64, 4, true, 2>", "igemm_skinny_kernel<*, false>", "igemm_kernel<128, 128, 32, 2, 2, true>",
                  "conv3_small_kernel<4>", "igemm4_kernel<128, 128, 128, 5, 3, 1>", "igemm4_kernel<64, 64, *, 6, 3, 1>",
-                 "igemm4_kernel<64, 64, *, 6, 3, 2>"]
+                 "igemm4_kernel<64, 64, *, 6, 3, 2>", "igemm4_kernel<64, 64, 8, 6, 3, 1>", "igemm4_kernel<128, 64, 64, 6, 3, 1>"]
+        # (a '*' stands for the map width 16 / 32 / 64; the width-8 symbol -- the sliced, weight-streaming launches of the 8x8 maps --
+        # has an entry of its own)
         v = max(range(NV), key=lambda i: out[i * 3 + 1])
         launches, ms, flops = out[v * 3], out[v * 3 + 1], out[v * 3 + 2]
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -537,7 +539,7 @@ def main():
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             import re as _re
             pat = _re.compile("^" + _re.escape(names[v]).replace("\\*", "[0-9]+") + "$")
-            ks = [k for key, k in pj["kernels"].items() if pat.match(key)]        # a '*' stands for the map-width template argument
+            ks = [k for key, k in pj["kernels"].items() if pat.match(key) and (key == names[v] or key not in names)]   # a '*' stands for the map-width template argument
             nd = sum(k["FETCH_SIZE"]["dispatches"] for k in ks)
             traffic = int(sum((k["FETCH_SIZE"]["bytes_per_launch"] + k["WRITE_SIZE"]["bytes_per_launch"]) * k["FETCH_SIZE"]["dispatches"] for k in ks) / nd)
             traffic_source = ("committed profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "

@@ -277,7 +277,7 @@ extern "C" int ishap_profile_begin(void) {
 // out[v*3 + {0,1,2}] = {launches, total milliseconds, algorithmic FLOPs} for variant v:
 //   0 conv3x3 128x128 tile, 1 conv3x3 64x64 tile, 2 GEMM 128x128 tile, 3 GEMM 64x64 tile, 4 conv3x3 64x64 two-team,
 //   5 small-map kernel, 6 register-staged (BK = 32) kernel, 7 small-map 3x3 kernel, 8 / 9 / 10 the dx-reuse conv kernel
-//   (igemm4.hip): 128x128 tile / 64x64 tile / 64x64 two-team
+//   (igemm4.hip): 128x128 tile / 64x64 tile / 64x64 two-team, 11 its sliced launches on the 8x8 maps, 12 its 128x64 tiles
 extern "C" int ishap_profile_end(double* out, int nvar) {
   g_prof_on = false;
   for (int i = 0; i < nvar * 3; ++i) out[i] = 0.0;
@@ -322,6 +322,7 @@ int igemm2_launch_main(const IgemmArgs& a, bool big, hipStream_t s);   // igemm2
 bool igemm2_two_teams(const IgemmArgs& a, bool big);
 bool igemm4_applicable(const IgemmArgs& a, bool big);                  // igemm4.hip (3x3 with each activation slab staged once for dx = -1, 0, +1)
 bool igemm4_two_teams(const IgemmArgs& a, bool big);
+bool igemm4_tall_tiles(const IgemmArgs& a, bool big);
 int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s);
 // ISHAP_IGEMM4: 0 = never, 1 = 128x128 tiles only, 2 (default) = every shape igemm4 takes
 static bool igemm4_wanted(const IgemmArgs& a, bool big) {
@@ -351,7 +352,8 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
     // 5 small-map kernel (set in igemm_launch), 6 register-staged BK=32 kernel (stem conv)
     r.variant = BK == 64 ? ((CONV3 ? 0 : 2) + (BM == 128 ? 0 : 1)) : 6;
     if (BK == 64 && igemm2_two_teams(a, BM == 128)) r.variant = 4;
-    if (BK == 64 && CONV3 && igemm4_wanted(a, BM == 128)) r.variant = BM == 128 ? 8 : (igemm4_two_teams(a, false) ? 10 : 9);
+    if (BK == 64 && CONV3 && igemm4_wanted(a, BM == 128))
+      r.variant = BM == 128 ? 8 : (a.W == 8 ? 11 : (igemm4_tall_tiles(a, false) ? 12 : (igemm4_two_teams(a, false) ? 10 : 9)));
     r.M = a.M * a.nbatch; r.N = a.N; r.K = a.K; r.conv3 = CONV3; r.big = BM == 128; r.ksplit = a.ksplit;
     g_igemm_prof_start = r.a; g_igemm_prof_stop = r.b;      // attached to the dispatch: kernel begin / end timestamps
     const int rc = fire();
