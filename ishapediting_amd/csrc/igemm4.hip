@@ -17,6 +17,10 @@
 // Swizzle of the activation slab: 16-byte chunk ^ (row & 7) -- conflict-free for ds_read_b128 fragments starting at ANY
 // row under the lane grouping of MI355X_MICROARCH.md (LDS table), which the shifted reads need; the weight slab keeps
 // igemm2's chunk ^ ((row >> 1) & 7).
+// Tile shapes (igemm4_launch_main): 128x128 on maps 16 ... 128 wide (several image rows per tile below 128; fragment reads
+// interleaved into the MFMA blocks), 64x64 one- and two-team on maps 16 ... 64 wide, 128 pixels x 64 channels on the 64-wide
+// maps, and on the 8x8 maps 64x64 tiles (= one image) with K cut into ~16 slices whose fp32 partial tiles are left for the
+// consuming GroupNorm kernel to add up (igemm4_small_map_slices; took the level over from conv3_small late in round 4).
 // Reference arithmetic: conv2d 3x3, padding 1 (gd/unet.py ResBlock in_layers / out_layers, :236-256) and its input
 // gradient (flipped, transposed weights).  Same products as igemm2, another order of the K sum inside the fp32
 // accumulators: the two kernels agree to summation order (tests/test_gpu_fullsize.py: <= 2e-3 relative over the full model).
