@@ -567,6 +567,10 @@ int igemm4_small_map_slices(const IgemmArgs& a) {
 #define IG4_SMALL_W 6
 #define IG4_SMALL_X 3
 #endif
+#ifndef IG4_W8_W               // the 8x8 maps' sliced launches: 9-18 K-steps per workgroup -- a 4-slot weight ring (3 steps in flight) lets
+#define IG4_W8_W 4             // a 9-step slice take the loader's compile-time path and beats the 6-slot one by 4-6 % per launch
+#define IG4_W8_X 3             // (profiles/round4_igemm4_w8_ring_probe.txt)
+#endif
 #ifndef IG4_TEAM_W
 #define IG4_TEAM_W 6
 #define IG4_TEAM_X 3
@@ -600,11 +604,11 @@ int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
   if (igemm4_two_teams(a, big)) {
     if (a.W == 64) return launch4<64, 64, 64, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);
     if (a.W == 32) return launch4<64, 64, 32, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);
-    if (a.W == 8) return launch4<64, 64, 8, IG4_SMALL_W, IG4_SMALL_X>(a, s);
+    if (a.W == 8) return launch4<64, 64, 8, IG4_W8_W, IG4_W8_X>(a, s);
     return launch4<64, 64, 16, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);
   }
   if (a.W == 64) return launch4<64, 64, 64, IG4_SMALL_W, IG4_SMALL_X>(a, s);
   if (a.W == 32) return launch4<64, 64, 32, IG4_SMALL_W, IG4_SMALL_X>(a, s);
-  if (a.W == 8) return launch4<64, 64, 8, IG4_SMALL_W, IG4_SMALL_X>(a, s);
+  if (a.W == 8) return launch4<64, 64, 8, IG4_W8_W, IG4_W8_X>(a, s);
   return launch4<64, 64, 16, IG4_SMALL_W, IG4_SMALL_X>(a, s);
 }
