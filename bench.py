@@ -524,10 +524,10 @@ def main():
         names = ["igemm2_kernel<128, 128, 4, true, 1>", "igemm2_kernel<64, 64, 4, true, 1>",
                  "igemm2_kernel<128, 128, 4, false, 1>", "igemm2_kernel<64, 64, 4, false, 1>",
                  "igemm2_kernel<64, 64, 4, true, 2>", "igemm_skinny_kernel<*, false>", "igemm_kernel<128, 128, 32, 2, 2, true>",
-                 "conv3_small_kernel<4>", "igemm4_kernel<128, 128, 128, 5, 3, 1>", "igemm4_kernel<64, 64, *, 6, 3, 1>",
-                 "igemm4_kernel<64, 64, *, 6, 3, 2>", "igemm4_kernel<64, 64, 8, 6, 3, 1>", "igemm4_kernel<128, 64, 64, 6, 3, 1>"]
-        # (a '*' stands for the map width 16 / 32 / 64; the width-8 symbol -- the sliced, weight-streaming launches of the 8x8 maps --
-        # has an entry of its own)
+                 "conv3_small_kernel<4>", "igemm4_kernel<128, 128, 128, 5, 3, 1>", "igemm4_kernel<64, 64, *, *, 3, 1>",
+                 "igemm4_kernel<64, 64, *, 6, 3, 2>", "igemm4_kernel<64, 64, 8, 4, 3, 1>", "igemm4_kernel<128, 64, 64, 6, 3, 1>"]
+        # (the '*'s stand for the map width 16 / 32 / 64 and the weight-ring depth 6 / 4 (4 for slices of 9-12 K-steps); the width-8
+        # symbol -- the sliced, weight-streaming launches of the 8x8 maps -- has an entry of its own)
         v = max(range(NV), key=lambda i: out[i * 3 + 1])
         launches, ms, flops = out[v * 3], out[v * 3 + 1], out[v * 3 + 2]
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

@@ -607,8 +607,18 @@ int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
     if (a.W == 8) return launch4<64, 64, 8, IG4_W8_W, IG4_W8_X>(a, s);
     return launch4<64, 64, 16, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);
   }
+  if (a.W == 8) return launch4<64, 64, 8, IG4_W8_W, IG4_W8_X>(a, s);
+  // slices of 9-12 K-steps: too short for the 6-slot ring's compile-time loader path (13 steps), long enough for the 4-slot
+  // ring's (9) -- -13 % per launch there (16^2 512->512 in 8 slices 7.7 -> 6.7 us, 32^2 256->512 in 4 slices 9.9 -> 8.6;
+  // profiles/round4_igemm4_ring_by_slice_length_probe.txt); longer slices keep the deeper ring (+5 % at 36 steps with 4 slots)
+  static const int short_on = [] { const char* e = getenv("ISHAP_IG4_SHORT_RING"); return e ? atoi(e) : 1; }();
+  const int steps = 3 * ((3 * (a.Cin / 64) + a.ksplit - 1) / a.ksplit);
+  if (short_on && a.K2 == 0 && steps >= 9 && steps <= 12) {
+    if (a.W == 64) return launch4<64, 64, 64, IG4_W8_W, IG4_W8_X>(a, s);
+    if (a.W == 32) return launch4<64, 64, 32, IG4_W8_W, IG4_W8_X>(a, s);
+    return launch4<64, 64, 16, IG4_W8_W, IG4_W8_X>(a, s);
+  }
   if (a.W == 64) return launch4<64, 64, 64, IG4_SMALL_W, IG4_SMALL_X>(a, s);
   if (a.W == 32) return launch4<64, 64, 32, IG4_SMALL_W, IG4_SMALL_X>(a, s);
-  if (a.W == 8) return launch4<64, 64, 8, IG4_W8_W, IG4_W8_X>(a, s);
   return launch4<64, 64, 16, IG4_SMALL_W, IG4_SMALL_X>(a, s);
 }

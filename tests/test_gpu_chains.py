@@ -585,7 +585,7 @@ def test_runtime_switches_keep_the_results(tmp_path):
             "ISHAP_IG4_TEAMS=0": {"ISHAP_IG4_TEAMS": "0"}, "ISHAP_IG4_TALL=0": {"ISHAP_IG4_TALL": "0"},
             "ISHAP_IG4_W8=0": {"ISHAP_IG4_W8": "0"}, "ISHAP_G1_SLICES=0": {"ISHAP_G1_SLICES": "0"},
             "ISHAP_ATTN_BWD_TEAMS=4": {"ISHAP_ATTN_BWD_TEAMS": "4"}, "ISHAP_ATTN_BWD_TEAMS=2": {"ISHAP_ATTN_BWD_TEAMS": "2"},
-            "ISHAP_ATTN_XCD=0": {"ISHAP_ATTN_XCD": "0"}}
+            "ISHAP_ATTN_XCD=0": {"ISHAP_ATTN_XCD": "0"}, "ISHAP_IG4_SHORT_RING=0": {"ISHAP_IG4_SHORT_RING": "0"}}
     res = {}
     for name, env in runs.items():
         path = str(tmp_path / (name.replace("=", "_") + ".npz"))
