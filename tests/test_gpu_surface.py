@@ -102,6 +102,14 @@ def test_smoothing_and_chamfer_match_cpu_statement():
     assert float((sm_d - v).abs().max()) > 1e-3                         # and it did move
     sm_d2 = smooth_mesh(v, f, 10)
     assert torch.equal(sm_d, sm_d2)                                    # fixed-point accumulation: bitwise repeatable
+    # the sweeps ping-pong between the vertex buffer and scratch: odd counts end in scratch and are copied back; the adjacency
+    # lists' internal order depends on atomics and must not matter; a mesh whose scan spans several 2048-entry blocks
+    for iters in (1, 3):
+        assert float((smooth_mesh(v, f, iters).cpu() - S.smooth_simple(v.cpu(), f.cpu().long(), iters)).abs().max()) < 1e-4, iters
+    assert torch.equal(smooth_mesh(v, f, 0), v)
+    vb, fb = extract_surface(sphere(64, 21.7).to(dev()))
+    assert vb.shape[0] > 3 * 2048
+    assert float((smooth_mesh(vb, fb, 3).cpu() - S.smooth_simple(vb.cpu(), fb.cpu().long(), 3)).abs().max()) < 1e-4
     pa, pb = v, v + torch.tensor([0.5, 0.0, 0.0], device=v.device)
     c_d = chamfer_distance(pa, pb, None)
     c_o = S.chamfer_distance(pa.cpu(), pb.cpu(), None)
