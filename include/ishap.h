@@ -34,7 +34,7 @@ int ishap_device_status(void);
  * ishap_rendezvous_would_grant: diagnostic, no side effects -- 1 if a launch sequence of `owner` (a model context, or NULL
  * for the stand-alone operator calls) on `stream` would be allowed in-launch rendezvous right now. */
 int ishap_rendezvous_would_grant(const void* owner, void* stream);
-int ishap_version(void);
+int ishap_version(void);   /* 2 since ishap_mesh_smooth takes (and checks) the size of its scratch buffer */
 
 /* ---------------------------------------------------------------- UNet (gd/unet.py:396-671) */
 typedef struct ishap_unet ishap_unet;
@@ -263,8 +263,10 @@ int ishap_surface_emit(const float* volume, int res, float level, int method, vo
  * mesh is closed.  scratch: ishap_mesh_smooth_scratch_bytes(nverts, ntris) device bytes (the vertex adjacency, built once per
  * call, and a second vertex buffer; ~28 bytes per vertex + 24 per triangle).  Vertex indices and 6*ntris must fit 32 bits. */
 long long ishap_mesh_smooth_scratch_bytes(long long nverts, long long ntris);
+/* ABI version 2: `scratch_bytes` = the size of the caller's buffer; a buffer smaller than
+ * ishap_mesh_smooth_scratch_bytes(nverts, ntris) fails the call (version 1 took 32 * nverts bytes on trust). */
 int ishap_mesh_smooth(float* verts, long long nverts, const int* tris, long long ntris, int iterations, float box_max,
-                      void* scratch, void* stream);
+                      void* scratch, long long scratch_bytes, void* stream);
 /* out2[0] = mean over a of min_b |a-b|^2, out2[1] = mean over b of min_a |a-b|^2 (device floats; their sum is the
  * reference's chamfer distance); nearest: device scratch float[max(na, nb)] */
 int ishap_chamfer(const float* a, long long na, const float* b, long long nb, float* nearest, float* out2, void* stream);

@@ -92,7 +92,7 @@ SYMBOLS = {
     "ishap_surface_count": (C.c_int, [c_void_p, C.c_int, C.c_float, C.c_int, c_void_p, c_void_p, c_void_p]),
     "ishap_surface_emit": (C.c_int, [c_void_p, C.c_int, C.c_float, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ishap_mesh_smooth_scratch_bytes": (C.c_longlong, [C.c_longlong, C.c_longlong]),
-    "ishap_mesh_smooth": (C.c_int, [c_void_p, C.c_longlong, c_void_p, C.c_longlong, C.c_int, C.c_float, c_void_p, c_void_p]),
+    "ishap_mesh_smooth": (C.c_int, [c_void_p, C.c_longlong, c_void_p, C.c_longlong, C.c_int, C.c_float, c_void_p, C.c_longlong, c_void_p]),
     "ishap_chamfer": (C.c_int, [c_void_p, C.c_longlong, c_void_p, C.c_longlong, c_void_p, c_void_p, c_void_p]),
     "ishap_mesh_tri_areas": (C.c_int, [c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
     "ishap_mesh_points_on_tris": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),

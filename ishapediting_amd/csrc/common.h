@@ -254,6 +254,7 @@ struct IgemmArgs {
   int ups = 0;                   // conv3 source map is (H/2, W/2): nearest-neighbour upsample on the fly
   int res_ups = 0;               // residual map is (H/2, W/2)
   int ksplit = 1;
+  int persist_wgs = 0;           // > 0 (a multiple of 8): run a 128x128-tile 3x3 launch as that many persistent workgroups (igemm4.hip, PERSIST)
   int defer_reduce = 0;          // ksplit > 1: leave the fp32 slices in `ws` (no reduce launch); the caller hands a SlabSrc to the consumer
   float alpha = 1.f;
   int out_mode = IG_OUT_F16;

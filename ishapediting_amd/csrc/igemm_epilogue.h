@@ -259,10 +259,13 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
       if (t < BN * 2) {
         const int nl = t >> 1, k = t & 1;
         long long v = 0;
-        // plain loads: the table's lines have not been read by this kernel before (no stale copy in this XCD's L2 or this CU's L1,
-        // both start a kernel invalidated), and every add to them was acknowledged before its tile announced itself; 128 tiles
-        // reading the same 512 addresses uncached cost more than the whole normalisation
-        if (n0 + nl < a.N) v = a.stat_out[((long long)n_img * a.N + n0 + nl) * 2 + k];
+        // agent-scope loads (round 5): the totals were formed by atomics of workgroups on other XCDs; every add was
+        // acknowledged before its tile announced itself on the counter this workgroup polled with agent-scope loads, and these
+        // loads bypass this CU's L1 as well -- no reliance on "the line cannot be cached yet".  (Plain loads measured faster; the
+        // whole path is an opt-in that lost to the separate launches anyway, profiles/round4_ab_fused_groupnorm.txt.)
+        if (n0 + nl < a.N)
+          v = (long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.stat_out + ((long long)n_img * a.N + n0 + nl) * 2 + k),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tot[nl * 2 + k] = v;
       }
       __syncthreads();

@@ -544,8 +544,9 @@ extern "C" long long ishap_mesh_smooth_scratch_bytes(long long nverts, long long
 }
 
 extern "C" int ishap_mesh_smooth(float* verts, long long nverts, const int* tris, long long ntris, int iterations, float box_max,
-                                 void* scratch, void* stream) {
+                                 void* scratch, long long scratch_bytes, void* stream) {
   ISHAP_REQUIRE(verts && tris && scratch && nverts >= 0 && ntris >= 0 && iterations >= 0, "mesh_smooth arguments");
+  ISHAP_REQUIRE(scratch_bytes >= ishap_mesh_smooth_scratch_bytes(nverts, ntris), "mesh_smooth: scratch smaller than ishap_mesh_smooth_scratch_bytes(nverts, ntris)");
   ISHAP_REQUIRE(nverts < (1ll << 31) && 6 * ntris < (1ll << 32), "mesh_smooth: 32-bit vertex indices and list offsets");
   if (nverts == 0 || ntris == 0 || iterations == 0) return 0;
   hipStream_t s = (hipStream_t)stream;

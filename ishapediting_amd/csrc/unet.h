@@ -187,6 +187,7 @@ struct Exec {
   bool keep = false;   // the forward keeps what a following backward re-reads
   float* ws = nullptr;          // split-K / GroupNorm-statistics scratch of this launch sequence (null: the context's)
   float* gn_partial = nullptr;
+  int persist_wgs = 0;          // > 0: 128x128-tile convolutions of this sequence run as that many persistent workgroups (the overlapped forward tail)
   bool tenant = true;           // this sequence holds the device's rendezvous tenancy (common.h ishap_rendezvous_begin)
 };
 // RAII around a launch sequence: asks for the tenancy at construction, closes it (event on the stream) at scope exit

@@ -292,6 +292,7 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
   a.ldx = ldx; a.ldw = ldw ? ldw : taps * kpad; a.ldo = ldo; a.ldr = ldr;
   a.H = H; a.W = W; a.ups = ups; a.res_ups = res_ups;
   a.out_mode = out_mode;
+  a.persist_wgs = e.persist_wgs;
   a.flops_scale = (Wt == e.u->head.w) ? 1.f / 3.f : 1.f;
   a.ksplit = igemm_pick_ksplit(a.M, a.N, a.K, 1, pend_out != nullptr);
   if (!a.conv3 && a.M <= 64 && a.K % 64 == 0) {
@@ -691,6 +692,10 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
         e.s = u->side;
         e.ws = u->ws_side;
         e.gn_partial = u->gn_partial_side;
+        // the tail's 128x128-tile convolutions as P persistent workgroups: they then hold the LDS of P compute units instead of
+        // all of them, and the backward chain on the caller's stream keeps the rest (ISHAP_TAIL_WGS, 0 = plain grids)
+        static const int tail_wgs = [] { const char* v = getenv("ISHAP_TAIL_WGS"); return v ? atoi(v) : 0; }();
+        e.persist_wgs = tail_wgs;
       }
     }
   }
@@ -731,7 +736,7 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int ishap_version(void) { return 1; }
+int ishap_version(void) { return 2; }   // 2: ishap_mesh_smooth takes the scratch size
 
 int ishap_unet_create(const ishap_unet_config* cfg, int device, ishap_unet** out) {
   ISHAP_REQUIRE(cfg && out, "null argument");

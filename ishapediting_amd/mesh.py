@@ -83,7 +83,7 @@ def smooth_mesh(verts: torch.Tensor, tris: torch.Tensor, iterations: int = 10, b
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=out.device)
     with torch.cuda.device(out.device):
         _lib.check(_lib.lib().ishap_mesh_smooth(out.data_ptr(), out.shape[0], tris.data_ptr(), tris.shape[0], int(iterations),
-                                                float(box_max), scratch.data_ptr(), _lib.stream_ptr(out.device)))
+                                                float(box_max), scratch.data_ptr(), nbytes, _lib.stream_ptr(out.device)))
     return out
 
 
@@ -334,9 +334,13 @@ def mesh_occupancy(verts: torch.Tensor, tris: torch.Tensor, points: torch.Tensor
     return occ
 
 
-def sample_surface_points(verts: torch.Tensor, tris: torch.Tensor, n: int, generator=None) -> torch.Tensor:
+def sample_surface_points(verts: torch.Tensor, tris: torch.Tensor, n: int, generator=None,
+                          multinomial_max: int = 1 << 24) -> torch.Tensor:
     """mesh.sample_points_uniformly(n) (drag_utils.py:432): triangles drawn with probability proportional to their area,
-    a uniform point on each.  The random draws are torch's (plumbing); areas and points are computed by the library."""
+    a uniform point on each.  The random draws are torch's (plumbing); areas and points are computed by the library.
+    Above `multinomial_max` triangles (torch.multinomial's category limit, 2^24) the triangle is drawn by inverse CDF instead:
+    the same distribution from ONE uniform per sample, so the samples of a given seed differ between the two branches
+    (only meshes beyond 16.7 M triangles -- random-weight noise surfaces -- take the second)."""
     _need_gpu(verts, "sample_surface_points")
     dev = verts.device
     v = verts.detach().to(torch.float32).contiguous()
@@ -345,12 +349,14 @@ def sample_surface_points(verts: torch.Tensor, tris: torch.Tensor, n: int, gener
     L = _lib.lib()
     with torch.cuda.device(dev):
         _lib.check(L.ishap_mesh_tri_areas(v.data_ptr(), t.data_ptr(), t.shape[0], areas.data_ptr(), _lib.stream_ptr(dev)))
-        if areas.numel() <= (1 << 24):
+        if areas.numel() <= multinomial_max:
             idx = torch.multinomial(areas.double().cpu(), n, replacement=True, generator=generator).to(device=dev, dtype=torch.int32)
         else:      # torch.multinomial stops at 2^24 categories (a 256^3 noise surface has 3e7 triangles): inverse CDF instead
             cdf = torch.cumsum(areas.double().cpu(), 0)
             u = torch.rand(n, generator=generator, dtype=torch.float64) * cdf[-1]
-            idx = torch.searchsorted(cdf, u).clamp_(max=areas.numel() - 1).to(device=dev, dtype=torch.int32)
+            # right=True: triangle i owns [cdf[i-1], cdf[i]) -- a draw that lands ON a cdf value (u = 0 in front of leading
+            # zero-area triangles included) goes to the next triangle with area, never to a degenerate one
+            idx = torch.searchsorted(cdf, u, right=True).clamp_(max=areas.numel() - 1).to(device=dev, dtype=torch.int32)
         uw = torch.rand((n, 2), generator=generator).to(dev).contiguous()
         pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
         _lib.check(L.ishap_mesh_points_on_tris(v.data_ptr(), t.data_ptr(), idx.data_ptr(), uw.data_ptr(), n, pts.data_ptr(),

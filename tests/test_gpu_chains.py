@@ -520,7 +520,11 @@ def test_synthesize_latent_calc_grad_matches_oracle_autograd():
         (gx,) = torch.autograd.grad(loss, xd)
         r_g = rel(gx, ref_g)
         print(f"synthesize_latent(calc_grad=True, clip={clip}): gradient rel {r_g:.2e}; oracle fp16-vs-fp32 spread {spread:.2e}")
-        assert r_g < (max(1e-2, 2.0 * spread) if clip else 1e-2), (clip, r_g, spread)
+        # clip=True: the clamp's 0/1 derivative is decided by the last bit of pred_xstart, so the reference's own fp16-vs-fp32
+        # gradients differ by `spread` (0.16-0.25 on these weights).  MEASURED device/oracle ratio r_g / spread: 1.75 (round 4
+        # build, v_rcp_f32 sigmoid; 1.4 with the IEEE division before it) -- asserted at 1.9 so that a further drift fails
+        # (the bound was a loose 2.0)
+        assert r_g < (max(1e-2, 1.9 * spread) if clip else 1e-2), (clip, r_g, spread)
 
         r0 = synthesize_latent(m, diff, args, t1=Tn, t2=Tn - 3, inter_latent_idx=[Tn - 2], inter_feat_idx=[Tn - 2],
                                img=x0.to(dev()), calc_grad=False, noise=noise.to(dev()), feat_layer=fl, clip_denoised=clip)
@@ -585,7 +589,13 @@ def test_runtime_switches_keep_the_results(tmp_path):
             "ISHAP_IG4_TEAMS=0": {"ISHAP_IG4_TEAMS": "0"}, "ISHAP_IG4_TALL=0": {"ISHAP_IG4_TALL": "0"},
             "ISHAP_IG4_W8=0": {"ISHAP_IG4_W8": "0"}, "ISHAP_G1_SLICES=0": {"ISHAP_G1_SLICES": "0"},
             "ISHAP_ATTN_BWD_TEAMS=4": {"ISHAP_ATTN_BWD_TEAMS": "4"}, "ISHAP_ATTN_BWD_TEAMS=2": {"ISHAP_ATTN_BWD_TEAMS": "2"},
-            "ISHAP_ATTN_XCD=0": {"ISHAP_ATTN_XCD": "0"}, "ISHAP_IG4_SHORT_RING=0": {"ISHAP_IG4_SHORT_RING": "0"}}
+            "ISHAP_ATTN_XCD=0": {"ISHAP_ATTN_XCD": "0"}, "ISHAP_IG4_SHORT_RING=0": {"ISHAP_IG4_SHORT_RING": "0"},
+            # round 5: the switches the list had missed
+            "ISHAP_IG4_W8_K2=0": {"ISHAP_IG4_W8_K2": "0"}, "ISHAP_IG4_K2_SMALL=1": {"ISHAP_IG4_K2_SMALL": "1"},
+            "ISHAP_PEND_NOSPLIT=36 ISHAP_PEND_MINSTEPS=6": {"ISHAP_PEND_NOSPLIT": "36", "ISHAP_PEND_MINSTEPS": "6"},
+            "ISHAP_PEND_NOSPLIT=6 ISHAP_PEND_MINSTEPS=2": {"ISHAP_PEND_NOSPLIT": "6", "ISHAP_PEND_MINSTEPS": "2"},
+            "ISHAP_ATTN_TEAMS=2": {"ISHAP_ATTN_TEAMS": "2"}, "ISHAP_ATTN_TEAMS=4": {"ISHAP_ATTN_TEAMS": "4"},
+            "ISHAP_BIG_MIN=1": {"ISHAP_BIG_MIN": "1"}}
     res = {}
     for name, env in runs.items():
         path = str(tmp_path / (name.replace("=", "_") + ".npz"))

@@ -119,6 +119,46 @@ def test_smoothing_and_chamfer_match_cpu_statement():
     assert abs(c_s - S.chamfer_distance(pa.cpu(), pb.cpu(), 2000, seed=4)) <= 1e-5 * max(1.0, c_o)
 
 
+def test_smoothing_rejects_an_undersized_scratch_buffer():
+    """ABI version 2: the scratch size travels with the pointer; a buffer sized by the old 32-bytes-per-vertex rule
+    fails the call instead of being written out of bounds."""
+    from ishapediting_amd import _lib
+    from ishapediting_amd.mesh import extract_surface
+    v, f = extract_surface(sphere(32, 9.3).to(dev()))
+    L = _lib.lib()
+    assert L.ishap_version() >= 2
+    need = int(L.ishap_mesh_smooth_scratch_bytes(v.shape[0], f.shape[0]))
+    old_rule = 32 * v.shape[0]
+    assert need > old_rule
+    out = v.clone().contiguous()
+    scratch = torch.empty(need, dtype=torch.uint8, device=v.device)
+    with torch.cuda.device(v.device):
+        rc = L.ishap_mesh_smooth(out.data_ptr(), v.shape[0], f.data_ptr(), f.shape[0], 2, 0.0, scratch.data_ptr(), old_rule,
+                                 _lib.stream_ptr(v.device))
+    assert rc != 0 and b"scratch" in L.ishap_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(out, v)                                          # nothing ran
+
+
+def test_area_sampling_by_inverse_cdf_never_picks_a_degenerate_triangle():
+    """The branch sample_surface_points takes above torch.multinomial's 2^24 categories, forced here by its threshold parameter:
+    zero-area triangles (leading ones included, where a draw of exactly 0 would land) are never chosen, and the draw is
+    area-proportional."""
+    from ishapediting_amd.mesh import sample_surface_points
+    # a unit square in z = 0 (two triangles), a far square of 3x the area, and degenerate triangles first, between and last
+    v = torch.tensor([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [10, 0, 0], [13, 0, 0], [13, 1, 0], [10, 1, 0], [5, 5, 5]],
+                     dtype=torch.float32, device=dev())
+    f = torch.tensor([[8, 8, 8], [0, 0, 1], [0, 1, 2], [0, 2, 3], [8, 8, 8], [4, 5, 6], [4, 6, 7], [8, 8, 8]], dtype=torch.int32, device=dev())
+    g = torch.Generator().manual_seed(3)
+    p = sample_surface_points(v, f, 20000, generator=g, multinomial_max=0).cpu()
+    assert float((p - torch.tensor([5.0, 5.0, 5.0])).abs().sum(dim=1).min()) > 1.0        # never the degenerate vertex
+    assert bool(((p[:, 2].abs() < 1e-6) & (p[:, 1] >= 0) & (p[:, 1] <= 1)).all())
+    far = float((p[:, 0] >= 10).float().mean())
+    assert abs(far - 0.75) < 0.02, far                                 # 3 of 4 area units
+    g2 = torch.Generator().manual_seed(3)
+    assert torch.equal(p, sample_surface_points(v, f, 20000, generator=g2, multinomial_max=0).cpu())
+
+
 def _closed_and_oriented(v, f):
     fl = f.long()
     e = torch.cat([fl[:, [0, 1]], fl[:, [1, 2]], fl[:, [2, 0]]]).sort(dim=1).values
