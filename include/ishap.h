@@ -166,6 +166,12 @@ typedef struct {
 int ishap_ddpm_step(const float* x, const float* model_out, const float* noise, const float* variance_in,
                     const ishap_step_coefs* k, int N, int C, int HW,
                     float* sample, float* pred_xstart, float* variance, float* mean, void* stream);
+/* The step of p_sample_guidance (mode 0) and the guided update of the drag loop in ONE pass (round 5; gd/gaussian_diffusion.py:
+ * 446-510 followed by drag_utils.py:384-392): guided = sample + variance * (scale * grad [* *grad_mul_dev]) with the sample and
+ * variance this step computes; `sample` / `variance` are optional outputs (null: not written). */
+int ishap_ddpm_step_guided(const float* x, const float* model_out, const float* noise, const float* variance_in,
+                           const ishap_step_coefs* k, int N, int C, int HW, const float* grad, float scale,
+                           const float* grad_mul_dev, float* guided, float* sample, float* variance, void* stream);
 /* img = sample + variance * (scale * grad)   (drag_utils.py:384-392); grad_mul_dev: optional device scalar */
 int ishap_guided_update(const float* sample, const float* variance, const float* grad, float scale,
                         const float* grad_mul_dev, long long numel, float* out, void* stream);

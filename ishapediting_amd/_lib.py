@@ -77,6 +77,8 @@ SYMBOLS = {
                                              c_void_p, c_void_p, c_void_p]),
     "ishap_ddpm_step": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(StepCoefs), C.c_int, C.c_int,
                                   C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ishap_ddpm_step_guided": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(StepCoefs), C.c_int, C.c_int, C.c_int,
+                                         c_void_p, C.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ishap_guided_update": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_float, c_void_p, C.c_longlong, c_void_p,
                                       c_void_p]),
     "ishap_axpby": (C.c_int, [c_void_p, c_void_p, C.c_float, C.c_float, C.c_longlong, c_void_p, c_void_p]),

@@ -67,6 +67,14 @@ struct Tenant {
 Tenant g_tenant[64];
 }  // namespace
 
+unsigned ishap_event_flags() {
+  static const unsigned f = [] {
+    const char* e = getenv("ISHAP_EVENT_FENCE");
+    return (e && atoi(e)) ? (unsigned)hipEventDisableTiming : (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+  }();
+  return f;
+}
+
 bool ishap_rendezvous_begin(const void* owner, hipStream_t s) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
@@ -81,7 +89,7 @@ bool ishap_rendezvous_begin(const void* owner, hipStream_t s) {
     if (t.open) return false;                   // another sequence is being enqueued right now
     if (t.recorded && hipEventQuery(t.done) != hipSuccess) return false;   // ... or is still running
   }
-  if (!t.done && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) { t.done = nullptr; return false; }
+  if (!t.done && hipEventCreateWithFlags(&t.done, ishap_event_flags()) != hipSuccess) { t.done = nullptr; return false; }
   t.owner = owner; t.stream = s; t.have = true; t.open = true; t.recorded = false;
   return true;
 }
@@ -128,6 +136,21 @@ int ishap_ddpm_step(const float* x, const float* model_out, const float* noise, 
   a.min_log = k->min_log; a.max_log = k->max_log; a.sqrt_recip = k->sqrt_recip; a.sqrt_recipm1 = k->sqrt_recipm1;
   a.coef1 = k->coef1; a.coef2 = k->coef2; a.nonzero = k->nonzero; a.clip = k->clip_denoised; a.mode = k->mode;
   a.ddim_a = k->ddim_a; a.ddim_b = k->ddim_b; a.ddim_sigma = k->ddim_sigma;
+  return ddpm_step_launch(a, (hipStream_t)stream);
+}
+
+int ishap_ddpm_step_guided(const float* x, const float* model_out, const float* noise, const float* variance_in,
+                           const ishap_step_coefs* k, int N, int C, int HW, const float* grad, float scale,
+                           const float* grad_mul_dev, float* guided, float* sample, float* variance, void* stream) {
+  ISHAP_REQUIRE(x && model_out && k && grad && guided, "null argument");
+  ISHAP_REQUIRE(k->mode == 0, "the guided step is p_sample_guidance's sqrt(variance) form (mode 0)");
+  DdpmStepArgs a;
+  a.x = x; a.model_out = model_out; a.noise = noise; a.variance_in = variance_in;
+  a.sample = sample; a.variance = variance;
+  a.N = N; a.C = C; a.HW = HW;
+  a.min_log = k->min_log; a.max_log = k->max_log; a.sqrt_recip = k->sqrt_recip; a.sqrt_recipm1 = k->sqrt_recipm1;
+  a.coef1 = k->coef1; a.coef2 = k->coef2; a.nonzero = k->nonzero; a.clip = k->clip_denoised; a.mode = k->mode;
+  a.guide_grad = grad; a.guide_scale = scale; a.guide_mul = grad_mul_dev; a.guided = guided;
   return ddpm_step_launch(a, (hipStream_t)stream);
 }
 

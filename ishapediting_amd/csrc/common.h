@@ -41,6 +41,11 @@ void ishap_set_error(const std::string& msg);
 // no synchronisation) and fails with that code's message, so an earlier launch's failure surfaces at the next call --
 // the asynchronous-error contract of the HIP runtime itself.  ishap_device_status() reads (and clears) it on demand.
 enum { ISHAP_DEV_OK = 0, ISHAP_DEV_GN_RENDEZVOUS = 1, ISHAP_DEV_CHAIN_TIMEOUT = 2 };
+// Flags of the events that order the library's own streams / sequences among each other on ONE device (fork and join of the
+// overlapped forward tail, the rendezvous tenancy's closing event): no timing, and no system-scope fence when the event completes --
+// nothing on the host reads memory behind these events, and the default fence is a cache write-back + invalidate in front of
+// whatever the stream runs next (hip_runtime_api.h, hipEventDisableSystemFence).  ISHAP_EVENT_FENCE=1 restores the default.
+unsigned ishap_event_flags();
 unsigned* ishap_status_word();        // null only if the pinned allocation failed
 int ishap_check_status();             // 0, or -3 with the error string set (the word is cleared once reported)
 int ishap_cu_count();                 // compute units of the current device (cached per device)
@@ -254,7 +259,8 @@ struct IgemmArgs {
   int ups = 0;                   // conv3 source map is (H/2, W/2): nearest-neighbour upsample on the fly
   int res_ups = 0;               // residual map is (H/2, W/2)
   int ksplit = 1;
-  int persist_wgs = 0;           // > 0 (a multiple of 8): run a 128x128-tile 3x3 launch as that many persistent workgroups (igemm4.hip, PERSIST)
+  int force_small = 0;           // 1: 64x64 tiles whatever the tile policy says (experiment: the overlapped tail on tiles that leave room for a second workgroup per CU)
+  int chunk_tiles = 0;           // > 0 (a multiple of 8): igemm4 runs the layer as several launches of at most that many tiles (igemm4.hip, launch4)
   int defer_reduce = 0;          // ksplit > 1: leave the fp32 slices in `ws` (no reduce launch); the caller hands a SlabSrc to the consumer
   float alpha = 1.f;
   int out_mode = IG_OUT_F16;

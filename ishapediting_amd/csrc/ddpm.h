@@ -19,6 +19,12 @@ struct DdpmStepArgs {
   float ddim_a = 0, ddim_b = 0, ddim_sigma = 0;   // mode 3: sqrt(abar_prev), sqrt(1 - abar_prev - sigma^2), sigma
   int clip = 1;
   int mode = DDPM_MODE_SQRT_VAR;
+  // guided update folded into the step (round 5): guided = sample + variance * (guide_scale * (guide_grad * guide_mul))
+  // (drag_utils.py:384-392) -- the arithmetic of guided_update_kernel on the values this kernel has in registers
+  const float* guide_grad = nullptr;   // [N][C][HW] or null
+  const float* guide_mul = nullptr;    // optional device scalar (1 / loss scale of the fp16 backward pass)
+  float guide_scale = 0.f;
+  float* guided = nullptr;
 };
 int ddpm_step_launch(const DdpmStepArgs& a, hipStream_t s);
 int guided_update_launch(const float* sample, const float* variance, const float* grad, float* out, float scale,

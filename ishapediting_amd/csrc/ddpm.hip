@@ -7,6 +7,7 @@
 #include "ddpm.h"
 
 __global__ __launch_bounds__(256) void ddpm_step_kernel(DdpmStepArgs a) {
+  const float gm = (a.guided && a.guide_mul) ? *a.guide_mul : 1.f;
   const long long per_img = (long long)a.C * a.HW;           // floats per image in x
   const long long nvec = (long long)a.N * per_img / 4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
@@ -20,7 +21,9 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(DdpmStepArgs a) {
     if (a.noise) nz = *reinterpret_cast<const f32x4*>(a.noise + e);
     f32x4 var_in = {0.f, 0.f, 0.f, 0.f};
     if (a.variance_in) var_in = *reinterpret_cast<const f32x4*>(a.variance_in + e);
-    f32x4 o_sample, o_x0, o_var, o_mean;
+    f32x4 gr = {0.f, 0.f, 0.f, 0.f};
+    if (a.guided) gr = *reinterpret_cast<const f32x4*>(a.guide_grad + e);
+    f32x4 o_sample, o_x0, o_var, o_mean, o_guided;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float frac = (v[k] + 1.f) / 2.f;
@@ -38,7 +41,10 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(DdpmStepArgs a) {
       else if (a.mode == DDPM_MODE_EXP_HALF_LOGVAR) s = mean + a.nonzero * expf(0.5f * logvar) * nz[k];   // :443
       else s = mean + a.nonzero * sqrtf(a.variance_in ? var_in[k] : var) * nz[k];          // :503 / :508
       o_sample[k] = s; o_x0[k] = x0; o_var[k] = var; o_mean[k] = mean;
+      // the dict's "variance" is the caller's override when one was given (gaussian_diffusion.py:510), else the learned one
+      o_guided[k] = s + (a.variance_in ? var_in[k] : var) * (a.guide_scale * (gr[k] * gm));
     }
+    if (a.guided) *reinterpret_cast<f32x4*>(a.guided + e) = o_guided;
     if (a.sample) *reinterpret_cast<f32x4*>(a.sample + e) = o_sample;
     if (a.pred_xstart) *reinterpret_cast<f32x4*>(a.pred_xstart + e) = o_x0;
     if (a.variance) *reinterpret_cast<f32x4*>(a.variance + e) = o_var;

@@ -491,7 +491,7 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
     return rc;
   }
   const bool k64 = a.conv3 ? (a.Cin % 64 == 0) : (a.K % 64 == 0);
-  bool big = igemm_use_big(a.M, a.N, a.nbatch);
+  bool big = igemm_use_big(a.M, a.N, a.nbatch) && !a.force_small;
   if (a.stat_out || a.gb_x) {
     // the statistics epilogues file a whole tile under image m0 / HW: a tile must not straddle two images
     const int hw = a.H * a.W;

@@ -65,9 +65,9 @@ __device__ __forceinline__ void ig4_wait_vm(int n) {
 // CU that holds one workgroup gets two rings' worth of loads in flight and two MFMA waves per SIMD).
 // Folded second source (IgemmArgs::X2 / K2, a ResBlock's 1x1 skip convolution riding on its conv2): after the 3x3 part
 // the K loop goes on with K2 / 64 steps that each stage their own slab of X2 rows and read it unshifted.
-template <int BM, int BN, int WD, int NSTW, int NSTX, int HALVES = 1, bool PERSIST = false>
+template <int BM, int BN, int WD, int NSTW, int NSTX, int HALVES = 1>
 __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, const void* hWt, int hK, int hCin, int hldx, int hldw, int hH, int hW,
-                                                              int hksplit, int hnwg, unsigned hpacked, IgemmArgs a) {
+                                                              int hksplit, int hnwg, unsigned hpacked, int hbase, IgemmArgs a) {
   const IgemmHot h{(const half_t*)hX, (const half_t*)hWt, hK, hCin, hldx, hldw, hH, hW, hksplit, hnwg, hpacked};
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BK = 64;
@@ -96,404 +96,397 @@ __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, co
   const int wave = wave8 & 3;
   const int wm = wave >> 1, wn = wave & 1;
   IG_STAMP(0, wave_all == 0);
-  // PERSIST (round 5): the grid is P workgroups that walk the tiles P apart (a launch that must leave compute units to another
-  // stream's work -- the forward tail beside the backward pass -- cannot be budgeted any other way: a plain grid of 256 tiles
-  // takes the LDS of every CU for the length of a tile).  P % 8 == 0, so a workgroup's tiles keep its `lin & 7`, i.e. the XCD
-  // the tile remap below assumes; a tile leaves nothing in LDS that the next one reads (zero rows rewritten, one barrier between).
-  int lin = PERSIST ? (int)blockIdx.x : (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
-  do {
-    // zero rows (never written by the DMA): the source of a shifted pixel that falls off its image row
-    if (tid < HALVES * NSTX * 8) {
-      const int tm = tid / (NSTX * 8), k = tid - tm * (NSTX * 8);
-      *reinterpret_cast<f32x4*>(reinterpret_cast<half_t*>(smem_raw) + tm * RING + NSTW * WSLOT + (k >> 3) * XSLOT + BM * BK + (k & 7) * 8) =
-          (f32x4){0.f, 0.f, 0.f, 0.f};
+  // zero rows (never written by the DMA): the source of a shifted pixel that falls off its image row
+  if (tid < HALVES * NSTX * 8) {
+    const int tm = tid / (NSTX * 8), k = tid - tm * (NSTX * 8);
+    *reinterpret_cast<f32x4*>(reinterpret_cast<half_t*>(smem_raw) + tm * RING + NSTW * WSLOT + (k >> 3) * XSLOT + BM * BK + (k & 7) * 8) =
+        (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  int tile_m, tile_n, tile_z;
+  {
+    const int nx = h.ny_shift() >= 0 ? (1 << h.nx_shift()) : (int)gridDim.x, ny = h.ny_shift() >= 0 ? (1 << h.ny_shift()) : (int)gridDim.y;
+    const int nwg = h.nwg;
+    // hbase (round 5): a launch may cover only tiles [hbase, hbase + grid) of the layer -- the overlapped forward tail runs a
+    // layer as several one-dimensional launches of at most ISHAP_TAIL_WGS tiles, so that it never holds the LDS of more compute
+    // units than that and the backward chain on the caller's stream keeps the rest (launch4)
+    const int lin = hbase + blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, pos = lin >> 3;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    if (h.ny_shift() >= 0) {
+      tile_n = swz & (ny - 1);
+      tile_m = (swz >> h.ny_shift()) & (nx - 1);
+      tile_z = swz >> (h.ny_shift() + h.nx_shift());
+    } else {
+      tile_n = swz % ny;
+      tile_m = (swz / ny) % nx;
+      tile_z = swz / (ny * nx);
     }
-    int tile_m, tile_n, tile_z;
-    {
-      const int nx = h.ny_shift() >= 0 ? (1 << h.nx_shift()) : (int)gridDim.x, ny = h.ny_shift() >= 0 ? (1 << h.ny_shift()) : (int)gridDim.y;   // PERSIST: shifts (launcher)
-      const int nwg = h.nwg;
-      const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, pos = lin >> 3;
-      const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-      if (h.ny_shift() >= 0) {
-        tile_n = swz & (ny - 1);
-        tile_m = (swz >> h.ny_shift()) & (nx - 1);
-        tile_z = swz >> (h.ny_shift() + h.nx_shift());
-      } else {
-        tile_n = swz % ny;
-        tile_m = (swz / ny) % nx;
-        tile_z = swz / (ny * nx);
-      }
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int ks_id = tile_z;                        // nbatch == 1 (launcher)
-    const int H = h.H, HW = H * WD;
-    const int NC = h.Cin / BK;                       // 64-channel chunks
-    const int NC2 = (int)(h.packed >> 25);           // 64-channel chunks of the folded second source (launcher: K2 / 64)
-    const int G = 3 * NC;                            // slab groups (chunk, dy), three K-steps (dx) each
-    // this K slice: groups [g0, g1) of the 3x3 part and chunks [c20, c21) of the second source, both dealt out evenly
-    const int per = (G + h.ksplit - 1) / h.ksplit, per2 = (NC2 + h.ksplit - 1) / h.ksplit;
-    int g0 = min(G, ks_id * per), g1 = min(G, g0 + per);
-    int c20 = min(NC2, ks_id * per2), c21 = min(NC2, c20 + per2);
-    int nk_loop = (g1 - g0) * 3 + (c21 - c20);       // barrier count: identical for every wave of the workgroup
-    if (HALVES == 2) {
-      // team 0: the first ~half of the steps as whole groups; team 1: the other groups and the second source
-      const int ga = min(g1 - g0, (nk_loop + 3) / 6);
-      const int n0s = ga * 3, n1s = nk_loop - n0s;
-      nk_loop = max(n0s, n1s);
-      if (team == 0) { g1 = g0 + ga; c21 = c20; }
-      else g0 += ga;
-    }
-    const int ns3 = (g1 - g0) * 3, ns = ns3 + (c21 - c20);
-    const int n_img = h.hw_shift() >= 0 ? (m0 >> h.hw_shift()) : m0 / HW;
-    const int y0 = (m0 - n_img * HW) / WD;           // first image row of this tile
-    __syncthreads();                                 // the zero rows are in place
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int ks_id = tile_z;                        // nbatch == 1 (launcher)
+  const int H = h.H, HW = H * WD;
+  const int NC = h.Cin / BK;                       // 64-channel chunks
+  const int NC2 = (int)(h.packed >> 25);           // 64-channel chunks of the folded second source (launcher: K2 / 64)
+  const int G = 3 * NC;                            // slab groups (chunk, dy), three K-steps (dx) each
+  // this K slice: groups [g0, g1) of the 3x3 part and chunks [c20, c21) of the second source, both dealt out evenly
+  const int per = (G + h.ksplit - 1) / h.ksplit, per2 = (NC2 + h.ksplit - 1) / h.ksplit;
+  int g0 = min(G, ks_id * per), g1 = min(G, g0 + per);
+  int c20 = min(NC2, ks_id * per2), c21 = min(NC2, c20 + per2);
+  int nk_loop = (g1 - g0) * 3 + (c21 - c20);       // barrier count: identical for every wave of the workgroup
+  if (HALVES == 2) {
+    // team 0: the first ~half of the steps as whole groups; team 1: the other groups and the second source
+    const int ga = min(g1 - g0, (nk_loop + 3) / 6);
+    const int n0s = ga * 3, n1s = nk_loop - n0s;
+    nk_loop = max(n0s, n1s);
+    if (team == 0) { g1 = g0 + ga; c21 = c20; }
+    else g0 += ga;
+  }
+  const int ns3 = (g1 - g0) * 3, ns = ns3 + (c21 - c20);
+  const int n_img = h.hw_shift() >= 0 ? (m0 >> h.hw_shift()) : m0 / HW;
+  const int y0 = (m0 - n_img * HW) / WD;           // first image row of this tile
+  __syncthreads();                                 // the zero rows are in place
 
-    f32x4 acc[NT][MT];
+  f32x4 acc[NT][MT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    IG_STAMP(1, wave_all == 0);
-    if (loader) {
-      // ---- loader waves.  They pace the K loop (every step ends at a barrier they reach after their waits and issues), and a
-      // wave retires an instruction every ~5 cycles at best: the per-step path is kept to the DMA instructions, one 64-bit add
-      // per pointer and a few scalar instructions -- a first generic version of this loop (run-time load counts, addresses
-      // rebuilt per slab) cost 10-25 % of the whole launch (profiles/round4_igemm4_probe_v3.txt, column noload). ----
-      const int lrow = lane >> 3, pch = lane & 7;
-      // slab source of the issue head (chunk hc, kernel row hdy): xp = this lane's 16 bytes of pixel (y + hdy - 1, x), advanced by
-      // block-uniform deltas from slab to slab whether or not the row exists; a row outside the image reads zp (a zero line)
-      int hc = g0 / 3, hdy = g0 - hc * 3, hdx = 0;   // issue head of the 3x3 part: chunk, kernel row, column
-      const half_t* xp[XI];
-      const half_t* zp[XI];
-      int yr[XI], xc[XI];
+  IG_STAMP(1, wave_all == 0);
+  if (loader) {
+    // ---- loader waves.  They pace the K loop (every step ends at a barrier they reach after their waits and issues), and a
+    // wave retires an instruction every ~5 cycles at best: the per-step path is kept to the DMA instructions, one 64-bit add
+    // per pointer and a few scalar instructions -- a first generic version of this loop (run-time load counts, addresses
+    // rebuilt per slab) cost 10-25 % of the whole launch (profiles/round4_igemm4_probe_v3.txt, column noload). ----
+    const int lrow = lane >> 3, pch = lane & 7;
+    // slab source of the issue head (chunk hc, kernel row hdy): xp = this lane's 16 bytes of pixel (y + hdy - 1, x), advanced by
+    // block-uniform deltas from slab to slab whether or not the row exists; a row outside the image reads zp (a zero line)
+    int hc = g0 / 3, hdy = g0 - hc * 3, hdx = 0;   // issue head of the 3x3 part: chunk, kernel row, column
+    const half_t* xp[XI];
+    const half_t* zp[XI];
+    int yr[XI], xc[XI];
 #pragma unroll
-      for (int i = 0; i < XI; ++i) {
-        const int row = (wave * XI + i) * 8 + lrow;  // pixel of the tile = LDS row of the slab
-        yr[i] = y0 + row / WD;
-        xc[i] = row % WD;
-        const int sc = (pch ^ (row & 7)) * 8;
-        zp[i] = (const half_t*)g_zero_line4 + sc;
-        xp[i] = h.X + ((long long)n_img * HW + (long long)(yr[i] + hdy - 1) * WD + xc[i]) * h.ldx + hc * BK + sc;
-      }
-      const long long x_row = (long long)WD * h.ldx;          // one image row down
-      const half_t* wp[WI];
+    for (int i = 0; i < XI; ++i) {
+      const int row = (wave * XI + i) * 8 + lrow;  // pixel of the tile = LDS row of the slab
+      yr[i] = y0 + row / WD;
+      xc[i] = row % WD;
+      const int sc = (pch ^ (row & 7)) * 8;
+      zp[i] = (const half_t*)g_zero_line4 + sc;
+      xp[i] = h.X + ((long long)n_img * HW + (long long)(yr[i] + hdy - 1) * WD + xc[i]) * h.ldx + hc * BK + sc;
+    }
+    const long long x_row = (long long)WD * h.ldx;          // one image row down
+    const half_t* wp[WI];
 #pragma unroll
-      for (int i = 0; i < WI; ++i) {
-        const int row = (wave * WI + i) * 8 + lrow;
-        wp[i] = h.Wt + (long long)(n0 + row) * h.ldw + (pch ^ ((row >> 1) & 7)) * 8 + (long long)(3 * hdy) * h.Cin + hc * BK;
-      }
-      int hws = 0, hxs = 0;                          // ring slots of the head
-      int issued = 0, tot = 0;                       // K-steps / DMA instructions issued by this wave
-      auto issue3 = [&]() __attribute__((always_inline)) {      // one K-step of the 3x3 part
-        if (hdx == 0) {                              // a new slab: image rows y + hdy - 1 of chunk hc, staged once for dx = -1, 0, +1
-          half_t* x = sX + hxs * XSLOT;
-          const int dy = hdy - 1;
-          if (h.ups()) {                             // nearest-x2 upsampled source (4 launches per forward): addresses from scratch
-#pragma unroll
-            for (int i = 0; i < XI; ++i) {
-              const int yy = yr[i] + dy;
-              const bool ok = yy >= 0 && yy < H;
-              const int yc = ok ? yy : 0;
-              const long long pix = (long long)n_img * (HW >> 2) + (yc >> 1) * (WD >> 1) + (xc[i] >> 1);
-              const half_t* src = ok ? h.X + pix * h.ldx + hc * BK + (zp[i] - (const half_t*)g_zero_line4) : zp[i];
-              IG4_DMA(src, x + (wave * XI + i) * 8 * BK);
-            }
-          } else {
-            const long long dxp = hdy == 2 ? BK - 2 * x_row : x_row;      // to the next slab: a row down, or up two and a chunk on
-#pragma unroll
-            for (int i = 0; i < XI; ++i) {
-              const half_t* src = (unsigned)(yr[i] + dy) < (unsigned)H ? xp[i] : zp[i];
-              IG4_DMA(src, x + (wave * XI + i) * 8 * BK);
-              xp[i] += dxp;
-            }
-          }
-          hxs = hxs + 1 == NSTX ? 0 : hxs + 1;
-          tot += XI;
-        }
-        half_t* w = sW + hws * WSLOT;
-#pragma unroll
-        for (int i = 0; i < WI; ++i) IG4_DMA(wp[i], w + (wave * WI + i) * 8 * BK);
-        hws = hws + 1 == NSTW ? 0 : hws + 1;
-        long long dw = h.Cin;                        // taps are consecutive Cin-wide column blocks of the weight row
-        if (++hdx == 3) {
-          hdx = 0;
-          if (++hdy == 3) { hdy = 0; ++hc; dw = BK - 8LL * h.Cin; }
-        }
-#pragma unroll
-        for (int i = 0; i < WI; ++i) wp[i] += dw;
-        tot += WI;
-        ++issued;
-      };
-      auto issue2 = [&]() __attribute__((always_inline)) {      // one K-step of the folded second source: its own slab of X2 rows, unshifted
-        if (issued == ns3) {                         // entering it: re-aim the pointers (X2 rows; the last columns of the weight rows)
+    for (int i = 0; i < WI; ++i) {
+      const int row = (wave * WI + i) * 8 + lrow;
+      wp[i] = h.Wt + (long long)(n0 + row) * h.ldw + (pch ^ ((row >> 1) & 7)) * 8 + (long long)(3 * hdy) * h.Cin + hc * BK;
+    }
+    int hws = 0, hxs = 0;                          // ring slots of the head
+    int issued = 0, tot = 0;                       // K-steps / DMA instructions issued by this wave
+    auto issue3 = [&]() __attribute__((always_inline)) {      // one K-step of the 3x3 part
+      if (hdx == 0) {                              // a new slab: image rows y + hdy - 1 of chunk hc, staged once for dx = -1, 0, +1
+        half_t* x = sX + hxs * XSLOT;
+        const int dy = hdy - 1;
+        if (h.ups()) {                             // nearest-x2 upsampled source (4 launches per forward): addresses from scratch
 #pragma unroll
           for (int i = 0; i < XI; ++i) {
-            const int row = (wave * XI + i) * 8 + lrow;
-            xp[i] = a.X2 + (long long)(m0 + row) * a.ldx2 + c20 * BK + (pch ^ (row & 7)) * 8;
+            const int yy = yr[i] + dy;
+            const bool ok = yy >= 0 && yy < H;
+            const int yc = ok ? yy : 0;
+            const long long pix = (long long)n_img * (HW >> 2) + (yc >> 1) * (WD >> 1) + (xc[i] >> 1);
+            const half_t* src = ok ? h.X + pix * h.ldx + hc * BK + (zp[i] - (const half_t*)g_zero_line4) : zp[i];
+            IG4_DMA(src, x + (wave * XI + i) * 8 * BK);
           }
+        } else {
+          const long long dxp = hdy == 2 ? BK - 2 * x_row : x_row;      // to the next slab: a row down, or up two and a chunk on
 #pragma unroll
-          for (int i = 0; i < WI; ++i) {
-            const int row = (wave * WI + i) * 8 + lrow;
-            wp[i] = h.Wt + (long long)(n0 + row) * h.ldw + (pch ^ ((row >> 1) & 7)) * 8 + 9LL * h.Cin + (long long)c20 * BK;
+          for (int i = 0; i < XI; ++i) {
+            const half_t* src = (unsigned)(yr[i] + dy) < (unsigned)H ? xp[i] : zp[i];
+            IG4_DMA(src, x + (wave * XI + i) * 8 * BK);
+            xp[i] += dxp;
           }
         }
-        half_t* x = sX + hxs * XSLOT;
-#pragma unroll
-        for (int i = 0; i < XI; ++i) { IG4_DMA(xp[i], x + (wave * XI + i) * 8 * BK); xp[i] += BK; }
         hxs = hxs + 1 == NSTX ? 0 : hxs + 1;
-        half_t* w = sW + hws * WSLOT;
-#pragma unroll
-        for (int i = 0; i < WI; ++i) { IG4_DMA(wp[i], w + (wave * WI + i) * 8 * BK); wp[i] += BK; }
-        hws = hws + 1 == NSTW ? 0 : hws + 1;
-        tot += XI + WI;
-        ++issued;
-      };
-      using std::integral_constant;
-      // Everything that may be issued once the reads of K-steps < s are complete (s = -1: the prologue).  Step u needs its
-      // weight slot (u <= s + DIST) and, when it starts a slab, a dead slab slot: always true in the 3x3 part (3 NSTX >= DIST + 3),
-      // u <= s + NSTX - 1 for the one-step slabs of the second source.  The ring is NOT filled at once: a prologue of DIST
-      // stages from every CU at the same moment (HBM-cold weights) comes back at the burst rate of the whole chip and stage 0
-      // lands last-ish (9 800 cycles for 112 KB per CU against 4 400 for igemm2's 96 KB, in-kernel stamps) -- PRO steps first,
-      // then two more per iteration until DIST are in flight.
-      auto issue_after = [&](int s) __attribute__((always_inline)) {
-        while (issued < ns && issued <= s + DIST && issued < PRO + 2 * (s + 1) && (issued < ns3 || issued <= s + NSTX - 1)) {
-          if (issued < ns3) issue3();
-          else issue2();
-        }
-      };
-      int s = 0;
-      if (ns3 >= 2 * DIST + 3) {
-        // the common case, with compile-time load counts: PRO steps, RAMP peeled iterations that issue two steps each, then
-        // the steady loop (one step per iteration, DIST in flight) for as long as the step it issues is a 3x3 step
-#pragma unroll
-        for (int u = 0; u < PRO; ++u) issue3();
-        auto ramp_iter = [&](auto S) __attribute__((always_inline)) {
-          constexpr int s0 = decltype(S)::value;
-          constexpr int hd = PRO + 2 * s0;           // K-steps issued before barrier s0
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ig4_loads(s0 + 1, hd - 1, WI, XI)) : "memory");
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-          constexpr int upto = s0 + 1 + DIST < PRO + 2 * (s0 + 1) ? s0 + 1 + DIST : PRO + 2 * (s0 + 1);
-#pragma unroll
-          for (int u = hd; u < upto; ++u) issue3();
-        };
-        if constexpr (RAMP > 0) ramp_iter(integral_constant<int, 0>{});
-        if constexpr (RAMP > 1) ramp_iter(integral_constant<int, 1>{});
-        if constexpr (RAMP > 2) ramp_iter(integral_constant<int, 2>{});
-        if constexpr (RAMP > 3) ramp_iter(integral_constant<int, 3>{});
-        if constexpr (RAMP > 4) ramp_iter(integral_constant<int, 4>{});
-        if constexpr (RAMP > 5) ramp_iter(integral_constant<int, 5>{});
-        int ph = RAMP % 3;
-        for (s = RAMP; s + DIST < ns3; ++s) {
-          // K-step s has landed when at most the loads issued after its weights are outstanding: steps s+1 .. s+DIST-1
-          if (ph == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ig4_loads(1, DIST - 1, WI, XI)) : "memory");          // s = 0 (mod 3)
-          else if (ph == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ig4_loads(2, DIST, WI, XI)) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ig4_loads(3, DIST + 1, WI, XI)) : "memory");
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-          issue3();
-          ph = ph == 2 ? 0 : ph + 1;
-        }
-      } else {
-        issue_after(-1);
+        tot += XI;
       }
-      // the rest -- the tail of the 3x3 part, the second source, a slice too short for the loop above, the idle barriers of the
-      // shorter team -- with run-time counts: K-step s has landed when only the loads issued after its weights are outstanding
-      // (loads complete in order), i.e. everything issued so far minus everything up to and including step s
-      for (; s < nk_loop; ++s) {
-        if (s < ns) {
-          const int slabs = s < ns3 ? s / 3 + 1 : ns3 / 3 + (s - ns3 + 1);
-          ig4_wait_vm(tot - ((s + 1) * WI + slabs * XI));
+      half_t* w = sW + hws * WSLOT;
+#pragma unroll
+      for (int i = 0; i < WI; ++i) IG4_DMA(wp[i], w + (wave * WI + i) * 8 * BK);
+      hws = hws + 1 == NSTW ? 0 : hws + 1;
+      long long dw = h.Cin;                        // taps are consecutive Cin-wide column blocks of the weight row
+      if (++hdx == 3) {
+        hdx = 0;
+        if (++hdy == 3) { hdy = 0; ++hc; dw = BK - 8LL * h.Cin; }
+      }
+#pragma unroll
+      for (int i = 0; i < WI; ++i) wp[i] += dw;
+      tot += WI;
+      ++issued;
+    };
+    auto issue2 = [&]() __attribute__((always_inline)) {      // one K-step of the folded second source: its own slab of X2 rows, unshifted
+      if (issued == ns3) {                         // entering it: re-aim the pointers (X2 rows; the last columns of the weight rows)
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+          const int row = (wave * XI + i) * 8 + lrow;
+          xp[i] = a.X2 + (long long)(m0 + row) * a.ldx2 + c20 * BK + (pch ^ (row & 7)) * 8;
         }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+          const int row = (wave * WI + i) * 8 + lrow;
+          wp[i] = h.Wt + (long long)(n0 + row) * h.ldw + (pch ^ ((row >> 1) & 7)) * 8 + 9LL * h.Cin + (long long)c20 * BK;
+        }
+      }
+      half_t* x = sX + hxs * XSLOT;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) { IG4_DMA(xp[i], x + (wave * XI + i) * 8 * BK); xp[i] += BK; }
+      hxs = hxs + 1 == NSTX ? 0 : hxs + 1;
+      half_t* w = sW + hws * WSLOT;
+#pragma unroll
+      for (int i = 0; i < WI; ++i) { IG4_DMA(wp[i], w + (wave * WI + i) * 8 * BK); wp[i] += BK; }
+      hws = hws + 1 == NSTW ? 0 : hws + 1;
+      tot += XI + WI;
+      ++issued;
+    };
+    using std::integral_constant;
+    // Everything that may be issued once the reads of K-steps < s are complete (s = -1: the prologue).  Step u needs its
+    // weight slot (u <= s + DIST) and, when it starts a slab, a dead slab slot: always true in the 3x3 part (3 NSTX >= DIST + 3),
+    // u <= s + NSTX - 1 for the one-step slabs of the second source.  The ring is NOT filled at once: a prologue of DIST
+    // stages from every CU at the same moment (HBM-cold weights) comes back at the burst rate of the whole chip and stage 0
+    // lands last-ish (9 800 cycles for 112 KB per CU against 4 400 for igemm2's 96 KB, in-kernel stamps) -- PRO steps first,
+    // then two more per iteration until DIST are in flight.
+    auto issue_after = [&](int s) __attribute__((always_inline)) {
+      while (issued < ns && issued <= s + DIST && issued < PRO + 2 * (s + 1) && (issued < ns3 || issued <= s + NSTX - 1)) {
+        if (issued < ns3) issue3();
+        else issue2();
+      }
+    };
+    int s = 0;
+    if (ns3 >= 2 * DIST + 3) {
+      // the common case, with compile-time load counts: PRO steps, RAMP peeled iterations that issue two steps each, then
+      // the steady loop (one step per iteration, DIST in flight) for as long as the step it issues is a 3x3 step
+#pragma unroll
+      for (int u = 0; u < PRO; ++u) issue3();
+      auto ramp_iter = [&](auto S) __attribute__((always_inline)) {
+        constexpr int s0 = decltype(S)::value;
+        constexpr int hd = PRO + 2 * s0;           // K-steps issued before barrier s0
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ig4_loads(s0 + 1, hd - 1, WI, XI)) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue_after(s);
+        constexpr int upto = s0 + 1 + DIST < PRO + 2 * (s0 + 1) ? s0 + 1 + DIST : PRO + 2 * (s0 + 1);
+#pragma unroll
+        for (int u = hd; u < upto; ++u) issue3();
+      };
+      if constexpr (RAMP > 0) ramp_iter(integral_constant<int, 0>{});
+      if constexpr (RAMP > 1) ramp_iter(integral_constant<int, 1>{});
+      if constexpr (RAMP > 2) ramp_iter(integral_constant<int, 2>{});
+      if constexpr (RAMP > 3) ramp_iter(integral_constant<int, 3>{});
+      if constexpr (RAMP > 4) ramp_iter(integral_constant<int, 4>{});
+      if constexpr (RAMP > 5) ramp_iter(integral_constant<int, 5>{});
+      int ph = RAMP % 3;
+      for (s = RAMP; s + DIST < ns3; ++s) {
+        // K-step s has landed when at most the loads issued after its weights are outstanding: steps s+1 .. s+DIST-1
+        if (ph == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ig4_loads(1, DIST - 1, WI, XI)) : "memory");          // s = 0 (mod 3)
+        else if (ph == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ig4_loads(2, DIST, WI, XI)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ig4_loads(3, DIST + 1, WI, XI)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue3();
+        ph = ph == 2 ? 0 : ph + 1;
       }
     } else {
-      // ---- MFMA waves: fragment byte addresses within slot 0 of each ring, per 32-deep half; activations per shift ----
-      unsigned wo[2][NT], xo[3][2][MT];
-      const unsigned wbase = (unsigned)(unsigned long long)(lds_void4*)sW, xbase = (unsigned)(unsigned long long)(lds_void4*)sX;
+      issue_after(-1);
+    }
+    // the rest -- the tail of the 3x3 part, the second source, a slice too short for the loop above, the idle barriers of the
+    // shorter team -- with run-time counts: K-step s has landed when only the loads issued after its weights are outstanding
+    // (loads complete in order), i.e. everything issued so far minus everything up to and including step s
+    for (; s < nk_loop; ++s) {
+      if (s < ns) {
+        const int slabs = s < ns3 ? s / 3 + 1 : ns3 / 3 + (s - ns3 + 1);
+        ig4_wait_vm(tot - ((s + 1) * WI + slabs * XI));
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_after(s);
+    }
+  } else {
+    // ---- MFMA waves: fragment byte addresses within slot 0 of each ring, per 32-deep half; activations per shift ----
+    unsigned wo[2][NT], xo[3][2][MT];
+    const unsigned wbase = (unsigned)(unsigned long long)(lds_void4*)sW, xbase = (unsigned)(unsigned long long)(lds_void4*)sX;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int ch = (lane >> 4) + 4 * kk;
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = (lane >> 4) + 4 * kk;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-          const int row = wn * TNW + i * 16 + (lane & 15);
-          wo[kk][i] = wbase + 2 * (row * BK + ((ch ^ ((row >> 1) & 7)) * 8));
-        }
+      for (int i = 0; i < NT; ++i) {
+        const int row = wn * TNW + i * 16 + (lane & 15);
+        wo[kk][i] = wbase + 2 * (row * BK + ((ch ^ ((row >> 1) & 7)) * 8));
+      }
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-          const int pl = wm * TMW + j * 16 + (lane & 15);
-          const int x = pl % WD;
+      for (int j = 0; j < MT; ++j) {
+        const int pl = wm * TMW + j * 16 + (lane & 15);
+        const int x = pl % WD;
 #pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const int xs = x + d - 1;
-            const int row = (xs >= 0 && xs < WD) ? pl + d - 1 : BM;       // BM = the zero row
-            xo[d][kk][j] = xbase + 2 * (row * BK + (row == BM ? ch * 8 : ((ch ^ (row & 7)) * 8)));
-          }
+        for (int d = 0; d < 3; ++d) {
+          const int xs = x + d - 1;
+          const int row = (xs >= 0 && xs < WD) ? pl + d - 1 : BM;       // BM = the zero row
+          xo[d][kk][j] = xbase + 2 * (row * BK + (row == BM ? ch * 8 : ((ch ^ (row & 7)) * 8)));
         }
       }
-      half8 xa[MT], wa[NT], xb[MT], wb[NT];
-      unsigned sw_off = 0, sx_off = 0;               // byte offsets of the current W / X ring slots
-      auto read_frags = [&](const unsigned (&xs)[2][MT], int kk, unsigned swo, unsigned sxo, half8 (&xf)[MT], half8 (&wf)[NT]) {
+    }
+    half8 xa[MT], wa[NT], xb[MT], wb[NT];
+    unsigned sw_off = 0, sx_off = 0;               // byte offsets of the current W / X ring slots
+    auto read_frags = [&](const unsigned (&xs)[2][MT], int kk, unsigned swo, unsigned sxo, half8 (&xf)[MT], half8 (&wf)[NT]) {
 #pragma unroll
-        for (int j = 0; j < MT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[j]) : "v"(xs[kk][j] + sxo) : "memory");
+      for (int j = 0; j < MT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[j]) : "v"(xs[kk][j] + sxo) : "memory");
 #pragma unroll
-        for (int i = 0; i < NT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(wf[i]) : "v"(wo[kk][i] + swo) : "memory");
-      };
-      auto read_half = [&](auto DX, int kk, unsigned swo, unsigned sxo, half8 (&xf)[MT], half8 (&wf)[NT]) {
-        read_frags(xo[decltype(DX)::value], kk, swo, sxo, xf, wf);
-      };
-      auto wait_frags = [&](auto pending, half8 (&xf)[MT], half8 (&wf)[NT]) {
-        static_assert((MT == 2 || MT == 4) && (NT == 2 || NT == 4), "operand list");
-        if constexpr (MT == 4 && NT == 4)
-          asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3])
-                       : "n"(decltype(pending)::value) : "memory");
-        else if constexpr (MT == 4 && NT == 2)
-          asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(wf[0]), "+v"(wf[1])
-                       : "n"(decltype(pending)::value) : "memory");
-        else if constexpr (MT == 2 && NT == 4)
-          asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3])
-                       : "n"(decltype(pending)::value) : "memory");
-        else
-          asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(wf[0]), "+v"(wf[1]) : "n"(decltype(pending)::value) : "memory");
-      };
-      auto mfma_half = [&](half8 (&xf)[MT], half8 (&wf)[NT]) {
+      for (int i = 0; i < NT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(wf[i]) : "v"(wo[kk][i] + swo) : "memory");
+    };
+    auto read_half = [&](auto DX, int kk, unsigned swo, unsigned sxo, half8 (&xf)[MT], half8 (&wf)[NT]) {
+      read_frags(xo[decltype(DX)::value], kk, swo, sxo, xf, wf);
+    };
+    auto wait_frags = [&](auto pending, half8 (&xf)[MT], half8 (&wf)[NT]) {
+      static_assert((MT == 2 || MT == 4) && (NT == 2 || NT == 4), "operand list");
+      if constexpr (MT == 4 && NT == 4)
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3])
+                     : "n"(decltype(pending)::value) : "memory");
+      else if constexpr (MT == 4 && NT == 2)
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(wf[0]), "+v"(wf[1])
+                     : "n"(decltype(pending)::value) : "memory");
+      else if constexpr (MT == 2 && NT == 4)
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3])
+                     : "n"(decltype(pending)::value) : "memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(wf[0]), "+v"(wf[1]) : "n"(decltype(pending)::value) : "memory");
+    };
+    auto mfma_half = [&](half8 (&xf)[MT], half8 (&wf)[NT]) {
 #ifndef ABL_NOMFMA
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-          for (int j = 0; j < MT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < MT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
 #else
 #pragma unroll
-        for (int i = 0; i < NT; ++i) acc[i][0][0] += (float)wf[i][0];
+      for (int i = 0; i < NT; ++i) acc[i][0][0] += (float)wf[i][0];
 #pragma unroll
-        for (int j = 0; j < MT; ++j) acc[0][j][1] += (float)xf[j][0];
+      for (int j = 0; j < MT; ++j) acc[0][j][1] += (float)xf[j][0];
 #endif
-      };
-      // MFMAs of one 32-deep half with the fragment reads of the NEXT half in their gaps (one read behind each of the first MT + NT
-      // MFMAs, pinned by scheduling barriers): issued in a burst the eight reads and their address adds kept the MFMA pipe idle for
-      // ~100 cycles twice per K-step (the wave issues in order, the reads sat behind the sixteenth MFMA)
-      auto read_one = [&](const unsigned (&xs)[2][MT], int kk, unsigned swo, unsigned sxo, half8 (&xf)[MT], half8 (&wf)[NT], int r) __attribute__((always_inline)) {
-        if (r < MT) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[r]) : "v"(xs[kk][r] + sxo) : "memory");
-        else asm volatile("ds_read_b128 %0, %1" : "=v"(wf[r - MT]) : "v"(wo[kk][r - MT] + swo) : "memory");
-      };
-      auto mfma_reads = [&](half8 (&xf)[MT], half8 (&wf)[NT], const unsigned (&xs)[2][MT], int kk, unsigned swo, unsigned sxo, half8 (&xn)[MT],
-                            half8 (&wn)[NT]) __attribute__((always_inline)) {
+    };
+    // MFMAs of one 32-deep half with the fragment reads of the NEXT half in their gaps (one read behind each of the first MT + NT
+    // MFMAs, pinned by scheduling barriers): issued in a burst the eight reads and their address adds kept the MFMA pipe idle for
+    // ~100 cycles twice per K-step (the wave issues in order, the reads sat behind the sixteenth MFMA)
+    auto read_one = [&](const unsigned (&xs)[2][MT], int kk, unsigned swo, unsigned sxo, half8 (&xf)[MT], half8 (&wf)[NT], int r) __attribute__((always_inline)) {
+      if (r < MT) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[r]) : "v"(xs[kk][r] + sxo) : "memory");
+      else asm volatile("ds_read_b128 %0, %1" : "=v"(wf[r - MT]) : "v"(wo[kk][r - MT] + swo) : "memory");
+    };
+    auto mfma_reads = [&](half8 (&xf)[MT], half8 (&wf)[NT], const unsigned (&xs)[2][MT], int kk, unsigned swo, unsigned sxo, half8 (&xn)[MT],
+                          half8 (&wn)[NT]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-          for (int j = 0; j < MT; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-            const int r = i * MT + j;
-            if (r < MT + NT) {
-              read_one(xs, kk, swo, sxo, xn, wn, r);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-      };
-      using std::integral_constant;
-      // one K-step at shift DX (= dx + 1): second half read under the MFMAs of the first, first half of the next step read
-      // right after its barrier.  SLAB_ENDS: the step is the last one on its slab (dx = +1, or any step of the second
-      // source).  The next step reads at shift (DX + 1) % 3 inside the 3x3 part and unshifted (1) in the second source.
-      // 128x128 tiles (MFMA-paced K loop): the interleaved form, -1.5 / -2.2 % per launch (128^2: 256->256 26.2 -> 25.8 us, 512->256
-      // 43.2 -> 42.2; profiles/round4_igemm4_interleave_probe.txt); on the 64x64 tiles (paced by the staging) it is 1-3 % slower in situ
-      constexpr bool INTERLEAVE = BM == 128 && BN == 128;
-      auto step_il = [&](auto DX, auto SLAB_ENDS, int s) {
-        constexpr int d = decltype(DX)::value;
-        wait_frags(integral_constant<int, 0>{}, xa, wa);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_reads(xa, wa, xo[d], 1, sw_off, sx_off, xb, wb);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_frags(integral_constant<int, 0>{}, xb, wb);
-        sw_off = sw_off + WSLOT * 2 == NSTW * WSLOT * 2 ? 0u : sw_off + WSLOT * 2;
-        if (decltype(SLAB_ENDS)::value) sx_off = sx_off + XSLOT * 2 == NSTX * XSLOT * 2 ? 0u : sx_off + XSLOT * 2;
-        if (s + 1 < nk_loop) {
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-          if (s + 1 < ns) {
+        for (int j = 0; j < MT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          const int r = i * MT + j;
+          if (r < MT + NT) {
+            read_one(xs, kk, swo, sxo, xn, wn, r);
             __builtin_amdgcn_sched_barrier(0);
-            if (decltype(SLAB_ENDS)::value && s + 1 >= ns3) mfma_reads(xb, wb, xo[1], 0, sw_off, sx_off, xa, wa);
-            else mfma_reads(xb, wb, xo[(d + 1) % 3], 0, sw_off, sx_off, xa, wa);
-            __builtin_amdgcn_sched_barrier(0);
-            return;
           }
         }
-        mfma_half(xb, wb);
-      };
-      auto step_burst = [&](auto DX, auto SLAB_ENDS, int s) {
-        constexpr int d = decltype(DX)::value;
-        read_half(DX, 1, sw_off, sx_off, xb, wb);
-        wait_frags(integral_constant<int, MT + NT>{}, xa, wa);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_half(xa, wa);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_frags(integral_constant<int, 0>{}, xb, wb);
-        sw_off = sw_off + WSLOT * 2 == NSTW * WSLOT * 2 ? 0u : sw_off + WSLOT * 2;
-        if (decltype(SLAB_ENDS)::value) sx_off = sx_off + XSLOT * 2 == NSTX * XSLOT * 2 ? 0u : sx_off + XSLOT * 2;
-        if (s + 1 < nk_loop) {
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-          if (s + 1 < ns) {
-            if (decltype(SLAB_ENDS)::value && s + 1 >= ns3) read_half(integral_constant<int, 1>{}, 0, sw_off, sx_off, xa, wa);
-            else read_half(integral_constant<int, (d + 1) % 3>{}, 0, sw_off, sx_off, xa, wa);
-          }
+    };
+    using std::integral_constant;
+    // one K-step at shift DX (= dx + 1): second half read under the MFMAs of the first, first half of the next step read
+    // right after its barrier.  SLAB_ENDS: the step is the last one on its slab (dx = +1, or any step of the second
+    // source).  The next step reads at shift (DX + 1) % 3 inside the 3x3 part and unshifted (1) in the second source.
+    // 128x128 tiles (MFMA-paced K loop): the interleaved form, -1.5 / -2.2 % per launch (128^2: 256->256 26.2 -> 25.8 us, 512->256
+    // 43.2 -> 42.2; profiles/round4_igemm4_interleave_probe.txt); on the 64x64 tiles (paced by the staging) it is 1-3 % slower in situ
+    constexpr bool INTERLEAVE = BM == 128 && BN == 128;
+    auto step_il = [&](auto DX, auto SLAB_ENDS, int s) {
+      constexpr int d = decltype(DX)::value;
+      wait_frags(integral_constant<int, 0>{}, xa, wa);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_reads(xa, wa, xo[d], 1, sw_off, sx_off, xb, wb);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_frags(integral_constant<int, 0>{}, xb, wb);
+      sw_off = sw_off + WSLOT * 2 == NSTW * WSLOT * 2 ? 0u : sw_off + WSLOT * 2;
+      if (decltype(SLAB_ENDS)::value) sx_off = sx_off + XSLOT * 2 == NSTX * XSLOT * 2 ? 0u : sx_off + XSLOT * 2;
+      if (s + 1 < nk_loop) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 1 < ns) {
           __builtin_amdgcn_sched_barrier(0);
+          if (decltype(SLAB_ENDS)::value && s + 1 >= ns3) mfma_reads(xb, wb, xo[1], 0, sw_off, sx_off, xa, wa);
+          else mfma_reads(xb, wb, xo[(d + 1) % 3], 0, sw_off, sx_off, xa, wa);
+          __builtin_amdgcn_sched_barrier(0);
+          return;
         }
-        mfma_half(xb, wb);
-      };
-      auto step = [&](auto DX, auto SLAB_ENDS, int s) __attribute__((always_inline)) {
-        if constexpr (INTERLEAVE) step_il(DX, SLAB_ENDS, s);
-        else step_burst(DX, SLAB_ENDS, s);
-      };
-      if (nk_loop > 0) __builtin_amdgcn_s_barrier();      // step 0 has landed (every wave passes nk_loop barriers)
-      asm volatile("" ::: "memory");
-      IG_STAMP(2, wave_all == 0);
-      if (ns > 0) {
-        if (ns3 > 0) read_half(integral_constant<int, 0>{}, 0, sw_off, sx_off, xa, wa);
-        else read_half(integral_constant<int, 1>{}, 0, sw_off, sx_off, xa, wa);
       }
-      int s = 0;
-      for (; s < ns3; s += 3) {
-        step(integral_constant<int, 0>{}, std::false_type{}, s);
-        step(integral_constant<int, 1>{}, std::false_type{}, s + 1);
-        step(integral_constant<int, 2>{}, std::true_type{}, s + 2);
+      mfma_half(xb, wb);
+    };
+    auto step_burst = [&](auto DX, auto SLAB_ENDS, int s) {
+      constexpr int d = decltype(DX)::value;
+      read_half(DX, 1, sw_off, sx_off, xb, wb);
+      wait_frags(integral_constant<int, MT + NT>{}, xa, wa);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_half(xa, wa);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_frags(integral_constant<int, 0>{}, xb, wb);
+      sw_off = sw_off + WSLOT * 2 == NSTW * WSLOT * 2 ? 0u : sw_off + WSLOT * 2;
+      if (decltype(SLAB_ENDS)::value) sx_off = sx_off + XSLOT * 2 == NSTX * XSLOT * 2 ? 0u : sx_off + XSLOT * 2;
+      if (s + 1 < nk_loop) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 1 < ns) {
+          if (decltype(SLAB_ENDS)::value && s + 1 >= ns3) read_half(integral_constant<int, 1>{}, 0, sw_off, sx_off, xa, wa);
+          else read_half(integral_constant<int, (d + 1) % 3>{}, 0, sw_off, sx_off, xa, wa);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      for (; s < ns; ++s) step(integral_constant<int, 1>{}, std::true_type{}, s);
-      for (; s < nk_loop; ++s)                       // the shorter team of a two-team workgroup idles through the last barriers
-        if (s + 1 < nk_loop) __builtin_amdgcn_s_barrier();
+      mfma_half(xb, wb);
+    };
+    auto step = [&](auto DX, auto SLAB_ENDS, int s) __attribute__((always_inline)) {
+      if constexpr (INTERLEAVE) step_il(DX, SLAB_ENDS, s);
+      else step_burst(DX, SLAB_ENDS, s);
+    };
+    if (nk_loop > 0) __builtin_amdgcn_s_barrier();      // step 0 has landed (every wave passes nk_loop barriers)
+    asm volatile("" ::: "memory");
+    IG_STAMP(2, wave_all == 0);
+    if (ns > 0) {
+      if (ns3 > 0) read_half(integral_constant<int, 0>{}, 0, sw_off, sx_off, xa, wa);
+      else read_half(integral_constant<int, 1>{}, 0, sw_off, sx_off, xa, wa);
     }
-    IG_STAMP(3, wave_all == 0);
-    // two teams on the staged path: both teams' partial tiles go straight into the epilogue, which adds them row by row
-    const bool merge_in_epilogue = HALVES == 2 && igemm_epilogue_is_staged(a, 0);
-    if (HALVES == 2 && !merge_in_epilogue) {
-      // team 1 hands its accumulators to team 0 through (its own, now idle) ring memory
-      f32x4* red = reinterpret_cast<f32x4*>(reinterpret_cast<half_t*>(smem_raw) + RING);
-      __syncthreads();                               // every fragment read of the K loop is done
-      if (!loader && team == 1) {
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-          for (int j = 0; j < MT; ++j) red[((i * MT + j) * 4 + wave) * 64 + lane] = acc[i][j];
-      }
-      __syncthreads();
-      if (!loader && team == 0) {
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-          for (int j = 0; j < MT; ++j) acc[i][j] += red[((i * MT + j) * 4 + wave) * 64 + lane];
-      }
+    int s = 0;
+    for (; s < ns3; s += 3) {
+      step(integral_constant<int, 0>{}, std::false_type{}, s);
+      step(integral_constant<int, 1>{}, std::false_type{}, s + 1);
+      step(integral_constant<int, 2>{}, std::true_type{}, s + 2);
     }
-    IG_STAMP(4, wave_all == 0);
-    igemm_epilogue<MT, NT, TMW, TNW, BN, 512 * HALVES>(a, acc, m0, n0, wm, wn, lane, 0, ks_id, reinterpret_cast<float*>(smem_raw),
-                                                       !loader && (team == 0 || merge_in_epilogue), merge_in_epilogue ? team : -1);
-    if (!PERSIST) break;
-    lin += (int)gridDim.x;
-    if (lin >= h.nwg) break;
-    __syncthreads();                               // the epilogue's LDS tiles are dead: the next tile's ring may land
-  } while (true);
+    for (; s < ns; ++s) step(integral_constant<int, 1>{}, std::true_type{}, s);
+    for (; s < nk_loop; ++s)                       // the shorter team of a two-team workgroup idles through the last barriers
+      if (s + 1 < nk_loop) __builtin_amdgcn_s_barrier();
+  }
+  IG_STAMP(3, wave_all == 0);
+  // two teams on the staged path: both teams' partial tiles go straight into the epilogue, which adds them row by row
+  const bool merge_in_epilogue = HALVES == 2 && igemm_epilogue_is_staged(a, 0);
+  if (HALVES == 2 && !merge_in_epilogue) {
+    // team 1 hands its accumulators to team 0 through (its own, now idle) ring memory
+    f32x4* red = reinterpret_cast<f32x4*>(reinterpret_cast<half_t*>(smem_raw) + RING);
+    __syncthreads();                               // every fragment read of the K loop is done
+    if (!loader && team == 1) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) red[((i * MT + j) * 4 + wave) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (!loader && team == 0) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] += red[((i * MT + j) * 4 + wave) * 64 + lane];
+    }
+  }
+  IG_STAMP(4, wave_all == 0);
+  igemm_epilogue<MT, NT, TMW, TNW, BN, 512 * HALVES>(a, acc, m0, n0, wm, wn, lane, 0, ks_id, reinterpret_cast<float*>(smem_raw),
+                                                     !loader && (team == 0 || merge_in_epilogue), merge_in_epilogue ? team : -1);
 #endif
 }
 
@@ -504,35 +497,35 @@ static int launch4(const IgemmArgs& a, hipStream_t s) {
   constexpr size_t smem = ring > epi ? ring : epi;
   static_assert(smem <= 163840, "LDS");
   auto kern = igemm4_kernel<BM, BN, WD, NSTW, NSTX, HALVES>;
-  dim3 grid(a.M / BM, ceil_div(a.N, BN), a.ksplit);
-  // persistent form (IgemmArgs::persist_wgs): P workgroups walk the tiles; 128x128 tiles only (the forward tail's launches)
-  if constexpr (BM == 128 && BN == 128 && HALVES == 1) {
-    const int tiles = (int)(grid.x * grid.y * grid.z);
-    const bool pow2 = (grid.x & (grid.x - 1)) == 0 && (grid.y & (grid.y - 1)) == 0;
-    if (a.persist_wgs > 0 && a.persist_wgs % 8 == 0 && tiles > a.persist_wgs && pow2) {
-      kern = igemm4_kernel<BM, BN, WD, NSTW, NSTX, HALVES, true>;
-      grid = dim3(a.persist_wgs, 1, 1);
-    }
-  }
-  const dim3 tiles3(a.M / BM, ceil_div(a.N, BN), a.ksplit);
   ISHAP_TRY(ishap_set_max_lds((const void*)kern, (int)smem));
+  const dim3 grid(a.M / BM, ceil_div(a.N, BN), a.ksplit);
   IgemmArgs b = a;
   auto lg2 = [](int v) { int k = 0; while ((1 << k) < v) ++k; return (1 << k) == v ? k : -1; };
   b.w_shift = lg2(a.W);
   b.hw_shift = lg2(a.H * a.W);
   if (b.w_shift < 0 || b.hw_shift < 0) b.w_shift = b.hw_shift = -1;
-  b.nx_shift = lg2((int)tiles3.x);
-  b.ny_shift = lg2((int)tiles3.y);
+  b.nx_shift = lg2((int)grid.x);
+  b.ny_shift = lg2((int)grid.y);
   if (b.nx_shift < 0 || b.ny_shift < 0) b.nx_shift = b.ny_shift = -1;
   IgemmHot h;
   h.X = b.X; h.Wt = b.Wt; h.K = b.K; h.Cin = b.Cin; h.ldx = b.ldx; h.ldw = b.ldw; h.H = b.H; h.W = b.W; h.ksplit = b.ksplit;
-  h.nwg = (int)(tiles3.x * tiles3.y * tiles3.z);
+  h.nwg = (int)(grid.x * grid.y * grid.z);
   h.packed = (unsigned)(b.w_shift & 0x3f) | (unsigned)(b.hw_shift & 0x3f) << 6 | (unsigned)(b.nx_shift & 0x3f) << 12 |
              (unsigned)(b.ny_shift & 0x3f) << 18 | (b.ups ? 1u << 24 : 0u) | (unsigned)(b.K2 / 64) << 25;
-  if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(512 * HALVES), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0,
-                                                (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, b);
+  // chunked form (IgemmArgs::chunk_tiles > 0, a multiple of 8 so that a tile keeps the `lin & 7` = XCD of the remap): the layer as
+  // ceil(tiles / chunk) launches of at most `chunk` tiles each, back to back on the stream
+  const int tiles = h.nwg;
+  const bool chunked = a.chunk_tiles > 0 && a.chunk_tiles % 8 == 0 && tiles > a.chunk_tiles && b.nx_shift >= 0 && !g_igemm_prof_start;
+  if (chunked) {
+    for (int base = 0; base < tiles; base += a.chunk_tiles) {
+      const int n = tiles - base < a.chunk_tiles ? tiles - base : a.chunk_tiles;
+      hipLaunchKernelGGL(kern, dim3(n), dim3(512 * HALVES), smem, s,
+                         (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, base, b);
+    }
+  } else if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(512 * HALVES), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0,
+                                                (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, 0, b);
   else hipLaunchKernelGGL(kern, grid, dim3(512 * HALVES), smem, s,
-                          (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, b);
+                          (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, 0, b);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

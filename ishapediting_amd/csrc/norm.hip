@@ -174,82 +174,106 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(int h_main_blocks, int h_
 #pragma unroll
   for (int i = 0; i < 8; ++i) { gam[i] = a.gamma[c0 + i]; bet[i] = a.beta[c0 + i]; }
   int cur_n = -1;
-  for (int pix = tg / CV; pix < npix; pix += pstep) {
-    const int n = h_N == 1 ? 0 : pix / HWo;
-    const int p = pix - n * HWo;
-    if (n != cur_n) {
-      cur_n = n;
+  auto image_params = [&](int n) __attribute__((always_inline)) {
+    if (n == cur_n) return;
+    cur_n = n;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c0 + i, g = c / cpg;
-        mu[i] = stats[(n * 32 + g) * 2];
-        rs[i] = stats[(n * 32 + g) * 2 + 1];
-        if (FILM) {
-          sc[i] = (half_t)(1.f + rh(a.emb[(long long)n * a.emb_ld + c]));
-          sh[i] = (half_t)a.emb[(long long)n * a.emb_ld + h_C + c];
-        }
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i, g = c / cpg;
+      mu[i] = stats[(n * 32 + g) * 2];
+      rs[i] = stats[(n * 32 + g) * 2 + 1];
+      if (FILM) {
+        sc[i] = (half_t)(1.f + rh(a.emb[(long long)n * a.emb_ld + c]));
+        sh[i] = (half_t)a.emb[(long long)n * a.emb_ld + h_C + c];
       }
     }
-    auto one = [&](const half8& v, float* o) {
+  };
+  auto one = [&](const half8& v, float* o) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float y;
-        if (SPLIT) {                                  // fp32 head: no fp16 rounding points
-          y = ((float)v[i] - mu[i]) * rs[i] * gam[i] + bet[i];
-          if (ACT) y = gn_silu(y);
-        } else {
-          half_t yh = gn_affine((float)v[i], mu[i], rs[i], gam[i], bet[i]);
-          if (FILM) yh = gn_film(yh, sc[i], sh[i]);
-          y = (float)yh;
-          if (ACT) y = rh(gn_silu(y));
-        }
-        o[i] = y;
+    for (int i = 0; i < 8; ++i) {
+      float y;
+      if (SPLIT) {                                  // fp32 head: no fp16 rounding points
+        y = ((float)v[i] - mu[i]) * rs[i] * gam[i] + bet[i];
+        if (ACT) y = gn_silu(y);
+      } else {
+        half_t yh = gn_affine((float)v[i], mu[i], rs[i], gam[i], bet[i]);
+        if (FILM) yh = gn_film(yh, sc[i], sh[i]);
+        y = (float)yh;
+        if (ACT) y = rh(gn_silu(y));
       }
-    };
-    float o[8];
-    if (POOL) {
+      o[i] = y;
+    }
+  };
+  if (POOL) {
+    for (int pix = tg / CV; pix < npix; pix += pstep) {
+      const int n = h_N == 1 ? 0 : pix / HWo;
+      const int p = pix - n * HWo;
+      image_params(n);
       const int Wo = h_W >> 1;
       const int yo = p / Wo, xo = p % Wo;
       float acc[8], xacc[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) { acc[i] = 0.f; xacc[i] = 0.f; }
+      half8 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                  // the four inputs of the 2x2 cell in flight together
+        const long long src = (long long)n * h_H * h_W + (2 * yo + (q >> 1)) * h_W + 2 * xo + (q & 1);
+        v[q] = *reinterpret_cast<const half8*>(a.x + src * h_C + c0);
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        long long src = (long long)n * h_H * h_W + (2 * yo + (q >> 1)) * h_W + 2 * xo + (q & 1);
-        half8 v = *reinterpret_cast<const half8*>(a.x + src * h_C + c0);
         float t[8];
-        one(v, t);
+        one(v[q], t);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { acc[i] += t[i]; xacc[i] += (float)v[i]; }
+        for (int i = 0; i < 8; ++i) { acc[i] += t[i]; xacc[i] += (float)v[q][i]; }
       }
       half8 ov, xv;
 #pragma unroll
       for (int i = 0; i < 8; ++i) { ov[i] = (half_t)(acc[i] * 0.25f); xv[i] = (half_t)(xacc[i] * 0.25f); }
       *reinterpret_cast<half8*>(a.out + (long long)pix * h_C + c0) = ov;
       if (a.xpool) *reinterpret_cast<half8*>(a.xpool + (long long)pix * h_C + c0) = xv;
-    } else {
-      half8 v;
-      if (a.x2) {                                   // two-source input (skip concatenation); also emit the raw copy
-        v = c0 < a.csplit ? *reinterpret_cast<const half8*>(a.x + (long long)pix * a.csplit + c0)
-                          : *reinterpret_cast<const half8*>(a.x2 + (long long)pix * (h_C - a.csplit) + (c0 - a.csplit));
-        *reinterpret_cast<half8*>(a.xcopy + (long long)pix * h_C + c0) = v;
-      } else {
-        v = *reinterpret_cast<const half8*>(a.x + (long long)pix * h_C + c0);
+    }
+  } else {
+    // Round 5: a thread's pixels are fetched U at a time BEFORE any of them is processed.  With one 16-byte load per wave in
+    // flight (the old loop) a CU held 16 KB of loads and the 128^2 maps streamed at 1.9 TB/s -- Little's law on a ~2 us
+    // round trip, not an HBM limit (MI355X_MICROARCH.md: ~32 KB in flight per CU for streaming rates).
+    constexpr int U = 4;
+    for (int pix0 = tg / CV; pix0 < npix; pix0 += U * pstep) {
+      half8 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pix = pix0 + u * pstep;
+        if (pix < npix) {
+          if (a.x2) {                               // two-source input (skip concatenation)
+            v[u] = c0 < a.csplit ? *reinterpret_cast<const half8*>(a.x + (long long)pix * a.csplit + c0)
+                                 : *reinterpret_cast<const half8*>(a.x2 + (long long)pix * (h_C - a.csplit) + (c0 - a.csplit));
+          } else {
+            v[u] = *reinterpret_cast<const half8*>(a.x + (long long)pix * h_C + c0);
+          }
+        }
       }
-      one(v, o);
-      if (SPLIT) {
-        half8 hi, lo;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { hi[i] = (half_t)o[i]; lo[i] = (half_t)(o[i] - (float)hi[i]); }
-        half_t* dst = a.out + (long long)pix * (3LL * h_C);
-        *reinterpret_cast<half8*>(dst + c0) = hi;
-        *reinterpret_cast<half8*>(dst + h_C + c0) = lo;
-        *reinterpret_cast<half8*>(dst + 2 * h_C + c0) = hi;
-      } else {
-        half8 ov;
+      for (int u = 0; u < U; ++u) {
+        const int pix = pix0 + u * pstep;
+        if (pix >= npix) break;
+        image_params(h_N == 1 ? 0 : pix / HWo);
+        if (a.x2) *reinterpret_cast<half8*>(a.xcopy + (long long)pix * h_C + c0) = v[u];      // also emit the raw concatenation
+        float o[8];
+        one(v[u], o);
+        if (SPLIT) {
+          half8 hi, lo;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ov[i] = (half_t)o[i];
-        *reinterpret_cast<half8*>(a.out + (long long)pix * h_C + c0) = ov;
+          for (int i = 0; i < 8; ++i) { hi[i] = (half_t)o[i]; lo[i] = (half_t)(o[i] - (float)hi[i]); }
+          half_t* dst = a.out + (long long)pix * (3LL * h_C);
+          *reinterpret_cast<half8*>(dst + c0) = hi;
+          *reinterpret_cast<half8*>(dst + h_C + c0) = lo;
+          *reinterpret_cast<half8*>(dst + 2 * h_C + c0) = hi;
+        } else {
+          half8 ov;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ov[i] = (half_t)o[i];
+          *reinterpret_cast<half8*>(a.out + (long long)pix * h_C + c0) = ov;
+        }
       }
     }
   }

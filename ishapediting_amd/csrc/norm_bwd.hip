@@ -125,40 +125,56 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const long long* h_cs
 #pragma unroll
   for (int i = 0; i < 8; ++i) { gam[i] = a.gamma[c0 + i]; bet[i] = (FILM || ACT) ? a.beta[c0 + i] : 0.f; esc[i] = 0.f; esh[i] = 0.f; }
   int cur_n = -1;
-  for (int pix = tg / CV; pix < npix; pix += pstep) {
-    const int n = h_N == 1 ? 0 : pix / HW, p = pix - n * HW;
-    const int y = wpow2 ? p >> wsh : p / h_W, x = p - y * h_W;
-    if (n != cur_n) {
-      cur_n = n;
+  // Round 5: the operands of U pixels are fetched before the first of them is processed (2U-4U loads per wave in flight instead
+  // of 2-4: these passes stream the 128^2 / 64^2 maps, and a CU's bytes in flight set the rate -- see gn_apply_kernel, norm.hip)
+  constexpr int U = 2;
+  for (int pix0 = tg / CV; pix0 < npix; pix0 += U * pstep) {
+    float up[U][8], ad[U][8];
+    half8 xv[U], a2[U];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c0 + i, g = c / cpg;
-        mu[i] = a.stats[(n * 32 + g) * 2];
-        rs[i] = a.stats[(n * 32 + g) * 2 + 1];
-        m1[i] = sh_m[(n * 32 + g) * 2];
-        m2[i] = sh_m[(n * 32 + g) * 2 + 1];
-        if (FILM) { esc[i] = a.emb[(long long)n * a.emb_ld + c]; esh[i] = a.emb[(long long)n * a.emb_ld + h_C + c]; }
+    for (int u = 0; u < U; ++u) {
+      const int pix = pix0 + u * pstep;
+      a2[u] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (pix < npix) {
+        const int n = h_N == 1 ? 0 : pix / HW, p = pix - n * HW;
+        const int y = wpow2 ? p >> wsh : p / h_W, x = p - y * h_W;
+        load_upstream(a.g, a.gmode, n, y, x, h_H, h_W, h_C, c0, up[u]);
+        xv[u] = *reinterpret_cast<const half8*>(a.x + (long long)pix * h_C + c0);
+        if (a.add) load_upstream(a.add, a.gmode, n, y, x, h_H, h_W, h_C, c0, ad[u]);
+        if (a.add2) a2[u] = *reinterpret_cast<const half8*>(a.add2 + (long long)pix * h_C + c0);
       }
     }
-    float up[8], ad[8];
-    load_upstream(a.g, a.gmode, n, y, x, h_H, h_W, h_C, c0, up);
-    const half8 xv = *reinterpret_cast<const half8*>(a.x + (long long)pix * h_C + c0);
-    if (a.add) load_upstream(a.add, a.gmode, n, y, x, h_H, h_W, h_C, c0, ad);
-    half8 a2 = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (a.add2) a2 = *reinterpret_cast<const half8*>(a.add2 + (long long)pix * h_C + c0);
-    half8 o;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float dyh, xh;
-      gn_bwd_term(up[i], (float)xv[i], mu[i], rs[i], gam[i], bet[i], esc[i], esh[i], FILM, ACT, dyh, xh);
-      float v = gn_bwd_dx(rs[i], dyh, xh, m1[i], m2[i]);
-      if (a.add) v += ad[i];
-      if (a.add2) v = (float)(half_t)v + (float)a2[i];      // same rounding as a separate fp16 add of the two gradient maps
-      o[i] = (half_t)v;
+    for (int u = 0; u < U; ++u) {
+      const int pix = pix0 + u * pstep;
+      if (pix >= npix) break;
+      const int n = h_N == 1 ? 0 : pix / HW;
+      if (n != cur_n) {
+        cur_n = n;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = c0 + i, g = c / cpg;
+          mu[i] = a.stats[(n * 32 + g) * 2];
+          rs[i] = a.stats[(n * 32 + g) * 2 + 1];
+          m1[i] = sh_m[(n * 32 + g) * 2];
+          m2[i] = sh_m[(n * 32 + g) * 2 + 1];
+          if (FILM) { esc[i] = a.emb[(long long)n * a.emb_ld + c]; esh[i] = a.emb[(long long)n * a.emb_ld + h_C + c]; }
+        }
+      }
+      half8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float dyh, xh;
+        gn_bwd_term(up[u][i], (float)xv[u][i], mu[i], rs[i], gam[i], bet[i], esc[i], esh[i], FILM, ACT, dyh, xh);
+        float v = gn_bwd_dx(rs[i], dyh, xh, m1[i], m2[i]);
+        if (a.add) v += ad[u][i];
+        if (a.add2) v = (float)(half_t)v + (float)a2[u][i];      // same rounding as a separate fp16 add of the two gradient maps
+        o[i] = (half_t)v;
+      }
+      if (a.csplit == 0) *reinterpret_cast<half8*>(a.dx + (long long)pix * h_C + c0) = o;
+      else if (c0 < a.csplit) *reinterpret_cast<half8*>(a.dx + (long long)pix * a.csplit + c0) = o;
+      else *reinterpret_cast<half8*>(a.dx2 + (long long)pix * (h_C - a.csplit) + (c0 - a.csplit)) = o;
     }
-    if (a.csplit == 0) *reinterpret_cast<half8*>(a.dx + (long long)pix * h_C + c0) = o;
-    else if (c0 < a.csplit) *reinterpret_cast<half8*>(a.dx + (long long)pix * a.csplit + c0) = o;
-    else *reinterpret_cast<half8*>(a.dx2 + (long long)pix * (h_C - a.csplit) + (c0 - a.csplit)) = o;
   }
 }
 

@@ -187,7 +187,8 @@ struct Exec {
   bool keep = false;   // the forward keeps what a following backward re-reads
   float* ws = nullptr;          // split-K / GroupNorm-statistics scratch of this launch sequence (null: the context's)
   float* gn_partial = nullptr;
-  int persist_wgs = 0;          // > 0: 128x128-tile convolutions of this sequence run as that many persistent workgroups (the overlapped forward tail)
+  int force_small = 0;          // 1: this sequence's convolutions take 64x64 tiles only
+  int chunk_tiles = 0;          // > 0: the dx-reuse convolutions of this sequence run as launches of at most that many tiles (the overlapped forward tail)
   bool tenant = true;           // this sequence holds the device's rendezvous tenancy (common.h ishap_rendezvous_begin)
 };
 // RAII around a launch sequence: asks for the tenancy at construction, closes it (event on the stream) at scope exit

@@ -292,7 +292,8 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
   a.ldx = ldx; a.ldw = ldw ? ldw : taps * kpad; a.ldo = ldo; a.ldr = ldr;
   a.H = H; a.W = W; a.ups = ups; a.res_ups = res_ups;
   a.out_mode = out_mode;
-  a.persist_wgs = e.persist_wgs;
+  a.chunk_tiles = e.chunk_tiles;
+  a.force_small = e.force_small;
   a.flops_scale = (Wt == e.u->head.w) ? 1.f / 3.f : 1.f;
   a.ksplit = igemm_pick_ksplit(a.M, a.N, a.K, 1, pend_out != nullptr);
   if (!a.conv3 && a.M <= 64 && a.K % 64 == 0) {
@@ -603,8 +604,8 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     } else {
       ISHAP_CHECK_HIP(hipStreamCreateWithPriority(&u->side, hipStreamNonBlocking, prio_env ? prio_least : prio_greatest));
     }
-    ISHAP_CHECK_HIP(hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming));
-    ISHAP_CHECK_HIP(hipEventCreateWithFlags(&u->ev_tail, hipEventDisableTiming));
+    ISHAP_CHECK_HIP(hipEventCreateWithFlags(&u->ev_fork, ishap_event_flags()));
+    ISHAP_CHECK_HIP(hipEventCreateWithFlags(&u->ev_tail, ishap_event_flags()));
     if (u->ws_floats) ISHAP_CHECK_HIP(hipMalloc((void**)&u->ws_side, u->ws_floats * sizeof(float)));
     ISHAP_CHECK_HIP(hipMalloc((void**)&u->gn_partial_side, std::max<size_t>(u->gn_partial_floats, 64) * sizeof(float)));
   }
@@ -692,10 +693,14 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
         e.s = u->side;
         e.ws = u->ws_side;
         e.gn_partial = u->gn_partial_side;
-        // the tail's 128x128-tile convolutions as P persistent workgroups: they then hold the LDS of P compute units instead of
-        // all of them, and the backward chain on the caller's stream keeps the rest (ISHAP_TAIL_WGS, 0 = plain grids)
-        static const int tail_wgs = [] { const char* v = getenv("ISHAP_TAIL_WGS"); return v ? atoi(v) : 0; }();
-        e.persist_wgs = tail_wgs;
+        // the tail's 3x3 convolutions as launches of at most P tiles: it then holds the LDS of at most P compute units at a time
+        // and the backward chain on the caller's stream keeps the rest (ISHAP_TAIL_WGS, 0 = whole-layer grids)
+        // in-situ sweep (profiles/round5_overlap_tail_ab.txt): 64 tiles per launch is the optimum (32: the tail becomes the critical
+        // path; 96 ... 192 and whole layers: the backward's convolutions wait for compute units)
+        static const int tail_wgs = [] { const char* v = getenv("ISHAP_TAIL_WGS"); return v ? atoi(v) : 64; }();
+        e.chunk_tiles = tail_wgs;
+        static const int tail_small = [] { const char* v = getenv("ISHAP_TAIL_SMALL"); return v ? atoi(v) : 0; }();
+        e.force_small = tail_small;
       }
     }
   }

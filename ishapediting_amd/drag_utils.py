@@ -91,7 +91,7 @@ def resize_feat_align(feature, cat_var=True):
     return feature[0][cm.reshape(-1)].reshape(3, -1, feature.shape[2], feature.shape[3]).type(th.float32)
 
 
-_OVERLAP_TAIL = os.environ.get("ISHAP_OVERLAP_TAIL", "0") == "1"
+_OVERLAP_TAIL = os.environ.get("ISHAP_OVERLAP_TAIL", "1") == "1"      # round 5: on by default (see training())
 
 
 class DragKernels:
@@ -356,23 +356,20 @@ class DragStuff:
             def loss_and_backward():          # needs the tap only
                 cot, scale2 = dk.loss_cotangent_ptr(self.model.tap_ptr(), origin.data_ptr(), loss_out=losses[i:i + 1])
                 got["grad"] = self.model.backward_input(cot, scale2)           # = img.grad of the reference (:384)
+                return got["grad"]
 
-            # ISHAP_OVERLAP_TAIL=1 runs loss + backward beside the part of the forward after the tap (p_sample_guidance's
-            # `between`).  Measured on MI355X: no gain (0.205 vs 0.200 s/edit) -- the tail's 128x128-tile convolutions hold
-            # every CU's LDS, so the latency-bound backward chain waits for them instead of filling idle CUs; stream
-            # priorities change nothing and a CU-masked side stream is far slower (0.30 s).  Off by default.
+            # loss + backward run beside the part of the forward after the tap (p_sample_guidance's `between`; ISHAP_OVERLAP_TAIL=0:
+            # the plain sequence).  Rounds 2-4 measured a LOSS with whole-layer grids (the tail's 128x128-tile convolutions hold
+            # every CU's LDS for a tile's length and the backward chain queues behind them).  Round 5: the tail's convolutions run as
+            # launches of at most 64 tiles (ISHAP_TAIL_WGS, csrc/igemm4.hip launch4), i.e. on a quarter of the compute units at a
+            # time: -1.7 % per edit on three boxes (profiles/round5_overlap_tail_ab.txt); bit-identical results, tested.
+            # the update img = sample + variance * scale * grad (:384-392) is formed by the step kernel (guided_scale): the loss +
+            # backward run between the model call and the step arithmetic either way, beside the forward tail when overlapping
             outs = self.diffusion.p_sample_guidance(self.model, img, i, feat_layer=self.args.feat_layer,
                                                     keep_for_backward=True, want_inter_feat=False,
-                                                    noise=self._noise(i, img), between=loss_and_backward if _OVERLAP_TAIL else None)
-            if not _OVERLAP_TAIL:
-                loss_and_backward()
-            grads1 = got["grad"]
-            new = th.empty_like(img)
-            with th.cuda.device(self.device):
-                _lib.check(L.ishap_guided_update(outs["sample"].data_ptr(), outs["variance"].data_ptr(),
-                                                 grads1.data_ptr(), float(scale), None, img.numel(), new.data_ptr(),
-                                                 _lib.stream_ptr(self.device)))
-            img = new
+                                                    noise=self._noise(i, img), between=loss_and_backward, overlap=_OVERLAP_TAIL,
+                                                    guided_scale=float(scale))
+            img = outs["guided"]
             self.last_losses.append(losses[i:i + 1])
             yield 1 - i / (self.args.w_time - 1.)
         self.mesh = self.get_mesh(img=img, t=stop_time)

@@ -123,12 +123,22 @@ class SpacedDiffusion:
             return model(x, ts, **model_kwargs), None
         return model(x, ts, feat_layer=feat_layer, **model_kwargs)
 
-    def _step(self, x, model_output, t, noise, variance_in, clip_denoised, mode, want=("sample",), eta=0.0):
+    def _step(self, x, model_output, t, noise, variance_in, clip_denoised, mode, want=("sample",), eta=0.0, guide=None):
         N, Cc = x.shape[:2]
         HW = int(np.prod(x.shape[2:]))
         assert model_output.shape[1] == 2 * Cc
         outs = {k: torch.empty_like(x) for k in want}
         k = self._coefs(t, clip_denoised, mode, eta)
+        if guide is not None:                 # (d loss / d x, scale): the guided update in the same pass
+            grad, scale = guide
+            assert grad.shape == x.shape and grad.dtype == torch.float32 and grad.is_contiguous()
+            outs["guided"] = torch.empty_like(x)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().ishap_ddpm_step_guided(
+                    x.data_ptr(), model_output.data_ptr(), _lib.ptr(noise), _lib.ptr(variance_in), C.byref(k), N, Cc, HW,
+                    grad.data_ptr(), scale, None, outs["guided"].data_ptr(), _lib.ptr(outs.get("sample")),
+                    _lib.ptr(outs.get("variance")), _lib.stream_ptr(x.device)))
+            return outs
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().ishap_ddpm_step(
                 x.data_ptr(), model_output.data_ptr(), _lib.ptr(noise), _lib.ptr(variance_in), C.byref(k), N, Cc, HW,
@@ -167,11 +177,14 @@ class SpacedDiffusion:
     # ------------------------------------------------------------------ reference surface
     def p_sample_guidance(self, model, x, t, noise=None, variance=None, variance_noise=None, clip_denoised=True,
                           denoised_fn=None, cond_fn=None, model_kwargs=None, feat_layer=-1, keep_for_backward=False,
-                          want_inter_feat=True, between=None):
+                          want_inter_feat=True, between=None, overlap=True, guided_scale=None):
         """gaussian_diffusion.py:446-510.  Returns the same dict keys.
         `between`: a callable run after the model call and before the step arithmetic -- the drag loop passes its loss +
-        backward here; the model then runs the part of the network those do not need (everything after the tap) beside
-        them, and the step arithmetic waits for it.  Results are identical with and without it."""
+        backward here; with `overlap` the model then runs the part of the network those do not need (everything after the tap)
+        beside them, and the step arithmetic waits for it.  Results are identical with and without it.
+        `guided_scale` (with a `between` that returns d loss / d x): the drag loop's update `sample + variance * scale * grad`
+        (drag_utils.py:384-392) is formed by the step kernel itself and returned as "guided" -- one launch instead of two, the
+        intermediate sample / variance tensors are not written."""
         assert denoised_fn is None and cond_fn is None, "not used on the path"
         ti = self._t_index(t)
         if torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled() and hasattr(model, "backward_from_output"):
@@ -182,13 +195,19 @@ class SpacedDiffusion:
         kw = dict(model_kwargs or {})
         if hasattr(model, "tap_ptr"):
             kw.update(keep_for_backward=keep_for_backward, want_inter_feat=want_inter_feat)
-            if between is not None and feat_layer >= 0 and hasattr(model, "join_tail"):
+            if between is not None and overlap and feat_layer >= 0 and hasattr(model, "join_tail"):
                 kw.update(overlap_tail=True)
         mo, inter = self._model(model, x, ti, feat_layer, **kw)
+        grad = None
         if between is not None:
-            between()
+            grad = between()
             if kw.get("overlap_tail"):
                 model.join_tail()
+        if guided_scale is not None and grad is not None and variance_noise is None:
+            noise = self._prep(noise if noise is not None else torch.randn_like(x))
+            vin = None if variance is None else self._prep(variance)
+            o = self._step(x, mo, ti, noise, vin, clip_denoised, 0, (), guide=(grad, float(guided_scale)))
+            return {"guided": o["guided"], "inter_feat": inter, "noise": noise}
         if variance_noise is not None:
             o = self._step(x, mo, ti, self._prep(variance_noise), None, clip_denoised, 2, ("sample", "variance"))
             return {"sample": o["sample"], "inter_feat": inter, "variance": o["variance"]}

@@ -4,7 +4,7 @@ igemm4_kernel<128,128,64|32|16,...>, csrc/igemm4.hip).  At batch 1 the tile poli
   * against the ORACLE: a mid-size configuration whose 64^2 / 32^2 / 16^2 levels all have >= 128 channels, run in a process
     of its own with ISHAP_BIG_MIN=1 (the policy threshold is read once per process) -- forward output, every output-block
     tap, input gradients from a tap and from the output; the launch profile proves that the three kernels ran;
-  * at FULL SIZE: batch 8 (where the default policy selects them on the 32^2 / 16^2 / 64^2 maps) against the same eight images
+  * at FULL SIZE: batch 8 (where the default policy selects them on the 64^2 and 32^2 maps) against the same eight images
     pushed through one at a time -- same arithmetic, another tile shape and split-K policy, i.e. summation order only.
 Needs an MI355X: -m gpu.  Nothing here reads /root/reference."""
 import os
@@ -122,7 +122,7 @@ def test_wide_tiles_on_narrow_maps_vs_oracle(tmp_path):
 def test_full_size_batch_8_equals_eight_single_images():
     """generate.py's default batch (generate.py:52) through the full 421 M-parameter model: one batch-8 forward against the same
     eight (image, timestep) pairs one at a time through the same context.  The batch-8 launch profile must contain 128x128
-    tiles on maps below 128 pixels (M = 8 * 4096 / 8 * 1024 / 8 * 256), which no batch-1 launch selects.  Same products,
+    tiles on maps below 128 pixels (M = 8 * 4096 and 8 * 1024: the 64- and 32-wide maps), which no batch-1 launch selects.  Same products,
     another tile shape / split-K policy: relative L2 <= 2e-3 per image (the igemm2-vs-igemm4 bound of
     test_gpu_fullsize.py); the batch-1 results themselves are pinned to the oracle by C1."""
     import ctypes as C
@@ -138,7 +138,7 @@ def test_full_size_batch_8_equals_eight_single_images():
     ts = [999.0, 870.0, 641.0, 500.0, 333.0, 120.0, 37.0, 0.0]
     L = _lib.lib()
     L.ishap_profile_begin()
-    out8 = m(x, ts, feat_layer=-1)[0].clone()
+    out8 = m(x, ts, feat_layer=-1).clone()
     torch.cuda.synchronize()
     buf = C.create_string_buffer(1 << 20)
     assert L.ishap_profile_shapes(buf, len(buf)) > 0
@@ -146,11 +146,11 @@ def test_full_size_batch_8_equals_eight_single_images():
     L.ishap_profile_end(tot, 16)
     lines = [l.split(",") for l in buf.value.decode().strip().split("\n")]
     big3 = {int(l[0]) for l in lines if int(l[3]) == 1 and int(l[4]) == 128}
-    assert {8 * 4096, 8 * 1024, 8 * 256} <= big3, big3
+    assert {8 * 4096, 8 * 1024} <= big3, big3          # (the 16-wide maps take them from batch 16 on: 16 x 6 tiles at batch 8 < 192; oracle test above)
     assert bool(torch.isfinite(out8).all())
     worst = 0.0
     for b in range(8):
-        o1 = m(x[b:b + 1], ts[b:b + 1], feat_layer=-1)[0]
+        o1 = m(x[b:b + 1], ts[b:b + 1], feat_layer=-1)
         r = rel(out8[b:b + 1], o1)
         worst = max(worst, r)
         assert r < 2e-3, (b, r)

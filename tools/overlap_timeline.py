@@ -1,8 +1,9 @@
 """From a rocprofv3 kernel_trace.csv of a run with the overlapped forward tail (ISHAP_OVERLAP_TAIL=1): per guided step, the
 window in which the side queue (the tail) runs, what the caller's queue (loss + backward) does inside it, and -- per
 kernel symbol -- duration and gap-before INSIDE the window against the same symbol OUTSIDE any window (same run), i.e.
-which kernels of the backward chain waited and for how long.  Usage: overlap_timeline.py kernel_trace.csv [baseline.csv]
-With a second trace (the plain sequence on the same box) the per-symbol baseline comes from that file instead."""
+which kernels of the backward chain waited and for how long.  Usage: overlap_timeline.py kernel_trace.csv [baseline.csv] [--list]
+With a second trace (the plain sequence on the same box) the per-symbol baseline comes from that file instead.
+--list: the launches of both queues around the median window, start times relative to the window's start."""
 import collections
 import csv
 import re
@@ -25,6 +26,8 @@ def short(name):
     return (m.group(1) if m else name)[:60]
 
 
+LIST = "--list" in sys.argv
+sys.argv = [a for a in sys.argv if a != "--list"]
 rows = load(sys.argv[1])
 qcount = collections.Counter(r[3] for r in rows)
 main_q = qcount.most_common(1)[0][0]
@@ -105,3 +108,11 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     base = outside.get(k)
     bs = f"{statistics.mean(x[0] for x in base) / 1e3:8.2f}" if base else "     n/a"
     print(f"  {k:60s} n/window {len(v) / len(bursts):5.1f}  avg {statistics.mean(v) / 1e3:8.2f} us   (plain sequence: {bs})")
+
+if LIST:
+    order = sorted(range(len(windows)), key=lambda i: windows[i][1] - windows[i][0])
+    w0, w1 = windows[order[len(order) // 2]]
+    print(f"launches from 150 us before the median window to 300 us after it (window = [0, {(w1 - w0) / 1e3:.0f}] us):")
+    for s_, e_, name, q in rows:
+        if w0 - 150_000 <= s_ <= w1 + 300_000:
+            print(f"  {'main' if q == main_q else 'SIDE'} {(s_ - w0) / 1e3:9.1f} +{(e_ - s_) / 1e3:7.1f}  {short(name)}")

@@ -19,7 +19,7 @@ for cfg in "$@"; do
   for kv in $cfg; do export "$kv"; done
   f=$(trace $n) || exit 1
   python3 $R/tools/overlap_check.py $f > $O/$n.txt
-  python3 $R/tools/overlap_timeline.py $f $fp >> $O/$n.txt
+  python3 $R/tools/overlap_timeline.py $f $fp --list >> $O/$n.txt
   python3 -c "import json;print('s/shape under the tracer:', json.load(open('$O/$n.json'))['value'])" >> $O/$n.txt
   for kv in $cfg; do unset "${kv%%=*}"; done
   unset ISHAP_OVERLAP_TAIL
