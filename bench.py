@@ -491,9 +491,14 @@ def main():
     roofline = None
     if rank == 0:
         L = _lib.lib()
+        # per-launch durations are measured in the PLAIN launch sequence: in the timed (default) configuration the forward tail
+        # shares the chip with loss + backward, and a launch's duration inside that window is not the kernel's own
+        from ishapediting_amd import drag_utils as _du
+        _ov, _du._OVERLAP_TAIL = _du._OVERLAP_TAIL, False
         L.ishap_profile_begin()
         one_edit(ds, src, tgt)
         torch.cuda.synchronize()
+        _du._OVERLAP_TAIL = _ov
         NV = 13
         out = (C.c_double * (NV * 3))()
         L.ishap_profile_end(out, NV)
@@ -533,26 +538,51 @@ def main():
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM-side bytes per launch of that kernel from the committed PMC passes (profiles/pmc_traffic.json, produced by
         # tools/pmc_only.sh + tools/pmc_summary.py: counters cannot be collected from inside this process)
-        traffic = None
-        traffic_source = None
+        pj = None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            import re as _re
-            pat = _re.compile("^" + _re.escape(names[v]).replace("\\*", "[0-9]+") + "$")
-            ks = [k for key, k in pj["kernels"].items() if pat.match(key) and (key == names[v] or key not in names)]   # a '*' stands for the map-width template argument
-            nd = sum(k["FETCH_SIZE"]["dispatches"] for k in ks)
-            traffic = int(sum((k["FETCH_SIZE"]["bytes_per_launch"] + k["WRITE_SIZE"]["bytes_per_launch"]) * k["FETCH_SIZE"]["dispatches"] for k in ks) / nd)
-            traffic_source = ("committed profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                              "tools/pmc_step.py (" + str(pj.get("source", "tools/pmc_only.sh")) + "), FETCH_SIZE doubled per "
-                              "MI355X_MICROARCH.md; not collected live (counters cannot be read from inside this process)")
-        except (OSError, KeyError, ValueError, ZeroDivisionError):
+        except (OSError, ValueError):
             pass
+
+        def counters(name):
+            """HBM-side bytes per launch and MFMA-busy share of one entry of `names` from the committed counter passes
+            (profiles/pmc_traffic.json: tools/final_profile.sh writes it from the same run as the round's pmc_*.txt files)"""
+            if pj is None:
+                return None, None
+            import re as _re
+            try:
+                pat = _re.compile("^" + _re.escape(name).replace("\\*", "[0-9]+") + "$")
+                ks = [k for key, k in pj["kernels"].items() if pat.match(key) and (key == name or key not in names)]   # a '*' stands for a template argument
+                nd = sum(k["FETCH_SIZE"]["dispatches"] for k in ks)
+                byt = int(sum((k["FETCH_SIZE"]["bytes_per_launch"] + k["WRITE_SIZE"]["bytes_per_launch"]) * k["FETCH_SIZE"]["dispatches"] for k in ks) / nd)
+                mf = [k["mfma_util_pct"] * k["FETCH_SIZE"]["dispatches"] for k in ks if "mfma_util_pct" in k]
+                return byt, (round(sum(mf) / nd / 100.0, 4) if len(mf) == len(ks) else None)
+            except (KeyError, ValueError, ZeroDivisionError):
+                return None, None
+        traffic, mfma_busy = counters(names[v])
+        traffic_source = None if traffic is None else (
+            "committed profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / MFMA passes of tools/pmc_step.py ("
+            + str(pj.get("source", "tools/final_profile.sh")) + "); not collected live (counters cannot be read from inside this process)")
+        # the single kernel SYMBOL with the most time (the dominant entry above may be a group of symbols that differ only in the
+        # map width / ring depth template arguments)
+        single = [i for i in range(NV) if "*" not in names[i]]
+        t1 = max(single, key=lambda i: out[i * 3 + 1])
+        t1_tf = out[t1 * 3 + 2] / max(out[t1 * 3 + 1], 1e-9) / 1e9
+        t1_traffic, t1_busy = counters(names[t1])
+        top_single = {"kernel": names[t1], "achieved": round(t1_tf, 1), "frac": round(t1_tf / PEAK_MFMA_F16_TFLOPS, 4),
+                      "launches_per_edit": int(out[t1 * 3]), "avg_launch_us": round(out[t1 * 3 + 1] * 1e3 / max(out[t1 * 3], 1), 2),
+                      "share_of_edit_time": round(out[t1 * 3 + 1] * 1e-3 / sec_per_shape, 3) if world == 1 else None,
+                      "traffic": t1_traffic, "mfma_busy": t1_busy}
         roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                    "mfma_busy": mfma_busy,
                     "kernel": names[v],
+                    "measured_in": "plain launch sequence (ISHAP_OVERLAP_TAIL=0) with HIP events attached to every implicit-GEMM dispatch; "
+                                   "the timed region runs the forward tail beside loss + backward",
                     "launches_per_edit": int(launches), "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
                     "flops_per_launch_avg": flops / max(launches, 1),
                     "share_of_edit_time": round(ms * 1e-3 / sec_per_shape / max(world, 1), 3) if world == 1 else None,
+                    "top_single_symbol": top_single,
                     "all_variants": {names[i]: {"launches": int(out[i * 3]), "ms": round(out[i * 3 + 1], 3),
                                                 "tflops": round(out[i * 3 + 2] / max(out[i * 3 + 1], 1e-9) / 1e9, 1)}
                                      for i in range(NV)}}

@@ -109,10 +109,20 @@ __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, co
     // hbase (round 5): a launch may cover only tiles [hbase, hbase + grid) of the layer -- the overlapped forward tail runs a
     // layer as several one-dimensional launches of at most ISHAP_TAIL_WGS tiles, so that it never holds the LDS of more compute
     // units than that and the backward chain on the caller's stream keeps the rest (launch4)
-    const int lin = hbase + blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    // bit 30 of hbase: the tile order WITHIN an XCD's share.  0: n-tiles fastest (an XCD holds few m-tiles x all weight panels:
+    // right when the activations dominate, the 64^2 / 128^2 maps); 1: m-tiles fastest, then K slices, n-tiles slowest (an XCD
+    // holds ONE or two weight panels x every m-tile and slice: right on the 32^2 / 16^2 maps, where the weights are most of the
+    // bytes and every XCD used to pull all of them: 29.4 MB fetched per 32^2 launch for 5.7 MB of operands, round 4 PMC pass)
+    const bool n_outer = (hbase >> 30) & 1;
+    const int lin = (hbase & 0x3fffffff) + blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
     const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, pos = lin >> 3;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-    if (h.ny_shift() >= 0) {
+    if (n_outer) {                                   // launcher: only with power-of-two nx
+      tile_m = swz & (nx - 1);
+      const int rest = swz >> h.nx_shift();
+      tile_n = rest / h.ksplit;
+      tile_z = rest - tile_n * h.ksplit;
+    } else if (h.ny_shift() >= 0) {
       tile_n = swz & (ny - 1);
       tile_m = (swz >> h.ny_shift()) & (nx - 1);
       tile_z = swz >> (h.ny_shift() + h.nx_shift());
@@ -514,18 +524,38 @@ static int launch4(const IgemmArgs& a, hipStream_t s) {
              (unsigned)(b.ny_shift & 0x3f) << 18 | (b.ups ? 1u << 24 : 0u) | (unsigned)(b.K2 / 64) << 25;
   // chunked form (IgemmArgs::chunk_tiles > 0, a multiple of 8 so that a tile keeps the `lin & 7` = XCD of the remap): the layer as
   // ceil(tiles / chunk) launches of at most `chunk` tiles each, back to back on the stream
+  // tile order within an XCD's share (kernel: bit 30 of hbase).  Bytes an XCD's L2 has to pull under each order, from the tiles it
+  // is dealt (q = tiles / 8 consecutive ids): a weight panel per distinct (n-tile, K slice), an activation slab per distinct
+  // (m-tile, K slice); neighbouring m-tiles share their halo rows inside one L2.  ISHAP_IG4_NOUTER=0 / 1 forces an order.
+  int n_outer = 0;
+  if (b.nx_shift >= 0) {
+    static const int force = [] { const char* e = getenv("ISHAP_IG4_NOUTER"); return e ? atoi(e) : 2; }();
+    const int nx = (int)grid.x, ny = (int)grid.y, nz = (int)grid.z;
+    const int q = (h.nwg + 7) / 8;
+    const double wp = (double)BN * (b.K / (double)nz) * 2.0;                 // one weight panel of one slice
+    const double xs = (double)BM * b.Cin * 2.0 / nz + (b.K2 ? (double)BM * b.K2 * 2.0 / nz : 0.0);   // one tile's pixels, one slice's channels
+    auto cdiv = [](int a, int d) { return (a + d - 1) / d; };
+    // order 0: n fastest, then m, then z
+    const int nA = ny < q ? ny : q, mzA = cdiv(q, ny), mA = nx < mzA ? nx : mzA, zA = cdiv(mzA, nx);
+    const double costA = (double)nA * zA * wp + (double)mA * zA * xs;
+    // order 1: m fastest, then z, then n
+    const int mB = nx < q ? nx : q, znB = cdiv(q, nx), zB = nz < znB ? nz : znB;
+    const double costB = (double)znB * wp + (double)mB * zB * xs;
+    n_outer = force == 2 ? (costB < 0.8 * costA) : force;
+  }
+  const int order_bit = n_outer ? (1 << 30) : 0;
   const int tiles = h.nwg;
   const bool chunked = a.chunk_tiles > 0 && a.chunk_tiles % 8 == 0 && tiles > a.chunk_tiles && b.nx_shift >= 0 && !g_igemm_prof_start;
   if (chunked) {
     for (int base = 0; base < tiles; base += a.chunk_tiles) {
       const int n = tiles - base < a.chunk_tiles ? tiles - base : a.chunk_tiles;
       hipLaunchKernelGGL(kern, dim3(n), dim3(512 * HALVES), smem, s,
-                         (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, base, b);
+                         (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, base | order_bit, b);
     }
   } else if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(512 * HALVES), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0,
-                                                (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, 0, b);
+                                                (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, order_bit, b);
   else hipLaunchKernelGGL(kern, grid, dim3(512 * HALVES), smem, s,
-                          (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, 0, b);
+                          (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, order_bit, b);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -234,10 +234,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(int h_main_blocks, int h_
       if (a.xpool) *reinterpret_cast<half8*>(a.xpool + (long long)pix * h_C + c0) = xv;
     }
   } else {
-    // Round 5: a thread's pixels are fetched U at a time BEFORE any of them is processed.  With one 16-byte load per wave in
-    // flight (the old loop) a CU held 16 KB of loads and the 128^2 maps streamed at 1.9 TB/s -- Little's law on a ~2 us
-    // round trip, not an HBM limit (MI355X_MICROARCH.md: ~32 KB in flight per CU for streaming rates).
-    constexpr int U = 4;
+    // Round 5: a thread's pixels are fetched U at a time BEFORE any of them is processed (one 16-byte load per wave in flight in
+    // the old loop).  Measured (profiles/round5_ab_gn_inflight.txt): 8.99 -> 8.64 us (plain + SiLU, 128^2 x 256) and 7.32 -> 6.62
+    // (FiLM variant) -- a few per cent, not the 2x a bytes-in-flight limit would have given: the launch is a chain of ~2 us phases
+    // (sums -> finalise -> barrier -> loads -> stores), not a stream.
+#ifndef GN_APPLY_U
+#define GN_APPLY_U 4
+#endif
+    constexpr int U = SPLIT ? 1 : GN_APPLY_U;      // the head's variant writes three vectors per pixel: batching it doubled its time (8.8 -> 15.8 us)
     for (int pix0 = tg / CV; pix0 < npix; pix0 += U * pstep) {
       half8 v[U];
 #pragma unroll

@@ -125,9 +125,12 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const long long* h_cs
 #pragma unroll
   for (int i = 0; i < 8; ++i) { gam[i] = a.gamma[c0 + i]; bet[i] = (FILM || ACT) ? a.beta[c0 + i] : 0.f; esc[i] = 0.f; esh[i] = 0.f; }
   int cur_n = -1;
-  // Round 5: the operands of U pixels are fetched before the first of them is processed (2U-4U loads per wave in flight instead
-  // of 2-4: these passes stream the 128^2 / 64^2 maps, and a CU's bytes in flight set the rate -- see gn_apply_kernel, norm.hip)
-  constexpr int U = 2;
+  // (round 5: the loop can fetch the operands of U pixels before it processes the first -- see gn_apply_kernel, norm.hip; here a
+  // pixel already has 2-4 loads in flight and U = 2 was slower)
+#ifndef GN_BWD_U
+#define GN_BWD_U 1      // measured: 2 pixels per batch 8.93 -> 9.47 us (170-188 registers), not kept (profiles/round5_ab_gn_inflight.txt)
+#endif
+  constexpr int U = GN_BWD_U;
   for (int pix0 = tg / CV; pix0 < npix; pix0 += U * pstep) {
     float up[U][8], ad[U][8];
     half8 xv[U], a2[U];

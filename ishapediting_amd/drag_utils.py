@@ -91,6 +91,7 @@ def resize_feat_align(feature, cat_var=True):
     return feature[0][cm.reshape(-1)].reshape(3, -1, feature.shape[2], feature.shape[3]).type(th.float32)
 
 
+_FUSED_UPDATE = os.environ.get("ISHAP_FUSED_UPDATE", "1") == "1"     # guided update inside the DDPM step kernel (0: two launches, for A/B)
 _OVERLAP_TAIL = os.environ.get("ISHAP_OVERLAP_TAIL", "1") == "1"      # round 5: on by default (see training())
 
 
@@ -368,8 +369,15 @@ class DragStuff:
             outs = self.diffusion.p_sample_guidance(self.model, img, i, feat_layer=self.args.feat_layer,
                                                     keep_for_backward=True, want_inter_feat=False,
                                                     noise=self._noise(i, img), between=loss_and_backward, overlap=_OVERLAP_TAIL,
-                                                    guided_scale=float(scale))
-            img = outs["guided"]
+                                                    guided_scale=float(scale) if _FUSED_UPDATE else None)
+            if _FUSED_UPDATE:
+                img = outs["guided"]
+            else:
+                new = th.empty_like(img)
+                with th.cuda.device(self.device):
+                    _lib.check(L.ishap_guided_update(outs["sample"].data_ptr(), outs["variance"].data_ptr(), got["grad"].data_ptr(),
+                                                     float(scale), None, img.numel(), new.data_ptr(), _lib.stream_ptr(self.device)))
+                img = new
             self.last_losses.append(losses[i:i + 1])
             yield 1 - i / (self.args.w_time - 1.)
         self.mesh = self.get_mesh(img=img, t=stop_time)

@@ -6,6 +6,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/ab
 mkdir -p $O
 cd $R
+cp ishapediting_amd/libishap_hip.so $O/lib_installed.so            # restored at the end: a variant must not stay installed
+trap 'cp $O/lib_installed.so $R/ishapediting_amd/libishap_hip.so' EXIT
 for round in 1 2; do
   for lib in "$@"; do
     cp $lib ishapediting_amd/libishap_hip.so

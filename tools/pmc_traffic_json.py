@@ -1,16 +1,23 @@
-"""profiles/pmc_traffic.json from the two pmc_summary.py outputs (FETCH_SIZE and WRITE_SIZE passes): bytes per launch per
-kernel symbol, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  Usage: pmc_traffic_json.py FETCH.txt WRITE.txt out.json"""
+"""profiles/pmc_traffic.json from the pmc_summary.py outputs of the FETCH_SIZE and WRITE_SIZE passes (bytes per launch per kernel
+symbol, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and, when given, the pmc_mfma_summary.py output of the
+MFMA pass (mfma_util_pct per symbol).  tools/final_profile.sh writes it from the SAME run as the round's pmc_*.txt files.
+Usage: pmc_traffic_json.py FETCH.txt WRITE.txt out.json [MFMA.txt]"""
 import json
 import re
 import sys
 
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_only.sh) over tools/pmc_step.py; FETCH_SIZE "
-                 "doubled (gfx950 counts 128-B requests of wide reads at 64 B, MI355X_MICROARCH.md HBM section); bytes per launch, "
-                 "mean over dispatches", "kernels": {}}
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES ... (separate passes, tools/final_profile.sh) over "
+                 "tools/pmc_step.py in the plain launch sequence (ISHAP_OVERLAP_TAIL=0); FETCH_SIZE doubled (gfx950 counts 128-B requests of "
+                 "wide reads at 64 B, MI355X_MICROARCH.md HBM section); bytes per launch, mean over dispatches", "kernels": {}}
 for path in sys.argv[1:3]:
     for line in open(path):
         m = re.match(r"(.+?)\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*(\d+)\s+mean=\s*([\d.]+) KiB\s+bytes_corrected=\s*(\d+)", line)
         if m:
             out["kernels"].setdefault(m.group(1).strip(), {})[m.group(2)] = {"dispatches": int(m.group(3)), "bytes_per_launch": int(m.group(5))}
+if len(sys.argv) > 4:
+    for line in open(sys.argv[4]):
+        m = re.match(r"(.+?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
+        if m and m.group(1).strip() in out["kernels"]:
+            out["kernels"][m.group(1).strip()]["mfma_util_pct"] = float(m.group(3))
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(f"{len(out['kernels'])} kernels -> {sys.argv[3]}")
