@@ -69,7 +69,8 @@ int gn_backward_launch(const GnBwdArgs& a, hipStream_t s);
 // (image, group) -- H*W pixels x C/32 channels, staged in LDS -- so statistics, normalisation, FiLM, SiLU, pooling and
 // (backward) the group means are ONE launch with no atomics, and the input may be a pending split-K result (SlabSrc).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int GN_REC_STRIDE = 32;     // 8-byte granules per (image, group) in the rendezvous record
+constexpr int GN_REC_HALF = 32;       // granules of one copy of a group's record (up to 8 parts x 4 granules)
+constexpr int GN_REC_STRIDE = 64;     // 8-byte granules per (image, group): the agent-scope copy, then the XCD-local copy (norm_local.hip)
 constexpr int GN_REC_PER_PART = 4;    // (hi, lo) fp32 pair for each of a part's two sums: up to 8 parts
 constexpr int GN_SPIN_LIMIT = 1 << 22; // polls before a rendezvous gives up (an error, see ISHAP_DEV_GN_RENDEZVOUS)
 

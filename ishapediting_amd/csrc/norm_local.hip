@@ -160,8 +160,21 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
 // rec = [parts][4] granules, zeroed before the launch (tag 0 = not yet written).  The launcher only uses parts > 1 when the
 // whole grid is resident at once; the spin is bounded all the same, and a give-up is an ERROR: it raises the process-wide
 // device status word (common.h) and poisons this group's sums with NaN, so nothing downstream looks plausible.
+// Round 5, XCD-local copy (GN_XCD_LOCAL): the launcher deals the parts of one (image, group) to workgroups with equal
+// `linear id & 7`, which the hardware places on ONE XCD (observed round-robin placement: speed only, never relied on for
+// correctness).  Every granule is then stored TWICE: with a plain store into the record's second half -- it stays in that XCD's
+// L2, where the other parts' L1-bypassing polls find it after an L2 round trip (~200 cycles) instead of a trip to the memory side
+// (~550-900) -- and with the agent-scope store as before.  A poller checks the local copy `GN_LOCAL_POLLS` times per look at the
+// agent-scope copy, so a placement that is NOT co-located (or an L2 that does not show the plain store) costs time, never
+// correctness: the agent-scope path is complete by itself.
+#ifndef GN_XCD_LOCAL
+#define GN_XCD_LOCAL 1
+#endif
+#ifndef GN_LOCAL_POLLS
+#define GN_LOCAL_POLLS 4
+#endif
 __device__ __forceinline__ void group_rendezvous(double& a, double& b, unsigned long long* rec, int part, int parts,
-                                                 double* scratch, unsigned* status, int spin_limit) {
+                                                 double* scratch, unsigned* status, int spin_limit, bool xcd_local) {
   if (parts <= 1) return;
   __syncthreads();
   if (threadIdx.x < GN_REC_PER_PART) {
@@ -169,14 +182,23 @@ __device__ __forceinline__ void group_rendezvous(double& a, double& b, unsigned 
     const float hi = (float)d;
     const float v = (threadIdx.x & 1) ? (float)(d - (double)hi) : hi;
     const unsigned long long granule = (unsigned long long)__float_as_uint(v) | (1ull << 32);
+    if (GN_XCD_LOCAL && xcd_local) rec[GN_REC_HALF + part * GN_REC_PER_PART + threadIdx.x] = granule;      // plain: stays in this XCD's L2
     __hip_atomic_store(rec + part * GN_REC_PER_PART + threadIdx.x, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if ((int)threadIdx.x < GN_REC_PER_PART * parts) {
     unsigned long long gr = 0;
     int spins = 0;
-    do {
-      gr = __hip_atomic_load(rec + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } while ((gr >> 32) == 0ull && ++spins < spin_limit);
+    if (GN_XCD_LOCAL && xcd_local) {
+      int k = 0;                         // polls GN_LOCAL_POLLS times at the local copy (sc1: past L1, served by L2), then once at the agent-scope one
+      do {
+        gr = __hip_atomic_load(rec + (k < GN_LOCAL_POLLS ? GN_REC_HALF : 0) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        k = k == GN_LOCAL_POLLS ? 0 : k + 1;
+      } while ((gr >> 32) == 0ull && ++spins < spin_limit);
+    } else {
+      do {
+        gr = __hip_atomic_load(rec + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } while ((gr >> 32) == 0ull && ++spins < spin_limit);
+    }
     double v = (double)__uint_as_float((unsigned)(gr & 0xffffffffull));
     if ((gr >> 32) == 0ull) {          // a part never arrived: the grid was not co-resident (or a part faulted)
       __hip_atomic_store(status, (unsigned)ISHAP_DEV_GN_RENDEZVOUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -195,22 +217,44 @@ __device__ __forceinline__ void group_rendezvous(double& a, double& b, unsigned 
   __syncthreads();
 }
 
+// workgroup -> (group, part).  xcd_local: the parts of a group get linear ids 8 apart (equal `id & 7` = one XCD under round-robin
+// placement; the image index blockIdx.y adds a multiple of 32 * parts, itself a multiple of 8); else parts are consecutive ids
+__device__ __forceinline__ void group_of_block(int parts, bool xcd_local, int& g, int& part) {
+  if (xcd_local) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    part = j % parts;
+    g = (j / parts) * 8 + xcd;
+  } else {
+    g = blockIdx.x / parts;
+    part = blockIdx.x - g * parts;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int VEC, bool FILM, bool ACT, bool POOL>
 __global__ __launch_bounds__(1024) void gn_local_kernel(int h_parts, int h_C, int h_HW, int h_Ca, GnLocalArgs a) {
   // h_*: copies of a.parts, a.C, a.H * a.W, a.Ca as leading scalar parameters -- preloaded into SGPRs at dispatch (common.h,
   // IgemmHot), so that the index arithmetic (three integer divisions) runs UNDER the s_load of the argument block, not after it
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if ((int)blockIdx.x >= 32 * h_parts) {           // prefetch workgroups (last in the grid: the GroupNorm ones are dispatched first)
-    const int npf = gridDim.x - 32 * h_parts;
-    prefetch_block(a.pf, (blockIdx.x - 32 * h_parts) + npf * blockIdx.y, npf * gridDim.y);
+  if ((int)blockIdx.x >= 32 * (h_parts < 0 ? (-h_parts & 63) : h_parts)) {           // prefetch workgroups (last in the grid: the GroupNorm ones are dispatched first)
+    const int nmain = 32 * (h_parts < 0 ? (-h_parts & 63) : h_parts), npf = gridDim.x - nmain;
+    prefetch_block(a.pf, (blockIdx.x - nmain) + npf * blockIdx.y, npf * gridDim.y);
     return;
   }
   double* scratch = reinterpret_cast<double*>(smem_raw);                 // 32 doubles (block_sum2: 2 x 16; rendezvous: 4 x parts)
   half_t* st = reinterpret_cast<half_t*>(smem_raw + 256);                // [HW][cpg]
-  const int g = blockIdx.x / h_parts, part = blockIdx.x - g * h_parts, n = blockIdx.y;
+  const bool xcd_local = h_parts < 0;                                    // the launcher passes -(parts [+ 64]) for the XCD-local dealing
+  const int parts = xcd_local ? (-h_parts & 63) : h_parts;
+  int g, part;
+  group_of_block(parts, xcd_local, g, part);
+  const int n = blockIdx.y;
+  // +64: touch the local copy of this group's record now -- its lines are then resident in this XCD's L2 when the parts' plain
+  // stores and polls arrive (the first poll otherwise waits for the line's fill from the memory side, ~1 us)
+  unsigned long long warm = 0;
+  if (xcd_local && (-h_parts & 64) && (int)threadIdx.x < GN_REC_PER_PART * parts)
+    warm = __hip_atomic_load(a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE + GN_REC_HALF + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int C = h_C, cpg = C / 32, VPP = cpg / VEC, HW = h_HW;
-  const int PP = HW / h_parts, p0 = part * PP;                           // this workgroup's pixels [p0, p0 + PP)
+  const int PP = HW / parts, p0 = part * PP;                             // this workgroup's pixels [p0, p0 + PP)
   const int nunits = PP * VPP, c0g = g * cpg;
   const int Cb = C - h_Ca;
   GN_STAMP(0);
@@ -285,7 +329,8 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(int h_parts, int h_C, in
   GN_STAMP(1);
   block_sum2(s, q, scratch);
   GN_STAMP(2);
-  group_rendezvous(s, q, a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE, part, a.parts, scratch, a.status, a.spin_limit);
+  group_rendezvous(s, q, a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE, part, parts, scratch, a.status, a.spin_limit, xcd_local);
+  asm volatile("" ::"v"(warm));
   GN_STAMP(3);
   const double cnt = (double)HW * (double)cpg;
   const double md = s / cnt;
@@ -395,17 +440,24 @@ template <int VEC, bool FILM, bool ACT, bool STAGE32>
 __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(int h_parts, int h_C, int h_HW, GnBwdLocalArgs a) {
   // h_*: preloaded copies of a.parts, a.C, a.H * a.W (see gn_local_kernel)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if ((int)blockIdx.x >= 32 * h_parts) {
-    const int npf = gridDim.x - 32 * h_parts;
-    prefetch_block(a.pf, (blockIdx.x - 32 * h_parts) + npf * blockIdx.y, npf * gridDim.y);
+  if ((int)blockIdx.x >= 32 * (h_parts < 0 ? (-h_parts & 63) : h_parts)) {
+    const int nmain = 32 * (h_parts < 0 ? (-h_parts & 63) : h_parts), npf = gridDim.x - nmain;
+    prefetch_block(a.pf, (blockIdx.x - nmain) + npf * blockIdx.y, npf * gridDim.y);
     return;
   }
   double* scratch = reinterpret_cast<double*>(smem_raw);
   half_t* st16 = reinterpret_cast<half_t*>(smem_raw + 256);
   float* st32 = reinterpret_cast<float*>(smem_raw + 256);
-  const int g = blockIdx.x / h_parts, part = blockIdx.x - g * h_parts, n = blockIdx.y;
+  const bool xcd_local = h_parts < 0;
+  const int parts = xcd_local ? (-h_parts & 63) : h_parts;
+  int g, part;
+  group_of_block(parts, xcd_local, g, part);
+  const int n = blockIdx.y;
+  unsigned long long warm = 0;           // see gn_local_kernel
+  if (xcd_local && (-h_parts & 64) && (int)threadIdx.x < GN_REC_PER_PART * parts)
+    warm = __hip_atomic_load(a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE + GN_REC_HALF + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int C = h_C, cpg = C / 32, VPP = cpg / VEC, HW = h_HW;
-  const int PP = HW / h_parts, p0 = part * PP;
+  const int PP = HW / parts, p0 = part * PP;
   const int nunits = PP * VPP, c0g = g * cpg;
   const float mu = a.stats[(n * 32 + g) * 2], rs = a.stats[(n * 32 + g) * 2 + 1];
   double s1 = 0.0, s2 = 0.0;
@@ -443,7 +495,8 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(int h_parts, int h_C
     if (a.add2) ld_half<VEC>(a.add2 + ((long long)n * HW + p) * C + c, f_a2);
   }
   block_sum2(s1, s2, scratch);
-  group_rendezvous(s1, s2, a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE, part, a.parts, scratch, a.status, a.spin_limit);
+  group_rendezvous(s1, s2, a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE, part, parts, scratch, a.status, a.spin_limit, xcd_local);
+  asm volatile("" ::"v"(warm));
   const double cnt = (double)HW * (double)cpg;
   const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt);
   __syncthreads();
@@ -523,7 +576,7 @@ int pick_parts(int N, int HW, int cpg, int unit, bool have_rec) {
   static const int env_wgs = [] { const char* e = getenv("ISHAP_GN_MAX_WGS"); return e ? atoi(e) : 0; }();
   int max_wgs = ishap_cu_count();
   if (env_wgs > 0 && env_wgs < max_wgs) max_wgs = env_wgs;
-  while (p * 2 <= maxp && p * 2 <= GN_REC_STRIDE / GN_REC_PER_PART && 32 * N * (p * 2) <= max_wgs && HW % (p * 2) == 0 &&
+  while (p * 2 <= maxp && p * 2 <= GN_REC_HALF / GN_REC_PER_PART && 32 * N * (p * 2) <= max_wgs && HW % (p * 2) == 0 &&
          (HW / (p * 2)) % unit == 0 && (long long)(HW / (p * 2)) * cpg >= min_el)
     p *= 2;
   return p;
@@ -540,6 +593,12 @@ int pf_blocks_for(const PrefetchHint& h, int threads, int N, size_t smem) {
 int spin_limit() {
   static const int v = [] { const char* e = getenv("ISHAP_GN_SPIN_LIMIT"); const int n = e ? atoi(e) : 0; return n > 0 ? n : GN_SPIN_LIMIT; }();
   return v;
+}
+
+// the parts of a group on one XCD (group_of_block) and the XCD-local copy of the record: ISHAP_GN_XCD=0 switches both off
+int xcd_deal(int parts) {          // 0: off; 1: XCD-local dealing + local copy; 2: also touch the local copy's lines at kernel start
+  static const int on = [] { const char* e = getenv("ISHAP_GN_XCD"); return e ? atoi(e) : 1; }();      // in situ: 1 and 2 both -0.4 % against 0, no difference between them (profiles/round5_ab_gn_xcd_local.txt)
+  return parts > 1 ? on : 0;
 }
 
 template <typename K>
@@ -579,7 +638,7 @@ int gn_local_launch(const GnLocalArgs& a, hipStream_t s) {
   do {                                                                                   \
     auto kern = gn_local_kernel<V, F, A, P>;                                             \
     ISHAP_TRY(set_lds(kern, smem));                                                      \
-    hipLaunchKernelGGL(kern, grid, blk, smem, s, b.parts, b.C, b.H * b.W, b.Ca, b);      \
+    hipLaunchKernelGGL(kern, grid, blk, smem, s, xcd_deal(b.parts) ? -(b.parts + (xcd_deal(b.parts) == 2 ? 64 : 0)) : b.parts, b.C, b.H * b.W, b.Ca, b);      \
   } while (0)
 #define GL_VARIANT(V)                                                                    \
   do {                                                                                   \
@@ -624,7 +683,7 @@ int gn_bwd_local_launch(const GnBwdLocalArgs& a, hipStream_t s) {
   do {                                                                                   \
     auto kern = gn_bwd_local_kernel<V, F, A, S32>;                                       \
     ISHAP_TRY(set_lds(kern, smem));                                                      \
-    hipLaunchKernelGGL(kern, grid, blk, smem, s, b.parts, b.C, b.H * b.W, b);            \
+    hipLaunchKernelGGL(kern, grid, blk, smem, s, xcd_deal(b.parts) ? -(b.parts + (xcd_deal(b.parts) == 2 ? 64 : 0)) : b.parts, b.C, b.H * b.W, b);            \
   } while (0)
 #define GB_VARIANT(V)                                                                    \
   do {                                                                                   \

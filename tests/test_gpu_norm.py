@@ -231,7 +231,9 @@ def test_rendezvous_give_up_raises_instead_of_using_zeros():
     error).  Forced here by one poll per wait (ISHAP_GN_SPIN_LIMIT=1, own process: the limit is read once): the launch
     poisons its output with NaN, the next status check fails with a message naming the rendezvous, and the word is cleared
     once reported."""
-    env = dict(os.environ, ISHAP_GN_SPIN_LIMIT="1")
+    # ISHAP_GN_XCD=0: the agent-scope copy of the record only -- with the XCD-local copy (round 5) the first poll waits for an L2
+    # fill and comes back with every part's granule, so one poll no longer fails; the give-up branch is the same code either way
+    env = dict(os.environ, ISHAP_GN_SPIN_LIMIT="1", ISHAP_GN_XCD="0")
     r = subprocess.run([sys.executable, "-c", _GIVE_UP % ROOT], env=env, capture_output=True, text=True, timeout=600)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
     assert line, r.stdout + r.stderr
