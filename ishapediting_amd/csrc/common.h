@@ -85,6 +85,23 @@ static inline int ishap_set_max_lds(const void* kern, int bytes) {
   return 0;
 }
 
+// 16-byte output store of a streaming kernel's result.  ISHAP_WT_STORES=1 (compile time): write-through (`sc1`), so that the bytes
+// leave for memory while the kernel runs instead of sitting dirty in the XCD's L2 until the end-of-kernel write-back (a
+// dependent boundary costs + B / 6 TB/s behind B dirty bytes, MI355X_MICROARCH.md price list, row `boundary`; the next kernel
+// reads them from the memory side either way: its L2 starts invalidated).
+#ifndef ISHAP_WT_STORES
+#define ISHAP_WT_STORES 0
+#endif
+#if defined(__HIPCC__)
+__device__ __forceinline__ void store_out16(half_t* p, const half8& v) {
+#if ISHAP_WT_STORES
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<half8*>(p) = v;
+#endif
+}
+#endif
+
 #define STAT_SCALE_SUM 16777216.f      /* 2^24 */
 #define STAT_SCALE_SQ 1048576.f        /* 2^20 */
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -158,7 +158,7 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
 #ifdef ABL_EPI_NOSTORE
       if (alpha == 12345.f)
 #endif
-      *reinterpret_cast<half8*>(out16 + (long long)(m0 + row) * a.ldo + n) = o;
+      store_out16(out16 + (long long)(m0 + row) * a.ldo + n, o);
       if (want_fwd) {
         *reinterpret_cast<half8*>(tileH + row * LDH + chunk * 8) = o;    // the statistics pass reads the stored values by column
       } else if (want_gb) {

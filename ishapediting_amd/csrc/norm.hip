@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(int h_main_blocks, int h_
           half8 ov;
 #pragma unroll
           for (int i = 0; i < 8; ++i) ov[i] = (half_t)o[i];
-          *reinterpret_cast<half8*>(a.out + (long long)pix * h_C + c0) = ov;
+          store_out16(a.out + (long long)pix * h_C + c0, ov);
         }
       }
     }
