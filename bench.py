@@ -214,7 +214,7 @@ def concurrent_edits_leg(device, ds, src, tgt, seed, reps=2):
     it: the headline is one edit per GPU, as the reference's DragStuff handles one shape at a time (drag_utils.py:303-304).
     The latency-bound chains fill each other's idle compute units (a guided step is 408 dependent launches, most of them
     far from filling 256 CUs); the library's rendezvous tenancy (include/ishap.h) lets one context at a time use the in-launch
-    GroupNorm rendezvous, the others run the same kernels with one workgroup per group.  tools/concurrent_probe.py: 1 / 2 / 3 / 4
+    GroupNorm rendezvous, the others run the same kernels with one workgroup per group.  tools/experiments/concurrent_probe.py: 1 / 2 / 3 / 4
     concurrent edits -> 0.1835 / 0.137 / 0.120 / 0.139 s per shape."""
     import threading
     from ishapediting_amd import synthetic

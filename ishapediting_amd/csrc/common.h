@@ -235,7 +235,7 @@ struct SlabSrc {
 
 // The arguments an LDS-DMA convolution kernel needs before it can issue its first load, as its FIRST kernel parameter: 14
 // dwords of plain scalars, which the build's -amdgpu-kernarg-preload-count=14 has the command processor place in SGPRs at
-// dispatch.  A kernel otherwise starts by waiting ~430 cycles (0.19 us, tools/kernarg_probe.hip) for the s_load of its
+// dispatch.  A kernel otherwise starts by waiting ~430 cycles (0.19 us, tools/experiments/kernarg_probe.hip) for the s_load of its
 // argument block; the rest of IgemmArgs (epilogue operands, second source, batch strides) arrives under the ring fill.
 struct IgemmHot {
   const half_t* X;

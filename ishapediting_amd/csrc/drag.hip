@@ -280,7 +280,7 @@ int drag_setup_launch(const DragArgs& a, hipStream_t s) {
 }
 
 // every workgroup of these passes ends with same-address atomics (loss sum, max|g|) that serialise at ~10 ns each:
-// few, fat workgroups (the loops are grid-stride).  Measured: tools/drag_probe.sh.
+// few, fat workgroups (the loops are grid-stride).  Measured: tools/experiments/drag_probe.sh.
 static int drag_terms_launch(const DragArgs& a, unsigned* bits, hipStream_t s) {
   static const int cap = [] { const char* e = getenv("ISHAP_DRAG_BLOCKS"); return e ? atoi(e) : 1024; }();
   const int side = 2 * a.r + 1;

@@ -403,7 +403,7 @@ int igemm_pick_ksplit(int M, int N, int K, int nbatch, bool pending) {
   long long blocks = (long long)(M / bm) * ceil_div(N, bn) * nbatch;
   int ks = K / 64;
   static const int nosplit = [] { const char* e = getenv("ISHAP_NOSPLIT_STEPS"); return e ? atoi(e) : 36; }();   // in situ: 36 beats 24 / 48 by ~0.5 %
-  static const int fill = [] { const char* e = getenv("ISHAP_SPLIT_FILL"); return e ? atoi(e) : 224; }();   // in-situ sweep (tools/sweep_split_policy.sh): plateau 208..256, 1 % better than 160
+  static const int fill = [] { const char* e = getenv("ISHAP_SPLIT_FILL"); return e ? atoi(e) : 224; }();   // in-situ sweep (tools/experiments/sweep_split_policy.sh): plateau 208..256, 1 % better than 160
   static const int minsteps = [] { const char* e = getenv("ISHAP_SPLIT_MINSTEPS"); return e ? atoi(e) : 6; }();
   // slices whose consumer adds them up cost no reduce launch: thresholds of their own (ISHAP_PEND_NOSPLIT / ISHAP_PEND_MINSTEPS)
   // in situ 12 / 3 against 36 / 6: 0.1783 -> 0.1777 s/shape (profiles/round4_env_ab_pending_split.txt)
@@ -430,7 +430,7 @@ int igemm_small3_launch(const IgemmArgs& a, int nt, hipStream_t s);
 int igemm_small3_slices(const IgemmArgs& a);
 bool igemm_small3_wanted(const IgemmArgs& a) {
   // 1: the 8x8 maps only (measured: on 16x16 / 32x32 maps every 16-channel tile re-stages its pixels and the tiled kernel
-  // wins, tools/s3_probe.sh), 2: every map up to 32x32, 0: off
+  // wins, tools/experiments/s3_probe.sh), 2: every map up to 32x32, 0: off
   static const int mode = [] { const char* e = getenv("ISHAP_SMALL3"); return e ? atoi(e) : 1; }();
   if (!mode || !a.conv3 || a.H * a.W > (mode == 2 ? 1024 : 64)) return false;
   if (a.defer_reduce && a.ksplit > 1 && igemm4_small_map_slices(a) == a.ksplit && igemm4_wanted(a, false)) return false;   // conv_op chose igemm4's sliced launch

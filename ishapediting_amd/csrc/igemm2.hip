@@ -257,7 +257,7 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
     // MFMA waves.  A K-step is two 32-deep halves; the fragments of the second half are read while the MFMAs of the
     // first run, and the first half of step k+1 is read (right after that step's barrier) under the MFMAs of the second
     // half of step k: the matrix pipe never waits for an LDS round trip (the straightforward loop -- read, wait, 16
-    // MFMAs, read, wait ... -- spent 1170 cycles per step on 512 cycles of MFMA work, tools/fixed_cost_probe2.sh).
+    // MFMAs, read, wait ... -- spent 1170 cycles per step on 512 cycles of MFMA work, tools/experiments/fixed_cost_probe2.sh).
     // All fragment reads of step k have returned (lgkmcnt(0)) before this wave enters barrier k+1, after which the
     // loaders may overwrite that ring slot.
     // The reads are inline asm with hand-counted s_waitcnt lgkmcnt: hipcc's own counting falls back to lgkmcnt(0) for
@@ -310,7 +310,7 @@ __global__ __launch_bounds__((256 + 64 * IG2_LOADERS) * HALVES) void igemm2_kern
       for (int j = 0; j < MT; ++j) acc[0][j][1] += (float)xf[j][0];
 #endif
     };
-    // Measured (tools/fixed_cost_probe2.sh, loads ablated): 0.44 us per 128x128x64 step = 1.23 PFLOP/s chip-wide, the
+    // Measured (tools/experiments/fixed_cost_probe2.sh, loads ablated): 0.44 us per 128x128x64 step = 1.23 PFLOP/s chip-wide, the
     // rate an MFMA-dense loop on random data sustains at the clock the chip holds under that load (MI355X_MICROARCH.md,
     // DVFS); spreading the reads one per MFMA gap instead of in a burst changed nothing.
     using std::integral_constant;

@@ -2,7 +2,7 @@
 // the three horizontal taps of a kernel row.
 //
 // Why: the K loop of the LDS-DMA kernels runs at the rate the CU's load path delivers bytes into LDS, ~36 B/clk per CU
-// whatever the hit rates (tools/pf_probe.sh, profiles/round4_kstep_ablation.txt: without the activation loads a 64x64-tile
+// whatever the hit rates (tools/experiments/pf_probe.sh, profiles/round4_kstep_ablation.txt: without the activation loads a 64x64-tile
 // launch loses 25-37 % of its time, without the weight loads 14-33 %; an L2 prefetch of the weight panel changes nothing) --
 // so the lever is staged bytes per FLOP.  igemm2 stages a BM x 64 activation slab per K-step, i.e. nine times per
 // (pixel, channel); here K runs (chunk, dy, dx) with dx innermost and the slab of (chunk, dy) is staged once and read at

@@ -212,7 +212,7 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
         }
         const double P = (double)(float)tileH[nl], nn = (double)BM_T;
         const double v = k ? Q + P * (2.0 * S + nn * P) : S + nn * P;
-#ifdef ABL_STAT_COPIES      // harness probe (tools/stat_probe2.sh): spread the same-address atomics over copies of the table
+#ifdef ABL_STAT_COPIES      // harness probe (tools/experiments/stat_probe2.sh): spread the same-address atomics over copies of the table
         atomicAdd(reinterpret_cast<unsigned long long*>(a.stat_out + (long long)((m0 / BM_T) % ABL_STAT_COPIES) * a.N * 2 +
                                                         ((long long)n_img * a.N + n0 + nl) * 2 + k),
 #else
@@ -338,7 +338,7 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
 // STAGE_THREADS > 0 (the LDS-DMA kernels; = threads of the workgroup, all of which call this function): fp16 outputs
 // of an unsplit launch are collected in LDS and leave as full 16-byte-per-lane row segments written by every wave,
 // loader waves included.  The fragment layout's own stores are 8 bytes per lane over 16 rows: issue-bound, ~9 us of
-// a 128^2-map launch against ~2 us this way (tools/fixed_cost_probe2.sh).  Values and their order of evaluation are
+// a 128^2-map launch against ~2 us this way (tools/experiments/fixed_cost_probe2.sh).  Values and their order of evaluation are
 // unchanged, so results are bit-identical to the direct path.
 // `team2` >= 0 (two-team kernels on the staged path only): this wave belongs to team `team2`, and BOTH teams hold partial
 // accumulators that the staged epilogue adds up (team 0 + team 1) while it finishes the rows -- the separate merge pass
@@ -385,7 +385,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     for (int c = 0; c < 4; ++c) { ssum[i][c] = 0.f; ssq[i][c] = 0.f; piv[i][c] = 0.f; }
   // One loop over the wave's MT x NT fragment tiles per output mode, the mode tested OUTSIDE the loop: with the tests
   // inside, every tile jumped over the other modes' code and the launch paid an instruction-cache miss per jump
-  // (~4 us of a 128x128-tile launch, tools/fixed_cost_probe3.sh).
+  // (~4 us of a 128x128-tile launch, tools/experiments/fixed_cost_probe3.sh).
   auto col = [&](int i) { return n0 + wn * TNW + i * 16 + (lane >> 4) * 4; };
   auto row = [&](int j) { return m0 + wm * TMW + j * 16 + (lane & 15); };
   if (!active) {

@@ -14,7 +14,7 @@
 #include "gn_bwd_terms.h"
 #include "gn_act.h"
 
-#ifdef GN_STAMPS          // diagnostic build (tools/persist_chain.hip -DGN_STAMPS): s_memtime of thread 0 at the phase boundaries
+#ifdef GN_STAMPS          // diagnostic build (tools/experiments/persist_chain.hip -DGN_STAMPS): s_memtime of thread 0 at the phase boundaries
 extern __device__ unsigned long long* g_gn_stamps;      // [workgroup][8]
 #define GN_STAMP(k)                                                                                    \
   do {                                                                                                 \
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(int h_parts, int h_C, in
     if (c < a.Ca) {
       if (pend) {
         // bias / residual are fetched BEFORE the slices are waited for: one memory round trip instead of three in a row
-        // (the kernel is latency-bound, tools/persist_chain.hip -DGN_STAMPS)
+        // (the kernel is latency-bound, tools/experiments/persist_chain.hip -DGN_STAMPS)
         float bv[VEC], b2v[VEC], r[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { bv[i] = 0.f; b2v[i] = 0.f; r[i] = 0.f; }
@@ -567,7 +567,7 @@ int pick_parts(int N, int HW, int cpg, int unit, bool have_rec) {
   if (!have_rec) return 1;
   // the rendezvous costs ~3 atomic round trips (3-4 us), yet more, smaller parts still win down to a few hundred elements
   // per workgroup (in-situ sweep: 0.2445 / 0.2464 / 0.2500 / 0.2574 s per edit at >= 256 / 1024 / 2048 / 4096 elements;
-  // with the tagged-granule rendezvous, tools/gn_parts_probe.sh: local-GN kernel time 193 / 198 / 216 / 243 at >= 128 / 256 /
+  // with the tagged-granule rendezvous, tools/experiments/gn_parts_probe.sh: local-GN kernel time 193 / 198 / 216 / 243 at >= 128 / 256 /
   // 1024 / 2048 elements, 226 / 271 with at most 4 / 2 parts, 203-214 with up to 16 parts)
   int p = 1;
   // co-residency: a workgroup of these kernels (<= 1024 threads, <= 160 KB of LDS) always fits a compute unit by itself, so

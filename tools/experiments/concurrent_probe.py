@@ -3,7 +3,7 @@
 throughput (s/shape) and latency per edit.  Development probe; bench.py reports k = 2 next to the headline."""
 import os, sys, time, threading
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench
 from ishapediting_amd import synthetic

@@ -1,5 +1,5 @@
 // EXPERIMENT (round 3), measured and NOT adopted: 17.0 us per launch against 17.5 us for the two launches it replaces
-// (tools/persist_chain.hip, profiles/round3_persistent_chain.txt).  The K loop of a workgroup that owns ALL of K for a
+// (tools/experiments/persist_chain.hip, profiles/round3_persistent_chain.txt).  The K loop of a workgroup that owns ALL of K for a
 // 64-pixel map is bound by LDS fragment reads: every (tap, 32-deep k-step, 16-pixel block) needs its own 1 KiB activation
 // fragment whatever the number of output channels, 1.2 MB per 1024 input channels = ~2100 cycles per 128-channel chunk,
 // 8 chunks = 8 us -- the product's sliced kernel spreads exactly that over 4 workgroups per tile.  Kept as a record.
@@ -33,7 +33,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifdef C8_STAMPS          // diagnostic build (tools/persist_chain.hip -DC8_STAMPS): s_memtime of wave 0 at the phase boundaries
+#ifdef C8_STAMPS          // diagnostic build (tools/experiments/persist_chain.hip -DC8_STAMPS): s_memtime of wave 0 at the phase boundaries
 extern __device__ unsigned long long* g_c8_stamps;      // [workgroup][8]
 #define C8_STAMP(k)                                                                                    \
   do {                                                                                                 \

@@ -1,6 +1,6 @@
 """debug aid: zero-displacement drag loss at the full tap size"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ishapediting_amd import synthetic
 from ishapediting_amd.drag_utils import DragKernels, feat_channel_map

@@ -7,7 +7,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from ishapediting_amd import synthetic  # noqa: E402
 from ishapediting_amd.unet import UNetModel  # noqa: E402

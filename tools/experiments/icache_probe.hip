@@ -1,5 +1,5 @@
 // How fast does a wave run straight-line code it has never fetched?  (development aid)
-// hipcc --offload-arch=gfx950 -O3 tools/icache_probe.hip -o build/icache_probe
+// hipcc --offload-arch=gfx950 -O3 tools/experiments/icache_probe.hip -o build/icache_probe
 // One wave per workgroup runs a block of N independent 8-byte VALU instructions twice: the first pass fetches the code from
 // beyond the instruction cache (cold: the cache is invalidated at every dispatch), the second finds it there.
 #include <hip/hip_runtime.h>

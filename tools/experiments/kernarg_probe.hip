@@ -1,5 +1,5 @@
 // How long does a kernel wait for its first kernel argument?  (development aid)
-// hipcc --offload-arch=gfx950 -O3 [-mllvm -amdgpu-kernarg-preload-count=14] tools/kernarg_probe.hip -o build/kernarg_probe[_pre]
+// hipcc --offload-arch=gfx950 -O3 [-mllvm -amdgpu-kernarg-preload-count=14] tools/experiments/kernarg_probe.hip -o build/kernarg_probe[_pre]
 // Each workgroup's wave 0 stamps s_memtime at entry and again once an argument value has reached a register; the probe is
 // launched behind a kernel that touches 64 MB (so the scalar cache / L2 hold nothing of the kernarg segment, as in the
 // network, where every launch has its own freshly written kernarg block).

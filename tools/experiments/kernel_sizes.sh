@@ -1,6 +1,6 @@
 #!/bin/bash
 # Code bytes of every kernel in the library (instruction-cache footprint: a launch re-fetches what it executes).
-cd $(dirname $0)/..
+cd $(dirname $0)/../..
 T=$(mktemp -d)
 for f in ishapediting_amd/csrc/*.hip; do
   b=$(basename $f .hip)

@@ -14,7 +14,7 @@
 //       cdna_hip_programming.md Guideline 16 (sc1 payload, every storing wave drains, one lane signals, relaxed sc1 polls,
 //       bounded spins that raise an error word).
 // Output: per-layer time of both forms and the relative difference of the final activations.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/persist_chain.hip -o build/persist_chain && ./build/persist_chain [L]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/experiments/persist_chain.hip -o build/persist_chain && ./build/persist_chain [L]
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4: K-step ablation table + L2 weight-prefetch / ring-depth variants of the LDS-DMA conv kernel (harness builds from
-# tools/pf_probe_build.sh).  Output: gpurun_out/pf_probe.txt
+# tools/experiments/pf_probe_build.sh).  Output: gpurun_out/pf_probe.txt
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/pf_probe.txt
 mkdir -p gpurun_out; : > $O

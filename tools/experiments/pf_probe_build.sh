@@ -1,6 +1,6 @@
 #!/bin/bash
-# builds the conv harness in the variants tools/pf_probe.sh runs (here, on the CPU box; the binaries travel under build/)
-cd $(dirname $0)/..
+# builds the conv harness in the variants tools/experiments/pf_probe.sh runs (here, on the CPU box; the binaries travel under build/)
+cd $(dirname $0)/../..
 mkdir -p build
 F="--offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result -mllvm -amdgpu-kernarg-preload-count=14"
 b() { n=$1; shift; echo "/opt/rocm/bin/hipcc $F $@ tools/bench_igemm.hip -o build/pf_$n"; }

@@ -1,6 +1,6 @@
 """Timing of ishap_mesh_smooth (10 sweeps) on a 256^3 noise volume and on a sphere; prints ms and a checksum."""
 import time, torch, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ishapediting_amd.mesh import extract_surface, smooth_mesh
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(3)

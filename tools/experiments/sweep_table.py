@@ -1,4 +1,4 @@
-"""Rank the (tile, ksplit) candidates measured by tools/sweep_igemm.sh; a split adds one reduce launch (~5.5 us)."""
+"""Rank the (tile, ksplit) candidates measured by tools/experiments/sweep_igemm.sh; a split adds one reduce launch (~5.5 us)."""
 import collections
 import re
 import sys
