@@ -63,6 +63,7 @@ struct Tenant {
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;      // recorded when the tenant's last sequence was enqueued completely
   bool have = false, open = false, recorded = false;
+  bool denied = false;            // another context / stream asked while this tenant held the device (read and cleared by the tenant)
 };
 Tenant g_tenant[64];
 }  // namespace
@@ -86,12 +87,25 @@ bool ishap_rendezvous_begin(const void* owner, hipStream_t s) {
     return true;
   }
   if (t.have) {
-    if (t.open) return false;                   // another sequence is being enqueued right now
-    if (t.recorded && hipEventQuery(t.done) != hipSuccess) return false;   // ... or is still running
+    if (t.open) { t.denied = true; return false; }                   // another sequence is being enqueued right now
+    if (t.recorded && hipEventQuery(t.done) != hipSuccess) { t.denied = true; return false; }   // ... or is still running
   }
   if (!t.done && hipEventCreateWithFlags(&t.done, ishap_event_flags()) != hipSuccess) { t.done = nullptr; return false; }
-  t.owner = owner; t.stream = s; t.have = true; t.open = true; t.recorded = false;
+  t.owner = owner; t.stream = s; t.have = true; t.open = true; t.recorded = false; t.denied = false;
   return true;
+}
+
+// true once after another context / stream was refused the tenancy while `owner` held it: the device is being shared, and work
+// that only pays when ONE sequence has the chip to itself (the overlapped forward tail) should not be started
+bool ishap_rendezvous_contended(const void* owner, hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  Tenant& t = g_tenant[dev];
+  std::lock_guard<std::mutex> lk(t.mu);
+  if (!t.have || t.owner != owner || t.stream != s) return true;
+  const bool d = t.denied;
+  t.denied = false;
+  return d;
 }
 
 void ishap_rendezvous_end(const void* owner, hipStream_t s, bool granted) {

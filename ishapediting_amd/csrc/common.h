@@ -61,7 +61,8 @@ int ishap_cu_count();                 // compute units of the current device (ca
 // and compute-unit-masked streams; there the bounded spin + status word (above) turn a starved rendezvous into an error
 // (include/ishap.h, "Tenancy").
 bool ishap_rendezvous_begin(const void* owner, hipStream_t s);   // true: this sequence may use in-launch rendezvous
-void ishap_rendezvous_end(const void* owner, hipStream_t s, bool granted);   // closes the sequence (records its event on s)
+void ishap_rendezvous_end(const void* owner, hipStream_t s, bool granted);
+bool ishap_rendezvous_contended(const void* owner, hipStream_t s);   // reads and clears "someone else asked while I held the device"   // closes the sequence (records its event on s)
 
 #define ISHAP_TRY(expr)        \
   do {                         \

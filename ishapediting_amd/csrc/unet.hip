@@ -590,8 +590,10 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
   e.keep = (keep & 1) != 0;
   // the overlapped tail fills what ONE edit leaves idle; when another context / stream of the process is running sequences on the
   // device (no tenancy: common.h) the chip is shared already and a second stream per edit only oversubscribes the hardware
-  // queues (three interleaved edits: 0.120 s/shape in the plain sequence, 0.248 with three overlapped tails)
-  const bool overlap = (keep & 2) != 0 && !dry && feat_layer >= 0 && feat_layer + 1 < (int)u->out_blocks.size() && tenancy.granted;
+  // queues (three interleaved edits: 0.120 s/shape in the plain sequence, 0.248 with three overlapped tails, 0.143 with the
+  // tenant's alone): also not while anyone else has asked for the device since this context's last sequence
+  const bool overlap = (keep & 2) != 0 && !dry && feat_layer >= 0 && feat_layer + 1 < (int)u->out_blocks.size() && tenancy.granted &&
+                       !ishap_rendezvous_contended(u, s);
   if (!dry) ISHAP_TRY(unet_join_tail(u, s));       // the previous forward's tail still owns the arena it is about to reuse
   if (overlap && !u->side) {
     // lowest priority: the tail is throughput work that should fill what the latency-bound chain on the caller's stream
