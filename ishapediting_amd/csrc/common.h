@@ -277,6 +277,9 @@ struct IgemmArgs {
   int ups = 0;                   // conv3 source map is (H/2, W/2): nearest-neighbour upsample on the fly
   int res_ups = 0;               // residual map is (H/2, W/2)
   int ksplit = 1;
+  int lite = 0;                  // 1 (experiment, the overlapped forward tail): kernels sized to SHARE a compute unit with another stream's workgroup --
+                                 // 128x128 tiles on a 3 + 2 slot ring (83 KB of LDS instead of 132) with the fragment-layout epilogue (no 119 KB staging),
+                                 // one-team 64x64 tiles (76 KB instead of 150)
   int force_small = 0;           // 1: 64x64 tiles whatever the tile policy says (experiment: the overlapped tail on tiles that leave room for a second workgroup per CU)
   int chunk_tiles = 0;           // > 0 (a multiple of 8): igemm4 runs the layer as several launches of at most that many tiles (igemm4.hip, launch4)
   int defer_reduce = 0;          // ksplit > 1: leave the fp32 slices in `ws` (no reduce launch); the caller hands a SlabSrc to the consumer

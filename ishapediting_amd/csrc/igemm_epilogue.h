@@ -47,7 +47,7 @@ extern __device__ unsigned long long* g_ig_stamps;      // [workgroup][16]
 __device__ __forceinline__ bool igemm_epilogue_is_staged(const IgemmArgs& a, int batch) {
   const half_t* out16 = (const half_t*)a.out + (long long)batch * a.bso;
   const bool aligned16 = ((reinterpret_cast<unsigned long long>(out16) | reinterpret_cast<unsigned long long>(a.res)) & 15) == 0;
-  return a.out_mode == IG_OUT_F16 && a.ksplit == 1 && (a.N & 7) == 0 && (a.ldo & 7) == 0 && (!a.res || (a.ldr & 7) == 0) && aligned16 &&
+  return !a.lite && a.out_mode == IG_OUT_F16 && a.ksplit == 1 && (a.N & 7) == 0 && (a.ldo & 7) == 0 && (!a.res || (a.ldr & 7) == 0) && aligned16 &&
          (!a.gb_x || (a.N & 31) == 0);
 }
 

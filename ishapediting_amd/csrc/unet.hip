@@ -294,6 +294,7 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
   a.out_mode = out_mode;
   a.chunk_tiles = e.chunk_tiles;
   a.force_small = e.force_small;
+  a.lite = e.lite;
   a.flops_scale = (Wt == e.u->head.w) ? 1.f / 3.f : 1.f;
   a.ksplit = igemm_pick_ksplit(a.M, a.N, a.K, 1, pend_out != nullptr);
   if (!a.conv3 && a.M <= 64 && a.K % 64 == 0) {
@@ -706,6 +707,9 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
         e.chunk_tiles = tail_wgs;
         static const int tail_small = [] { const char* v = getenv("ISHAP_TAIL_SMALL"); return v ? atoi(v) : 0; }();
         e.force_small = tail_small;
+        static const int tail_lite = [] { const char* v = getenv("ISHAP_TAIL_LITE"); return v ? atoi(v) : 0; }();
+        e.lite = tail_lite;
+        if (tail_lite) e.chunk_tiles = 0;              // whole-layer grids: the point is to share every CU, not to leave some free
       }
     }
   }

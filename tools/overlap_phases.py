@@ -1,8 +1,8 @@
 """Un-traced phase times of a guided step with the overlapped forward tail (rocprofv3's queue interception distorts two-queue
 runs: under the tracer the caller's queue stood still for 0.3-1 ms after the fork, tools/fork_probe.hip shows no such stall).
 torch events on the caller's stream: step start | loss + backward enqueued (between()) | tail joined | guided update done.
-Plain mode:      t1 - t0 = full forward + loss + backward                     t2 - t1 = 0
-Overlapped mode: t1 - t0 = forward to the tap + loss + backward (contended)    t2 - t1 = what the tail still needs after the backward
+Plain mode:      t1 - t0 = full forward + loss + backward                     t2 - t1 = DDPM step + guided update
+Overlapped mode: t1 - t0 = forward to the tap + loss + backward (contended)    t2 - t1 = what the tail still needs after the backward + step
 Usage: [ISHAP_OVERLAP_TAIL=1 ISHAP_TAIL_WGS=64] python tools/overlap_phases.py"""
 import os
 import statistics
@@ -44,32 +44,18 @@ def main():
         marks.append(ev)
         return out
     cls.p_sample_guidance = timed
-    ov = os.environ.get("ISHAP_OVERLAP_TAIL", "0") == "1"
-    if not ov:          # plain mode: loss + backward run after p_sample_guidance returns; wrap the model's backward to mark its end
-        m = ds.model
-        binner = m.backward_input
-
-        def btimed(*a, **k):
-            r = binner(*a, **k)
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            marks[-1].append(e)
-            return r
-        m.backward_input = btimed
+    ov = os.environ.get("ISHAP_OVERLAP_TAIL", "1") == "1"
     for _ in range(2):
         marks.clear()
         for _ in ds.training(src, tgt, scale=1200, cof=0.4):
             pass
         torch.cuda.synchronize()
-    if ov:
-        a = [m[0].elapsed_time(m[1]) for m in marks]
-        b = [m[1].elapsed_time(m[2]) for m in marks]
-        print(f"overlapped (ISHAP_TAIL_WGS={os.environ.get('ISHAP_TAIL_WGS', '0')}): start -> loss+backward done {statistics.median(a):.3f} ms; "
-              f"-> tail joined + DDPM step {statistics.median(b):.3f} ms; sum {statistics.median(a) + statistics.median(b):.3f} ms")
-    else:
-        a = [m[0].elapsed_time(m[2]) for m in marks]
-        b = [m[2].elapsed_time(m[3]) for m in marks]
-        print(f"plain: forward + DDPM step {statistics.median(a):.3f} ms; loss + backward {statistics.median(b):.3f} ms; sum {statistics.median(a) + statistics.median(b):.3f} ms")
+    a = [m[0].elapsed_time(m[1]) for m in marks]
+    b = [m[1].elapsed_time(m[2]) for m in marks]
+    what = (f"overlapped (ISHAP_TAIL_WGS={os.environ.get('ISHAP_TAIL_WGS', '64')}, ISHAP_TAIL_LITE={os.environ.get('ISHAP_TAIL_LITE', '0')})"
+            if ov else "plain sequence")
+    print(f"{what}: step start -> loss + backward done {statistics.median(a):.3f} ms; -> tail joined + DDPM step / update "
+          f"{statistics.median(b):.3f} ms; sum {statistics.median(a) + statistics.median(b):.3f} ms")
 
 
 if __name__ == "__main__":
