@@ -281,6 +281,7 @@ struct IgemmArgs {
                                  // 128x128 tiles on a 3 + 2 slot ring (83 KB of LDS instead of 132) with the fragment-layout epilogue (no 119 KB staging),
                                  // one-team 64x64 tiles (76 KB instead of 150)
   int force_small = 0;           // 1: 64x64 tiles whatever the tile policy says (experiment: the overlapped tail on tiles that leave room for a second workgroup per CU)
+  int chunk_tiles_big = 0;       // the same for the 128x128-tile launches (0: chunk_tiles)
   int chunk_tiles = 0;           // > 0 (a multiple of 8): igemm4 runs the layer as several launches of at most that many tiles (igemm4.hip, launch4)
   int defer_reduce = 0;          // ksplit > 1: leave the fp32 slices in `ws` (no reduce launch); the caller hands a SlabSrc to the consumer
   float alpha = 1.f;

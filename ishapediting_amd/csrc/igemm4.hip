@@ -546,10 +546,11 @@ static int launch4(const IgemmArgs& a, hipStream_t s) {
   }
   const int order_bit = n_outer ? (1 << 30) : 0;
   const int tiles = h.nwg;
-  const bool chunked = a.chunk_tiles > 0 && a.chunk_tiles % 8 == 0 && tiles > a.chunk_tiles && b.nx_shift >= 0 && !g_igemm_prof_start;
+  const int chunk = (BM == 128 && BN == 128 && a.chunk_tiles_big > 0) ? a.chunk_tiles_big : a.chunk_tiles;
+  const bool chunked = chunk > 0 && chunk % 8 == 0 && tiles > chunk && b.nx_shift >= 0 && !g_igemm_prof_start;
   if (chunked) {
-    for (int base = 0; base < tiles; base += a.chunk_tiles) {
-      const int n = tiles - base < a.chunk_tiles ? tiles - base : a.chunk_tiles;
+    for (int base = 0; base < tiles; base += chunk) {
+      const int n = tiles - base < chunk ? tiles - base : chunk;
       hipLaunchKernelGGL(kern, dim3(n), dim3(512 * HALVES), smem, s,
                          (const void*)h.X, (const void*)h.Wt, h.K, h.Cin, h.ldx, h.ldw, h.H, h.W, h.ksplit, h.nwg, h.packed, base | order_bit, b);
     }

@@ -189,6 +189,7 @@ struct Exec {
   float* gn_partial = nullptr;
   int lite = 0;                 // 1: this sequence's convolutions use the LDS-light kernel forms (IgemmArgs::lite)
   int force_small = 0;          // 1: this sequence's convolutions take 64x64 tiles only
+  int chunk_tiles_big = 0;
   int chunk_tiles = 0;          // > 0: the dx-reuse convolutions of this sequence run as launches of at most that many tiles (the overlapped forward tail)
   bool tenant = true;           // this sequence holds the device's rendezvous tenancy (common.h ishap_rendezvous_begin)
 };

@@ -293,6 +293,7 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
   a.H = H; a.W = W; a.ups = ups; a.res_ups = res_ups;
   a.out_mode = out_mode;
   a.chunk_tiles = e.chunk_tiles;
+  a.chunk_tiles_big = e.chunk_tiles_big;
   a.force_small = e.force_small;
   a.lite = e.lite;
   a.flops_scale = (Wt == e.u->head.w) ? 1.f / 3.f : 1.f;
@@ -705,6 +706,8 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
         // path; 96 ... 192 and whole layers: the backward's convolutions wait for compute units)
         static const int tail_wgs = [] { const char* v = getenv("ISHAP_TAIL_WGS"); return v ? atoi(v) : 64; }();
         e.chunk_tiles = tail_wgs;
+        static const int tail_wgs_big = [] { const char* v = getenv("ISHAP_TAIL_WGS_BIG"); return v ? atoi(v) : 0; }();
+        e.chunk_tiles_big = tail_wgs_big;
         static const int tail_small = [] { const char* v = getenv("ISHAP_TAIL_SMALL"); return v ? atoi(v) : 0; }();
         e.force_small = tail_small;
         static const int tail_lite = [] { const char* v = getenv("ISHAP_TAIL_LITE"); return v ? atoi(v) : 0; }();
