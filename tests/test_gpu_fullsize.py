@@ -68,6 +68,42 @@ def test_edit_is_bitwise_reproducible_and_moves_the_shape(ds):
     assert len(ds.last_losses) == W_TIME and all(bool(torch.isfinite(l).all()) for l in ds.last_losses)
 
 
+_LOAD = r"""
+import sys, time, torch
+a = torch.randn(4096, 4096, device="cuda", dtype=torch.float16)
+b = torch.randn(4096, 4096, device="cuda", dtype=torch.float16)
+torch.cuda.synchronize()
+print("ready", flush=True)
+t0 = time.time()
+while time.time() - t0 < 40.0:
+    for _ in range(7):
+        c = a @ b
+    torch.cuda.synchronize()
+    time.sleep(0.0007)
+"""
+
+
+def test_edits_stay_bitwise_repeatable_beside_a_loading_process(ds):
+    """The in-launch hand-offs of the default path (GroupNorm rendezvous with its XCD-local record, the overlapped forward tail's
+    fork / join) under UNEVEN load: a second PROCESS -- invisible to the library's tenancy guard -- keeps the chip busy in bursts
+    while eight edits run; every one must reproduce the unloaded edit bit for bit and leave the device status word clear.
+    (tools/stress_repeat.py is the long form: 60 full-length edits alone and 60 beside the load, 0 differing.)"""
+    import subprocess
+    import sys
+    from ishapediting_amd import _lib
+    lat0, vol0 = run_edit(ds, scale=1200.0)
+    child = subprocess.Popen([sys.executable, "-c", _LOAD], stdout=subprocess.PIPE, text=True)
+    try:
+        assert child.stdout.readline().strip() == "ready"
+        for k in range(8):
+            lat, vol = run_edit(ds, scale=1200.0)
+            assert torch.equal(lat, lat0) and torch.equal(vol, vol0), k
+            assert int(_lib.lib().ishap_device_status()) == 0, _lib.lib().ishap_last_error().decode()
+    finally:
+        child.terminate()
+        child.wait()
+
+
 def test_input_gradient_is_linear_in_the_cotangent(ds):
     """d sum(tap*c)/dx is linear in c.  fp16 gradient maps: additivity within 1e-2 relative L2, a power-of-two
     rescale within 3e-3 (not exact: fp16 subnormals and the fixed-point GroupNorm-backward sums have an absolute
