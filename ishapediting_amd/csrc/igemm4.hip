@@ -623,7 +623,7 @@ int igemm4_small_map_slices(const IgemmArgs& a) {
 // two teams: one workgroup per CU at most (<= 256 tiles) and a K slice long enough to halve (measured break-even: ~40 steps)
 bool igemm4_two_teams(const IgemmArgs& a, bool big) {
   static const int on = [] { const char* e = getenv("ISHAP_IG4_TEAMS"); return e ? atoi(e) : 2; }();
-  if (big || on != 2 || a.lite) return false;
+  if (big || on != 2 || a.lite == 1) return false;
   const long long tiles = (long long)(a.M / 64) * ((a.N + 63) / 64) * a.ksplit;
   const int groups = (3 * (a.Cin / 64) + a.ksplit - 1) / a.ksplit;
   static const int min_steps = [] { const char* e = getenv("ISHAP_IG4_TEAM_STEPS"); return e ? atoi(e) : 48; }();
@@ -633,14 +633,18 @@ bool igemm4_two_teams(const IgemmArgs& a, bool big) {
 // fills the chip (32 x 8 = 256 workgroups) and a K-step stages 13.3 KB for twice the FLOPs of a 64x64 tile's 10.7 KB
 bool igemm4_tall_tiles(const IgemmArgs& a, bool big) {
   static const int on = [] { const char* e = getenv("ISHAP_IG4_TALL"); return e ? atoi(e) : 1; }();
-  if (big || !on || a.lite || a.W != 64 || a.K2 != 0 || a.ksplit != 1 || a.M % 128 != 0 || (a.H * a.W) % 128 != 0) return false;
+  if (big || !on || a.lite == 1 || a.W != 64 || a.K2 != 0 || a.ksplit != 1 || a.M % 128 != 0 || (a.H * a.W) % 128 != 0) return false;
   const long long tiles = (long long)(a.M / 128) * ((a.N + 63) / 64);
   static const int tmin = [] { const char* e = getenv("ISHAP_IG4_TALL_MIN"); return e ? atoi(e) : 224; }();
   return tiles >= tmin && tiles <= 512;
 }
 int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
   if (big) {
-    if (a.W == 128 && a.lite) return launch4<128, 128, 128, 3, 2>(a, s);
+    if (a.lite) {                                    // 83 KB of LDS: two workgroups per CU
+      if (a.W == 128) return launch4<128, 128, 128, 3, 2>(a, s);
+      if (a.W == 64) return launch4<128, 128, 64, 3, 2>(a, s);
+      if (a.W == 32) return launch4<128, 128, 32, 3, 2>(a, s);
+    }
     if (a.W == 128) return launch4<128, 128, 128, IG4_BIG_W, IG4_BIG_X>(a, s);
     if (a.W == 64) return launch4<128, 128, 64, IG4_BIG_W, IG4_BIG_X>(a, s);
     if (a.W == 32) return launch4<128, 128, 32, IG4_BIG_W, IG4_BIG_X>(a, s);

@@ -296,6 +296,10 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
   a.chunk_tiles_big = e.chunk_tiles_big;
   a.force_small = e.force_small;
   a.lite = e.lite;
+  // experiment (ISHAP_LITE_BATCH=n): from batch n on, the 128x128-tile launches of EVERY sequence take the LDS-light form, two
+  // workgroups per CU -- with 4+ tiles per CU (the batched generate path) one tile's epilogue then runs under another's K loop
+  static const int lite_batch = [] { const char* v = getenv("ISHAP_LITE_BATCH"); return v ? atoi(v) : 0; }();
+  if (lite_batch > 0 && N >= lite_batch && taps == 9 && H * W >= 1024) a.lite = 2;
   a.flops_scale = (Wt == e.u->head.w) ? 1.f / 3.f : 1.f;
   a.ksplit = igemm_pick_ksplit(a.M, a.N, a.K, 1, pend_out != nullptr);
   if (!a.conv3 && a.M <= 64 && a.K % 64 == 0) {
