@@ -89,6 +89,11 @@ const void* ishap_unet_tap_ptr(const ishap_unet* u);
  * `out` is complete on a stream only after ishap_unet_join_tail(u, that stream); the next ishap_unet_forward, a
  * full-depth backward and ishap_unet_block_output join by themselves. */
 int ishap_unet_join_tail(ishap_unet* u, void* stream);
+/* Deferred form of the overlapped tail (the default; ISHAP_TAIL_DEFER=0: enqueued by the forward itself): the forward only plans the blocks after the tap;
+ * this call enqueues them on the context's stream of its own, behind the point the backward pass marked after its first
+ * output blocks (or behind the tap when no backward ran).  No-op when nothing is planned; ishap_unet_join_tail runs a plan that
+ * was never enqueued. */
+int ishap_unet_run_tail(ishap_unet* u);
 /* copy it into a caller buffer of N*S_tap^2*C_tap halfs (the guidance cache of drag_utils.py:275-276, kept
  * on the device in the tap's own layout instead of resized fp32 copies on the host) */
 int ishap_unet_copy_tap(const ishap_unet* u, void* dst, void* stream);

@@ -234,6 +234,16 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
     ISHAP_TRY(block_backward(e, b, g, gh, Ch, &gs));       // the first ResBlock writes d/d[h | skip] as two tensors
     skipgrad[n_in - 1 - i] = gs;     // hs.pop() order (unet.py:663)
     g = gh;
+    // a deferred forward tail starts behind this point: the backward's first (chip-filling) blocks have the GPU to themselves.
+    // Default: once the first output block on a map of at most 16 x 16 pixels has been differentiated (the real model: after
+    // out8 ... out5, i.e. four blocks -- in-situ sweep of the count, profiles/round5_overlap_tail_ab.txt 7); ISHAP_TAIL_MID=k: after
+    // k blocks, 0: never (the tail then starts at the fork)
+    static const int mid_k = [] { const char* v = getenv("ISHAP_TAIL_MID"); return v ? atoi(v) : -1; }();
+    const bool here = mid_k > 0 ? F - i + 1 == mid_k : (mid_k < 0 && b.res_in <= 16);
+    if (!dry && u->tail_deferred && !u->mid_recorded && here) {
+      ISHAP_CHECK_HIP(hipEventRecord(u->ev_mid, s));
+      u->mid_recorded = true;
+    }
   }
   // The gradient entering input block i is (gradient from the block after it) + (its skip-connection gradient).  When the
   // block after it ends its backward with a ResBlock (always, except the stem), that ResBlock's last kernel adds the skip

@@ -160,8 +160,13 @@ struct ishap_unet {
   // backward pass the caller enqueues next (those need nothing after the tap).  ishap_unet_join_tail orders a stream
   // behind them; the next forward / a full-depth backward / a block read-out joins by itself.
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_tail = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_tail = nullptr, ev_mid = nullptr;
   bool tail_pending = false;
+  // deferred tail (ISHAP_TAIL_DEFER): planned by the forward, enqueued by ishap_unet_run_tail behind ev_mid (recorded by the
+  // backward after its first output blocks)
+  struct TailState { size_t split; Tensor h; std::vector<Tensor> hs; int N; float* out; size_t arena_off, stat_off; bool keep; };
+  TailState tail{};
+  bool tail_deferred = false, mid_recorded = false;
   float* ws_side = nullptr;          // the side stream's own copies of the shared scratch buffers
   float* gn_partial_side = nullptr;
   float* attn_D = nullptr;      // backward attention row sums

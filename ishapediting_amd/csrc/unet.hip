@@ -578,10 +578,118 @@ static int block_forward(Exec& e, BlockL& b, Tensor h, Tensor& out) {
 }
 
 // order `s` behind a forward tail that is still running on the context's side stream (no-op when there is none)
+int unet_run_tail(ishap_unet* u);
 int unet_join_tail(ishap_unet* u, hipStream_t s) {
+  if (u->tail_deferred) ISHAP_TRY(unet_run_tail(u));     // planned but never enqueued: enqueue it now
   if (!u->tail_pending) return 0;
   ISHAP_CHECK_HIP(hipStreamWaitEvent(s, u->ev_tail, 0));
   u->tail_pending = false;
+  return 0;
+}
+
+// the launch-sequence settings of the forward tail on the context's side stream
+static void tail_exec(Exec& e, ishap_unet* u) {
+  e.s = u->side;
+  e.ws = u->ws_side;
+  e.gn_partial = u->gn_partial_side;
+  // the tail's 3x3 convolutions as launches of at most P tiles: it then holds the LDS of at most P compute units at a time
+  // and the backward chain on the caller's stream keeps the rest (ISHAP_TAIL_WGS, 0 = whole-layer grids)
+  // in-situ sweep (profiles/round5_overlap_tail_ab.txt): 64 tiles per launch is the optimum (32: the tail becomes the critical
+  // path; 96 ... 192 and whole layers: the backward's convolutions wait for compute units)
+  static const int tail_wgs = [] { const char* v = getenv("ISHAP_TAIL_WGS"); return v ? atoi(v) : 64; }();
+  e.chunk_tiles = tail_wgs;
+  static const int tail_wgs_big = [] { const char* v = getenv("ISHAP_TAIL_WGS_BIG"); return v ? atoi(v) : 0; }();
+  e.chunk_tiles_big = tail_wgs_big;
+  static const int tail_small = [] { const char* v = getenv("ISHAP_TAIL_SMALL"); return v ? atoi(v) : 0; }();
+  e.force_small = tail_small;
+  static const int tail_lite = [] { const char* v = getenv("ISHAP_TAIL_LITE"); return v ? atoi(v) : 0; }();
+  e.lite = tail_lite;
+  if (tail_lite) e.chunk_tiles = 0;              // whole-layer grids: the point is to share every CU, not to leave some free
+}
+
+// output blocks [i0, i1): skip concatenation + block (gd/unet.py:661-664); records the tap after block `feat_layer`
+static int out_blocks_range(Exec& e, ishap_unet* u, size_t i0, size_t i1, Tensor& h, std::vector<Tensor>& hs, int feat_layer) {
+  for (size_t i = i0; i < i1; ++i) {
+    BlockL& b = u->out_blocks[i];
+    Tensor skip = hs.back();
+    hs.pop_back();
+    Tensor cat{nullptr, h.N, h.H, h.W, h.C + skip.C};
+    ISHAP_REQUIRE(skip.H == h.H && cat.C == b.cin, "skip connection shape");
+    ISHAP_ALLOC(cat.p, e, cat.numel());
+    const bool first_is_res = b.layers[0].kind == 1;
+    if (first_is_res && local_gn(h.H * h.W, cat.C)) {
+      // no copy pass: the ResBlock's first (group-local) GroupNorm reads both halves -- adding up h if it is still
+      // pending -- and writes the concatenation as it goes
+      cat.cat_a = h.p; cat.cat_b = skip.p; cat.cat_ca = h.C; cat.cat_pend = h.pend;
+    } else if (first_is_res && h.sums && skip.sums && h.C % 8 == 0) {
+      cat.cat_a = h.p; cat.cat_b = skip.p; cat.cat_sa = h.sums; cat.cat_sb = skip.sums; cat.cat_ca = h.C;
+    } else {
+      ISHAP_TRY(slab_materialize(e, h));
+      cat.sums = (h.sums && skip.sums) ? salloc(e, (size_t)cat.N * cat.C * 2) : nullptr;
+      if (!e.dry) ISHAP_TRY(concat2(h.p, skip.p, cat.p, cat.rows(), h.C, skip.C, e.s, h.sums, skip.sums, cat.sums, cat.N));
+    }
+    b.cat = cat;
+    b.cat.cat_pend = SlabSrc{};
+    Tensor y;
+    ISHAP_TRY(block_forward(e, b, cat, y));
+    h = y;
+    if ((int)i == feat_layer) {
+      u->tap = h;
+      u->tap.pend = SlabSrc{};
+    }
+  }
+  return 0;
+}
+
+// ---- head in fp32 (unet.py:667-669): GroupNorm, SiLU, 3x3 conv with fp32 weights.  The fp32 products are
+//      formed on the fp16 MFMA from hi/lo splits of both operands (3 partial products, fp32 accumulate). ----
+static int forward_head(Exec& e, ishap_unet* u, Tensor h, int N, float* out) {
+  const ishap_unet_config& cfg = u->cfg;
+  const int S = cfg.image_size;
+  ISHAP_TRY(slab_materialize(e, h));      // the head's GroupNorm runs on the full-size map (never group-local in the real model)
+  u->h_final = h;
+  ISHAP_ALLOC(u->head_stats, e, (size_t)N * 64);
+  if (!h.sums) ISHAP_TRY(gn_stats_op(e, h, u->head_stats));
+  half_t* hsplit = nullptr; ISHAP_ALLOC(hsplit, e, (size_t)h.numel() * 3);
+  if (!e.dry) {
+    GnApplyArgs g;
+    g.x = h.p; g.out = hsplit; g.stats = u->head_stats; g.sums = h.sums; g.stats_out = h.sums ? u->head_stats : nullptr;
+    g.gamma = u->head_norm.gamma; g.beta = u->head_norm.beta;
+    g.N = N; g.H = S; g.W = S; g.C = h.C; g.act = 1; g.split = 1;
+    g.pf = pf_fwd(u->head);
+    ISHAP_TRY(gn_apply_launch(g, e.s));
+  }
+  ISHAP_TRY(conv_op(e, hsplit, N, S, S, 3 * h.C, u->head.w, u->head.kpad, 9, cfg.out_channels, u->head.bias, nullptr, 0, out,
+                    0, IG_OUT_NCHW_F32, 0, 0));
+  return 0;
+}
+
+// the deferred forward tail (ISHAP_TAIL_DEFER): the launches unet_forward_impl only planned, on the side stream, behind the event
+// the backward recorded after its first blocks (or behind the fork when it recorded none)
+int unet_run_tail(ishap_unet* u) {
+  if (!u->tail_deferred) return 0;
+  u->tail_deferred = false;
+  const size_t keep_arena = u->arena.off, keep_stat = u->stat_off;
+  u->arena.off = u->tail.arena_off;
+  u->stat_off = u->tail.stat_off;
+  ISHAP_CHECK_HIP(hipStreamWaitEvent(u->side, u->mid_recorded ? u->ev_mid : u->ev_fork, 0));
+  Exec e{u, u->side, false};
+  e.tenant = false;
+  e.keep = u->tail.keep;
+  tail_exec(e, u);
+  // tiles per launch: 128 = half a layer at a time (in-situ sweep with the start point: 96 / 112 / 128 / 144 / 160 / 192 / 256 ->
+  // 0.1706 / 0.1707 / 0.1682 / 0.1707 / 0.1714 / 0.1727 / 0.1785 s per edit, default before 0.1720-0.1731)
+  static const int wgs = [] { const char* v = getenv("ISHAP_TAIL_DEFER_WGS"); return v ? atoi(v) : 128; }();
+  e.chunk_tiles = wgs;
+  Tensor h = u->tail.h;
+  std::vector<Tensor> hs = u->tail.hs;
+  ISHAP_TRY(out_blocks_range(e, u, u->tail.split, u->out_blocks.size(), h, hs, u->last_feat));
+  ISHAP_TRY(forward_head(e, u, h, u->tail.N, u->tail.out));
+  ISHAP_CHECK_HIP(hipEventRecord(u->ev_tail, u->side));
+  u->tail_pending = true;
+  ISHAP_REQUIRE(u->arena.off == u->fwd_mark && u->stat_off == u->stat_fwd_mark, "the deferred tail allocated differently from its plan");
+  u->arena.off = keep_arena;
+  u->stat_off = keep_stat;
   return 0;
 }
 
@@ -617,6 +725,7 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     }
     ISHAP_CHECK_HIP(hipEventCreateWithFlags(&u->ev_fork, ishap_event_flags()));
     ISHAP_CHECK_HIP(hipEventCreateWithFlags(&u->ev_tail, ishap_event_flags()));
+    ISHAP_CHECK_HIP(hipEventCreateWithFlags(&u->ev_mid, ishap_event_flags()));
     if (u->ws_floats) ISHAP_CHECK_HIP(hipMalloc((void**)&u->ws_side, u->ws_floats * sizeof(float)));
     ISHAP_CHECK_HIP(hipMalloc((void**)&u->gn_partial_side, std::max<size_t>(u->gn_partial_floats, 64) * sizeof(float)));
   }
@@ -667,76 +776,50 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     h = y;
   }
   u->tap = Tensor{};
-  for (size_t i = 0; i < u->out_blocks.size(); ++i) {
-    BlockL& b = u->out_blocks[i];
-    Tensor skip = hs.back();
-    hs.pop_back();
-    Tensor cat{nullptr, h.N, h.H, h.W, h.C + skip.C};
-    ISHAP_REQUIRE(skip.H == h.H && cat.C == b.cin, "skip connection shape");
-    ISHAP_ALLOC(cat.p, e, cat.numel());
-    const bool first_is_res = b.layers[0].kind == 1;
-    if (first_is_res && local_gn(h.H * h.W, cat.C)) {
-      // no copy pass: the ResBlock's first (group-local) GroupNorm reads both halves -- adding up h if it is still
-      // pending -- and writes the concatenation as it goes
-      cat.cat_a = h.p; cat.cat_b = skip.p; cat.cat_ca = h.C; cat.cat_pend = h.pend;
-    } else if (first_is_res && h.sums && skip.sums && h.C % 8 == 0) {
-      cat.cat_a = h.p; cat.cat_b = skip.p; cat.cat_sa = h.sums; cat.cat_sb = skip.sums; cat.cat_ca = h.C;
-    } else {
-      ISHAP_TRY(slab_materialize(e, h));
-      cat.sums = (h.sums && skip.sums) ? salloc(e, (size_t)cat.N * cat.C * 2) : nullptr;
-      if (!dry) ISHAP_TRY(concat2(h.p, skip.p, cat.p, cat.rows(), h.C, skip.C, e.s, h.sums, skip.sums, cat.sums, cat.N));
-    }
-    b.cat = cat;
-    b.cat.cat_pend = SlabSrc{};
-    Tensor y;
-    ISHAP_TRY(block_forward(e, b, cat, y));
-    h = y;
-    if ((int)i == feat_layer) {
-      u->tap = h;
-      u->tap.pend = SlabSrc{};
-      if (overlap) {
-        // everything below needs only what exists now; whatever the caller enqueues on `s` after this call (loss,
-        // backward) needs nothing of what follows: fork
-        ISHAP_TRY(slab_materialize(e, h));             // the tap is complete on the caller's stream
-        u->tap = h;
-        ISHAP_CHECK_HIP(hipEventRecord(u->ev_fork, s));
+  const size_t n_out = u->out_blocks.size();
+  const size_t split = overlap ? (size_t)feat_layer + 1 : n_out;
+  ISHAP_TRY(out_blocks_range(e, u, 0, split, h, hs, feat_layer));
+  if (overlap) {
+    // everything after the tap needs only what exists now; whatever the caller enqueues on `s` after this call (loss,
+    // backward) needs nothing of what follows: fork
+    ISHAP_TRY(slab_materialize(e, h));             // the tap is complete on the caller's stream
+    u->tap = h;
+    ISHAP_CHECK_HIP(hipEventRecord(u->ev_fork, s));
+    static const int defer = [] { const char* v = getenv("ISHAP_TAIL_DEFER"); return v ? atoi(v) : 1; }();
+    if (defer) {
+      // DEFERRED tail (default since late round 5: -2.2 % against the tail forked at the tap): only PLAN the rest here -- allocate what it will allocate, launch nothing -- so that the
+      // caller's backward gets its scratch above the whole forward; ishap_unet_run_tail enqueues the launches later, behind an
+      // event the backward records after its first blocks (the tail then runs beside the backward's latency-bound middle,
+      // not beside its chip-filling first and last launches)
+      // ISHAP_TAIL_EARLY=n: the first n blocks after the tap are enqueued right away (at the fork, ISHAP_TAIL_WGS tiles per
+      // launch), only the rest is deferred
+      static const int early = [] { const char* v = getenv("ISHAP_TAIL_EARLY"); return v ? atoi(v) : 0; }();
+      size_t split2 = split;
+      if (early > 0) {
+        split2 = std::min(n_out, split + (size_t)early);
         ISHAP_CHECK_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
-        e.s = u->side;
-        e.ws = u->ws_side;
-        e.gn_partial = u->gn_partial_side;
-        // the tail's 3x3 convolutions as launches of at most P tiles: it then holds the LDS of at most P compute units at a time
-        // and the backward chain on the caller's stream keeps the rest (ISHAP_TAIL_WGS, 0 = whole-layer grids)
-        // in-situ sweep (profiles/round5_overlap_tail_ab.txt): 64 tiles per launch is the optimum (32: the tail becomes the critical
-        // path; 96 ... 192 and whole layers: the backward's convolutions wait for compute units)
-        static const int tail_wgs = [] { const char* v = getenv("ISHAP_TAIL_WGS"); return v ? atoi(v) : 64; }();
-        e.chunk_tiles = tail_wgs;
-        static const int tail_wgs_big = [] { const char* v = getenv("ISHAP_TAIL_WGS_BIG"); return v ? atoi(v) : 0; }();
-        e.chunk_tiles_big = tail_wgs_big;
-        static const int tail_small = [] { const char* v = getenv("ISHAP_TAIL_SMALL"); return v ? atoi(v) : 0; }();
-        e.force_small = tail_small;
-        static const int tail_lite = [] { const char* v = getenv("ISHAP_TAIL_LITE"); return v ? atoi(v) : 0; }();
-        e.lite = tail_lite;
-        if (tail_lite) e.chunk_tiles = 0;              // whole-layer grids: the point is to share every CU, not to leave some free
+        Exec ea = e;
+        tail_exec(ea, u);
+        ISHAP_TRY(out_blocks_range(ea, u, split, split2, h, hs, feat_layer));
       }
+      u->tail = ishap_unet::TailState{split2, h, hs, N, out, u->arena.off, u->stat_off, (keep & 1) != 0};
+      Exec plan = e;
+      plan.dry = true;
+      Tensor hp = h;
+      std::vector<Tensor> hsp = hs;
+      ISHAP_TRY(out_blocks_range(plan, u, split2, n_out, hp, hsp, feat_layer));
+      ISHAP_TRY(forward_head(plan, u, hp, N, out));
+      u->tail_deferred = true;
+      u->mid_recorded = false;
+    } else {
+      ISHAP_CHECK_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
+      tail_exec(e, u);
+      ISHAP_TRY(out_blocks_range(e, u, split, n_out, h, hs, feat_layer));
+      ISHAP_TRY(forward_head(e, u, h, N, out));
     }
+  } else {
+    ISHAP_TRY(forward_head(e, u, h, N, out));
   }
-  ISHAP_TRY(slab_materialize(e, h));      // the head's GroupNorm runs on the full-size map (never group-local in the real model)
-  u->h_final = h;
-  // ---- head in fp32 (unet.py:667-669): GroupNorm, SiLU, 3x3 conv with fp32 weights.  The fp32 products are
-  //      formed on the fp16 MFMA from hi/lo splits of both operands (3 partial products, fp32 accumulate). ----
-  ISHAP_ALLOC(u->head_stats, e, (size_t)N * 64);
-  if (!h.sums) ISHAP_TRY(gn_stats_op(e, h, u->head_stats));
-  half_t* hsplit = nullptr; ISHAP_ALLOC(hsplit, e, (size_t)h.numel() * 3);
-  if (!dry) {
-    GnApplyArgs g;
-    g.x = h.p; g.out = hsplit; g.stats = u->head_stats; g.sums = h.sums; g.stats_out = h.sums ? u->head_stats : nullptr;
-    g.gamma = u->head_norm.gamma; g.beta = u->head_norm.beta;
-    g.N = N; g.H = S; g.W = S; g.C = h.C; g.act = 1; g.split = 1;
-    g.pf = pf_fwd(u->head);
-    ISHAP_TRY(gn_apply_launch(g, e.s));
-  }
-  ISHAP_TRY(conv_op(e, hsplit, N, S, S, 3 * h.C, u->head.w, u->head.kpad, 9, cfg.out_channels, u->head.bias, nullptr, 0, out,
-                    0, IG_OUT_NCHW_F32, 0, 0));
   if (feat_layer >= 0 && inter_feat && !dry)
     ISHAP_TRY(nhwc_f16_to_nchw(u->tap.p, inter_feat, 0, N, u->tap.C, u->tap.H * u->tap.W, u->tap.C, s));
   if (e.s != s) {                                      // the tail ran on the side stream
@@ -815,6 +898,7 @@ void ishap_unet_destroy(ishap_unet* u) {
   if (u->side) (void)hipStreamDestroy(u->side);
   if (u->ev_fork) (void)hipEventDestroy(u->ev_fork);
   if (u->ev_tail) (void)hipEventDestroy(u->ev_tail);
+  if (u->ev_mid) (void)hipEventDestroy(u->ev_mid);
   fr(u->arena.base); fr(u->ws); fr(u->gn_partial); fr(u->attn_D); fr(u->stat_base);
   delete u;
 }
@@ -891,6 +975,12 @@ int ishap_unet_join_tail(ishap_unet* u, void* stream) {
   ISHAP_REQUIRE(u, "null argument");
   ISHAP_CHECK_HIP(hipSetDevice(u->device));
   return unet_join_tail(u, (hipStream_t)stream);
+}
+
+int ishap_unet_run_tail(ishap_unet* u) {
+  ISHAP_REQUIRE(u, "null argument");
+  ISHAP_CHECK_HIP(hipSetDevice(u->device));
+  return unet_run_tail(u);
 }
 
 int ishap_unet_forward(ishap_unet* u, const float* x, const float* timesteps, int N, int feat_layer, float* out,

@@ -202,6 +202,8 @@ class SpacedDiffusion:
         if between is not None:
             grad = between()
             if kw.get("overlap_tail"):
+                if hasattr(model, "run_tail"):
+                    model.run_tail()          # a tail the forward only planned (deferred form); no-op otherwise
                 model.join_tail()
         if guided_scale is not None and grad is not None and variance_noise is None:
             noise = self._prep(noise if noise is not None else torch.randn_like(x))

@@ -142,6 +142,11 @@ class UNetModel:
 
     __call__ = forward
 
+    def run_tail(self):
+        """Enqueue a forward tail that `forward(overlap_tail=True)` only planned (ISHAP_TAIL_DEFER=1); no-op otherwise."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ishap_unet_run_tail(self._h))
+
     def join_tail(self):
         """Order the current stream behind an overlapped forward tail (no-op when there is none)."""
         with torch.cuda.device(self.device):
