@@ -362,8 +362,10 @@ class DragStuff:
             # loss + backward run beside the part of the forward after the tap (p_sample_guidance's `between`; ISHAP_OVERLAP_TAIL=0:
             # the plain sequence).  Rounds 2-4 measured a LOSS with whole-layer grids (the tail's 128x128-tile convolutions hold
             # every CU's LDS for a tile's length and the backward chain queues behind them).  Round 5: the tail's convolutions run as
-            # launches of at most 64 tiles (ISHAP_TAIL_WGS, csrc/igemm4.hip launch4), i.e. on a quarter of the compute units at a
-            # time: -1.7 % per edit on three boxes (profiles/round5_overlap_tail_ab.txt); bit-identical results, tested.
+            # launches of at most 64-128 tiles (csrc/igemm4.hip launch4), and -- late round 5 -- the forward only plans them: they are
+            # enqueued (model.run_tail, inside p_sample_guidance) behind an event the backward records after its first 16x16 block,
+            # so they run beside the backward's latency-bound middle: -3.8 % per edit against the plain sequence
+            # (profiles/round5_overlap_tail_ab.txt); bit-identical results, tested.
             # the update img = sample + variance * scale * grad (:384-392) is formed by the step kernel (guided_scale): the loss +
             # backward run between the model call and the step arithmetic either way, beside the forward tail when overlapping
             outs = self.diffusion.p_sample_guidance(self.model, img, i, feat_layer=self.args.feat_layer,
