@@ -683,7 +683,17 @@ int unet_run_tail(ishap_unet* u) {
   e.chunk_tiles = wgs;
   Tensor h = u->tail.h;
   std::vector<Tensor> hs = u->tail.hs;
-  ISHAP_TRY(out_blocks_range(e, u, u->tail.split, u->out_blocks.size(), h, hs, u->last_feat));
+  // ISHAP_TAIL_LATE=k / ISHAP_TAIL_LATE_WGS=n: the last k blocks and the head with n tiles per launch (they run when the backward
+  // is back on its chip-filling input blocks)
+  static const int late = [] { const char* v = getenv("ISHAP_TAIL_LATE"); return v ? atoi(v) : 0; }();
+  static const int late_wgs = [] { const char* v = getenv("ISHAP_TAIL_LATE_WGS"); return v ? atoi(v) : 64; }();
+  const size_t n_out = u->out_blocks.size();
+  const size_t cut = late > 0 && n_out - u->tail.split > (size_t)late ? n_out - (size_t)late : n_out;
+  ISHAP_TRY(out_blocks_range(e, u, u->tail.split, cut, h, hs, u->last_feat));
+  if (cut < n_out) {
+    e.chunk_tiles = late_wgs;
+    ISHAP_TRY(out_blocks_range(e, u, cut, n_out, h, hs, u->last_feat));
+  }
   ISHAP_TRY(forward_head(e, u, h, u->tail.N, u->tail.out));
   ISHAP_CHECK_HIP(hipEventRecord(u->ev_tail, u->side));
   u->tail_pending = true;
