@@ -270,7 +270,8 @@ bool exec_is_solo(const Exec& e) {
 
 bool small_map(int HW) {
   static const int on = [] { const char* v = getenv("ISHAP_LOCAL_GN"); return v ? atoi(v) : 1; }();
-  return on && HW <= (on == 2 ? 64 : 1024);      // 2: only the 8x8 maps
+  static const int max_hw = [] { const char* v = getenv("ISHAP_LOCAL_GN_HW"); return v ? atoi(v) : 1024; }();   // experiment: 4096 = the 64x64 maps too
+  return on && HW <= (on == 2 ? 64 : max_hw);      // 2: only the 8x8 maps
 }
 bool local_gn(int HW, int C) { return small_map(HW) && gn_local_fits(HW, C); }
 
