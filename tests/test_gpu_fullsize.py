@@ -87,7 +87,7 @@ def test_edits_stay_bitwise_repeatable_beside_a_loading_process(ds):
     """The in-launch hand-offs of the default path (GroupNorm rendezvous with its XCD-local record, the overlapped forward tail's
     fork / join) under UNEVEN load: a second PROCESS -- invisible to the library's tenancy guard -- keeps the chip busy in bursts
     while eight edits run; every one must reproduce the unloaded edit bit for bit and leave the device status word clear.
-    (tools/stress_repeat.py is the long form: 60 full-length edits alone and 60 beside the load, 0 differing.)"""
+    (tools/stress_repeat.py is the long form: 120 full-length edits alone and 120 beside the load with the deferred tail, 0 differing.)"""
     import subprocess
     import sys
     from ishapediting_amd import _lib
