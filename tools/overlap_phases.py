@@ -36,8 +36,9 @@ def main():
         between = kw.get("between")
         if between is not None:
             def b2():
-                between()
+                g = between()
                 ev[1].record()
+                return g
             kw["between"] = b2
         out = inner(self, model, x, t, **kw)
         ev[2].record()
