@@ -14,3 +14,24 @@ struct AttnArgs {
 };
 int attn_forward_launch(const AttnArgs& a, hipStream_t s);
 int attn_backward_launch(const AttnArgs& a, hipStream_t s);
+
+// Round 5: the body of an AttentionBlock on an 8x8 map (T = 64 tokens = one tile, head width 64) after its GroupNorm as ONE launch:
+// qkv = Wqkv xn + b (gd/unet.py:299-301), QKVAttentionLegacy per head (:337-354), and proj_out as per-head fp32 K slices that the
+// consuming GroupNorm pass adds up with proj's bias and the residual (the pending-tensor mechanism, common.h SlabSrc).
+struct Attn8Args {
+  const half_t* xn = nullptr;     // [N][64][C] GroupNorm output
+  const half_t* wqkv = nullptr;   // [3C rows (padded)][C], row = qkv channel (legacy order: head h at rows [h*192, h*192 + 192): q | k | v)
+  const float* bqkv = nullptr;    // [3C]
+  const half_t* wproj = nullptr;  // [C rows (padded)][C]
+  half_t* qkv = nullptr;          // [N][64][3C]   kept for the backward pass
+  half_t* aout = nullptr;         // [N][64][C]    kept for the backward pass
+  float* lse = nullptr;           // [N][heads][64]
+  float* slices = nullptr;        // [heads][N * 64][C] fp32: slice h = a_h Wproj[:, h*64 .. h*64+63]^T
+  unsigned* flags = nullptr;      // [N][heads][16], zero before the launch
+  unsigned* status = nullptr;     // device status word (common.h)
+  int spin_limit = 1 << 22;
+  int N = 1, C = 0, heads = 0;
+  float alpha = 1.f;              // 1 / sqrt(64)
+};
+bool attn8_applicable(int N, int T, int C, int d);
+int attn8_fused_launch(const Attn8Args& a, hipStream_t s);

@@ -528,3 +528,262 @@ int attn_backward_launch(const AttnArgs& a_in, hipStream_t s) {
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Round 5: qkv GEMM + attention + proj_out of an 8x8-map AttentionBlock in one launch (Attn8Args, attention.h).
+// A head is 192 qkv channels = A8_PARTS workgroups of 16 channels each (so that the 6.3 + 2.1 MB of weights stream through
+// ~200 CUs, not 16).  Part j of head h:
+//   1. qkv channels [h*192 + 16 j, +16) of all 64 tokens: 4 waves split K = C, fragments straight from global memory
+//      (igemm_skinny.hip's scheme), partial tiles meet in LDS in wave order; + bias, fp16, written to the qkv tensor with
+//      agent-scope (write-through) 8-byte stores; every wave drains its stores, then ONE lane raises the part's flag;
+//   2. waits for the 12 flags of its head (bounded spin: a give-up raises the status word and poisons the outputs), reads the
+//      head's q | k | v (24 KB) with agent-scope loads -- MI355X_MICROARCH.md hand-off table, first row: every store and every
+//      load of the handed-off bytes is sc1, the flag follows the storing waves' vmcnt(0) -- and computes the head's attention
+//      exactly as attn_fwd_kernel does (S^T = K Q^T, per-lane softmax state, O^T = V^T P^T through the transposed LDS read);
+//      every part does this redundantly (2 x 0.5 MFLOP): it is cheaper than a second exchange;
+//   3. its share of proj_out's K slice of this head: out_h[64][n] = a_h[64][64] Wproj[n][h*64 ..]^T for its 16-channel tiles
+//      (64 tiles of C = 1024 dealt over the 12 parts), fp32, into slices[h]: the consumer adds the 16 slices up.
+// Part 0 also writes a_h and lse for the backward pass.  All parts of all heads must be resident together: <= 256 workgroups
+// (the launcher), on a sequence that holds the device's rendezvous tenancy (the caller).
+constexpr int A8_PARTS = 12;
+
+__device__ __forceinline__ half4 ld8_agent(const half_t* p) {
+  const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __builtin_bit_cast(half4, b);
+}
+__device__ __forceinline__ void st8_agent(half_t* p, half4 v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#ifndef A8_NW
+#define A8_NW 4          // waves per workgroup: 4 / 8 / 16 -> 14.2 / 15.4 / 27 us per launch (C = 1024)
+#endif
+constexpr int A8_WAVES = A8_NW;
+constexpr int A8_SMEM = (A8_WAVES * 4 * 64 * 16 > 64 * (72 + 80 + 72) * 2 ? A8_WAVES * 4 * 64 * 16 : 64 * (72 + 80 + 72) * 2) + 16;
+constexpr int A8_WAVES_UNUSED = 0;     // phase 1: one 64-deep K-step per wave at C = 1024, every fragment load of the workgroup in flight at once
+__global__ __launch_bounds__(A8_WAVES * 64) void attn8_fused_kernel(Attn8Args a) {
+  constexpr int D = 64, RS = D + 8, VS = D + 16, KK = D / 32, DS = D / 16;
+  // one LDS block: phase 1's partial tiles red[wave][sub-tile][lane] (64 KB), then the K | V | A tiles (28 KB)
+  extern __shared__ __attribute__((aligned(16))) char a8_smem[];         // A8_SMEM bytes: the tiles, then one int
+  int& s_ok = *reinterpret_cast<int*>(a8_smem + A8_SMEM - 16);
+  f32x4 (*red)[4][64] = reinterpret_cast<f32x4 (*)[4][64]>(a8_smem);
+  half_t* const tK = reinterpret_cast<half_t*>(a8_smem);                  // [64][RS]
+  half_t* const tV = tK + 64 * RS;                                        // [64][VS]
+  half_t* const tA = tV + 64 * VS;                                        // [64][RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, col = lane & 15;
+  const int h = blockIdx.x / A8_PARTS, part = blockIdx.x - h * A8_PARTS, n = blockIdx.y;
+  const int C = a.C, ld3 = 3 * C;
+  const half_t* const xn = a.xn + (long long)n * 64 * C;
+  half_t* const qkv = a.qkv + (long long)n * 64 * ld3;
+  // ---- phase 3 operands first: this part's proj_out weight fragments (read-only data, their latency hides under phase 1) ----
+  const int ntile = C / 16;                                               // 16-channel output tiles of proj_out
+  const int tper = ntile / A8_PARTS, trem = ntile - tper * A8_PARTS;      // parts < trem take one tile more
+  const int t0 = part * tper + (part < trem ? part : trem), tcnt = tper + (part < trem ? 1 : 0);
+  constexpr int TMAX = 6;                                                 // C <= 1152 (launcher)
+  half8 wp[TMAX][KK];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t)
+    if (t < tcnt) {
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+        wp[t][kk] = *reinterpret_cast<const half8*>(a.wproj + (long long)((t0 + t) * 16 + col) * C + h * D + kk * 32 + 8 * g);
+    }
+  // ---- phase 1: 64 tokens x 16 qkv channels, K = C split over the four waves ----
+  const int n0 = h * 3 * D + part * 16;
+  {
+    const int ks = C / 64, per = (ks + A8_WAVES - 1) / A8_WAVES, s0 = wave * per, s1 = min(ks, s0 + per);
+    const half_t* wrow = a.wqkv + (long long)(n0 + col) * C + 8 * g;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    struct Frag { half8 w[2]; half8 x[4][2]; };
+    auto load = [&](int s, Frag& f) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) f.w[kk] = *reinterpret_cast<const half8*>(wrow + s * 64 + kk * 32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          f.x[j][kk] = *reinterpret_cast<const half8*>(xn + (long long)(j * 16 + col) * C + s * 64 + 8 * g + kk * 32);
+    };
+    // every fragment load of a batch of up to four K-steps is issued before the first MFMA (a wave has at most four steps at
+    // C = 1024 with four waves: one round trip instead of a chain of them -- the two-deep ring took 6.5 us here)
+    Frag ring[4];
+#ifdef A8_ABL_NO_PHASE1            // timing probe: wrong results
+    const int s1x = s0;
+#else
+    const int s1x = s1;
+#endif
+    for (int sb = s0; sb < s1x; sb += 4) {
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd)
+        if (sb + dd < s1x) load(sb + dd, ring[dd]);
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd)
+        if (sb + dd < s1x) {
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[dd].w[kk], ring[dd].x[j][kk], acc[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave][j][lane] = acc[j];
+    __syncthreads();
+    // wave j < 4 finishes token sub-tile j: lane = (token j*16 + col, channels n0 + 4g .. +3); partials add in wave order
+    if (wave < 4) {
+      const int j = wave;
+      f32x4 v = red[0][j][lane];
+#pragma unroll
+      for (int w = 1; w < A8_WAVES; ++w) v += red[w][j][lane];
+      v += *reinterpret_cast<const f32x4*>(a.bqkv + n0 + 4 * g);
+      const half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      st8_agent(qkv + (long long)(j * 16 + col) * ld3 + n0 + 4 * g, o);
+    }
+  }
+  if (tid == 0) s_ok = 1;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's stores are acknowledged ...
+  __syncthreads();                                                        // ... and so are every wave's (and red[] has been read)
+  unsigned* const flags = a.flags + ((long long)n * a.heads + h) * 16;
+  if (tid == 0) __hip_atomic_store(flags + part, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef A8_ABL_PHASE1_ONLY          // timing probe: wrong results
+  return;
+#endif
+  // ---- phase 2: the head's q | k | v ----
+  if (tid < A8_PARTS) {
+    int spins = 0;
+    unsigned f;
+    do {
+      f = __hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } while (f == 0u && ++spins < a.spin_limit);
+    if (f == 0u) {                                                        // a part never arrived: not co-resident (or it faulted)
+      __hip_atomic_store(a.status, (unsigned)ISHAP_DEV_CHAIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      s_ok = 0;
+    }
+  }
+  __syncthreads();
+  const bool ok = s_ok != 0;
+  const half_t* const hb = qkv + h * 3 * D;                               // head block of a token row: q | k | v
+  const int qw = wave & 3;                                                // waves 4 .. 15 mirror 0 .. 3 below and store nothing
+  const bool mine = wave < 4;
+  half8 qf[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const half_t* p = hb + (long long)(qw * 16 + col) * ld3 + kk * 32 + 8 * g;
+    const half4 lo = ld8_agent(p), hi = ld8_agent(p + 4);
+    qf[kk] = (half8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+  {
+    // K and V tiles: 64 rows x 16 eight-byte pieces each; ALL of a thread's pieces are requested before the first goes to LDS
+    constexpr int NP = (64 * 16 + A8_WAVES * 64 - 1) / (A8_WAVES * 64);
+    half4 kr[NP], vr[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int c = tid + i * A8_WAVES * 64;
+      if (c < 64 * 16) {
+        const int r = c >> 4, pc = c & 15;
+        kr[i] = ld8_agent(hb + (long long)r * ld3 + D + pc * 4);
+        vr[i] = ld8_agent(hb + (long long)r * ld3 + 2 * D + pc * 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int c = tid + i * A8_WAVES * 64;
+      if (c < 64 * 16) {
+        const int r = c >> 4, pc = c & 15;
+        *reinterpret_cast<half4*>(tK + r * RS + pc * 4) = kr[i];
+        *reinterpret_cast<half4*>(tV + r * VS + pc * 4) = vr[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (!mine) return;                                                      // waves 4 .. only helped with phase 1 and the staging (an ended wave no longer counts at s_barrier)
+  // S^T = K Q^T (row = key, column = this lane's query), softmax over the 64 keys, O^T = V^T P^T: attn_fwd_kernel's arithmetic
+  f32x4 st[4];
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    st[sub] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+      st[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_frag(tK, RS, sub * 16, kk * 32, lane), qf[kk], st[sub], 0, 0, 0);
+  }
+  float mx = -1e30f;
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st[sub][r] *= a.alpha; mx = fmaxf(mx, st[sub][r]); }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float rs = 0.f;
+  half8 pb[2];
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pv = __expf(st[sub][r] - mx);
+      rs += pv;
+      pb[sub >> 1][(sub & 1) * 4 + r] = (half_t)pv;
+    }
+  rs += __shfl_xor(rs, 16);
+  rs += __shfl_xor(rs, 32);
+  f32x4 ot[DS];
+#pragma unroll
+  for (int i = 0; i < DS; ++i) {
+    ot[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const half_t* vb = tV + (4 * g + (col >> 2)) * VS + i * 16 + 4 * (col & 3);
+      const half4 lo = lds_read_tr4(vb + (2 * pr) * 16 * VS);
+      const half4 hi = lds_read_tr4(vb + (2 * pr + 1) * 16 * VS);
+      const half8 va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      ot[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[pr], ot[i], 0, 0, 0);
+    }
+  }
+  const int q = qw * 16 + col;
+  const float inv = ok ? 1.f / rs : __builtin_nanf("");
+  if (mine) {
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+      const half4 o4 = {(half_t)(ot[i][0] * inv), (half_t)(ot[i][1] * inv), (half_t)(ot[i][2] * inv), (half_t)(ot[i][3] * inv)};
+      *reinterpret_cast<half4*>(tA + q * RS + i * 16 + 4 * g) = o4;         // a_h[q][d]: operand of the proj_out slice
+      if (part == 0) *reinterpret_cast<half4*>(a.aout + ((long long)n * 64 + q) * C + h * D + i * 16 + 4 * g) = o4;
+    }
+    if (part == 0 && g == 0) a.lse[((long long)n * a.heads + h) * 64 + q] = mx + __logf(rs);
+  }
+  __syncthreads();
+  if (!mine) return;
+  // ---- phase 3: out_h[token][n] for this part's 16-channel tiles; wave = token sub-tile ----
+  half8 af[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) af[kk] = ld_frag(tA, RS, qw * 16, kk * 32, lane);
+  float* const slice = a.slices + ((long long)h * a.N + n) * 64 * C;
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t)
+    if (t < tcnt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp[t][kk], af[kk], acc, 0, 0, 0);
+      // accumulator: row = channel (t0 + t) * 16 + 4g + r, column = token wave * 16 + col
+      *reinterpret_cast<f32x4*>(slice + (long long)(qw * 16 + col) * C + (t0 + t) * 16 + 4 * g) = acc;
+    }
+}
+
+bool attn8_applicable(int N, int T, int C, int d) {
+  static const int on = [] { const char* e = getenv("ISHAP_ATTN8"); return e ? atoi(e) : 1; }();      // -1.0 % per edit (profiles/round5_ab_attn8_fused.txt)
+  return on && T == 64 && d == 64 && C % 64 == 0 && C / 16 <= 6 * A8_PARTS && N * (C / 64) * A8_PARTS <= ishap_cu_count();
+}
+
+int attn8_fused_launch(const Attn8Args& a, hipStream_t s) {
+  ISHAP_REQUIRE(a.xn && a.wqkv && a.bqkv && a.wproj && a.qkv && a.aout && a.lse && a.slices && a.flags && a.status, "attn8: null argument");
+  ISHAP_REQUIRE(a.heads * 64 == a.C && a.C / 16 <= 6 * A8_PARTS && a.N * a.heads * A8_PARTS <= ishap_cu_count(), "attn8: shape / co-residency");
+  ISHAP_TRY(ishap_set_max_lds((const void*)attn8_fused_kernel, A8_SMEM));
+  Attn8Args b = a;
+  // polls before the wait for the head's other parts gives up (ISHAP_GN_SPIN_LIMIT: the test hook of the GroupNorm rendezvous)
+  static const int spin = [] { const char* e = getenv("ISHAP_GN_SPIN_LIMIT"); const int n = e ? atoi(e) : 0; return n > 0 ? n : (1 << 22); }();
+  b.spin_limit = spin;
+  hipLaunchKernelGGL(attn8_fused_kernel, dim3(a.heads * A8_PARTS, a.N), dim3(A8_WAVES * 64), A8_SMEM, s, b);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -532,6 +532,32 @@ static int attn_forward(Exec& e, AttnL& L, Tensor x, Tensor& y) {
   }
   Tensor qkv{nullptr, N, x.H, x.W, 3 * C};
   ISHAP_ALLOC(qkv.p, e, qkv.numel());
+  if (attn8_applicable(N, T, C, d) && L.qkv.kpad == C && L.proj.kpad == C && small_map(T) && exec_is_solo(e)) {
+    // 8x8 map: qkv GEMM + attention + proj_out in ONE launch (attention.hip, attn8_fused_kernel); proj_out leaves as per-head
+    // K slices that the next GroupNorm pass adds up with its bias and the residual x (ISHAP_ATTN8=1)
+    Tensor a = x;
+    ISHAP_ALLOC(a.p, e, x.numel());
+    float* slices = nullptr;
+    ISHAP_ALLOC(slices, e, (size_t)heads * N * T * C);
+    long long* fl = nullptr;
+    ISHAP_SALLOC(fl, e, (size_t)N * heads * 8);                  // 16 flags of 4 bytes per (image, head), zeroed with the statistics arena
+    y = x;
+    y.pend = SlabSrc{};
+    ISHAP_ALLOC(y.p, e, x.numel());
+    y.sums = nullptr;
+    y.pend.ws = slices; y.pend.nslab = heads; y.pend.zstride = (long long)N * T * C;
+    y.pend.bias = L.proj.bias; y.pend.res = x.p; y.pend.ldr = C;
+    if (!e.dry) {
+      Attn8Args g;
+      g.xn = nrm.p; g.wqkv = L.qkv.w; g.bqkv = L.qkv.bias; g.wproj = L.proj.w; g.qkv = qkv.p; g.aout = a.p; g.lse = lse;
+      g.slices = slices; g.flags = reinterpret_cast<unsigned*>(fl); g.status = ishap_status_word();
+      ISHAP_REQUIRE(g.status != nullptr, "device status word");
+      g.N = N; g.C = C; g.heads = heads; g.alpha = 1.f / sqrtf((float)d);
+      ISHAP_TRY(attn8_fused_launch(g, e.s));
+    }
+    L.sv.x = x; L.sv.qkv = qkv; L.sv.a = a; L.sv.stats = st; L.sv.lse = lse; L.sv.P = nullptr;
+    return 0;
+  }
   ISHAP_TRY(conv_op(e, nrm.p, N, x.H, x.W, C, L.qkv.w, L.qkv.kpad, 1, 3 * C, L.qkv.bias, nullptr, 0, qkv.p, 3 * C,
                     IG_OUT_F16, 0, 0));
   Tensor a = x;

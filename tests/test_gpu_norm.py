@@ -241,6 +241,39 @@ def test_rendezvous_give_up_raises_instead_of_using_zeros():
     assert int(bad) == 1 and int(rc) == -3 and int(again) == 0 and "rendezvous" in msg, line[0]
 
 
+_ATTN8_GIVE_UP = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from ishapediting_amd import synthetic, _lib
+from ishapediting_amd.unet import UNetModel
+from ishapediting_amd.unet_spec import UNetConfig
+cfg = UNetConfig(image_size=32, in_channels=6, model_channels=64, out_channels=12, num_res_blocks=1,
+                 attention_resolutions="16,8", channel_mult=(1, 2, 4), num_head_channels=64)
+m = UNetModel(cfg, torch.device("cuda", 0))
+m.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 91)))
+x = torch.randn(1, 6, 32, 32, generator=torch.Generator().manual_seed(21)).to("cuda")
+out = m(x, [617.0], feat_layer=-1)
+torch.cuda.synchronize()
+bad = int(torch.isnan(out).any())
+rc = int(_lib.lib().ishap_device_status())
+msg = _lib.lib().ishap_last_error().decode()
+print("RESULT", bad, rc, msg)
+"""
+
+
+def test_fused_attention_exchange_gives_up_loudly():
+    """The 8x8-map AttentionBlock kernel (csrc/attention.hip, attn8_fused_kernel) waits inside the launch for the other eleven
+    workgroups of its head.  One poll per wait (ISHAP_GN_SPIN_LIMIT=1; ISHAP_GN_PARTS=1 takes the GroupNorm rendezvous out of
+    the picture) makes that wait fail: the output is NaN and the next status check reports the chain time-out -- never a
+    silently wrong attention."""
+    env = dict(os.environ, ISHAP_GN_SPIN_LIMIT="1", ISHAP_GN_PARTS="1", ISHAP_ATTN8="1")
+    r = subprocess.run([sys.executable, "-c", _ATTN8_GIVE_UP % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+    assert line, r.stdout + r.stderr
+    bad, rc, msg = line[0].split(" ", 3)[1:]
+    assert int(bad) == 1 and int(rc) == -3 and "gave up waiting" in msg, line[0]
+
+
 # ------------------------------------------------------------------------------------------ like-for-like fp16 loops (G14)
 def tiny_args(Tn, w_time, feat_layer):
     return Namespace(clip_denoised=True, num_samples=1, batch_size=1, use_ddim=False, num_steps=Tn, image_size=16,
