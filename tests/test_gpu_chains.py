@@ -151,6 +151,10 @@ def test_smaller_batches_on_a_context_built_for_more():
         own.load_state_dict(sd)
         o_big, _ = big(x[:n], ts[:n], feat_layer=k, keep_for_backward=True)
         g_big = big.backward_input(cot[:n].contiguous())
+        # each context runs ALONE on the device (a context that arrives while another's work is in flight holds no rendezvous
+        # tenancy and takes the wait-free kernel forms: the same values for GroupNorm, the three-launch form -- equal to summation
+        # order only -- for the 8x8 attention block of round 5)
+        torch.cuda.synchronize()
         o_own, _ = own(x[:n], ts[:n], feat_layer=k, keep_for_backward=True)
         g_own = own.backward_input(cot[:n].contiguous())
         torch.cuda.synchronize()
