@@ -35,3 +35,23 @@ struct Attn8Args {
 };
 bool attn8_applicable(int N, int T, int C, int d);
 int attn8_fused_launch(const Attn8Args& a, hipStream_t s);
+
+// The backward twin (round 5): d proj_out -> attention backward (both roles) -> d qkv of an 8x8-map AttentionBlock in one launch.
+// No workgroup waits for another: every one of a head's 12 workgroups recomputes the head's dA (a 64 x 64 x C product) and its
+// attention backward (T = 64: one tile) itself and differs only in the columns of the input-gradient slice it produces.
+struct Attn8BwdArgs {
+  const half_t* dy = nullptr;      // [N][64][C] gradient arriving at proj_out's output
+  const half_t* wprojT = nullptr;  // proj_out's input-gradient operand [C rows (c_in)][ldp] (ConvW::wT)
+  const half_t* wqkvT = nullptr;   // qkv's input-gradient operand [C rows (c_in)][ldq]
+  int ldp = 0, ldq = 0;
+  const half_t* qkv = nullptr;     // forward tensors (AttnSaved)
+  const half_t* aout = nullptr;
+  const float* lse = nullptr;
+  half_t* dA = nullptr;            // [N][64][C] scratch: every part of a head writes the same values
+  half_t* dqkv = nullptr;          // [N][64][3C] scratch, likewise
+  float* slices = nullptr;         // [heads][N * 64][C] fp32: slice h = dqkv_h Wqkv[h*192 .. +191][:]  (the gradient at the GroupNorm output)
+  int N = 1, C = 0, heads = 0;
+  float alpha = 1.f;
+};
+bool attn8_bwd_applicable(int N, int T, int C, int d);
+int attn8_bwd_fused_launch(const Attn8BwdArgs& a, hipStream_t s);

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256 * TEAMS) void attn_fwd_kernel(const void* h_qkv
 // Returns false for the teams that are done (they have passed every barrier of the merge).
 template <int NA, int TEAMS>
 __device__ __forceinline__ bool attn_bwd_merge(f32x4 (&acc)[NA], int team, int tid, float* mrg) {
-  if (blockDim.x == 256) return true;          // a single tile is launched with one team
+  if (blockDim.x == 256 || TEAMS == 1) return true;          // a single tile is launched with one team
   f32x4* m4 = reinterpret_cast<f32x4*>(mrg);   // [slot][NA][256] 16-byte entries
   if (TEAMS == 4) {
     if (team >= 2) {
@@ -784,6 +784,135 @@ int attn8_fused_launch(const Attn8Args& a, hipStream_t s) {
   static const int spin = [] { const char* e = getenv("ISHAP_GN_SPIN_LIMIT"); const int n = e ? atoi(e) : 0; return n > 0 ? n : (1 << 22); }();
   b.spin_limit = spin;
   hipLaunchKernelGGL(attn8_fused_kernel, dim3(a.heads * A8_PARTS, a.N), dim3(A8_WAVES * 64), A8_SMEM, s, b);
+  ISHAP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Round 5: backward of an 8x8-map AttentionBlock after its proj_out gradient arrives, one launch (Attn8BwdArgs, attention.h).
+// Workgroup (head h, part j), 512 threads:
+//   A. dA_h[token][c] = sum_n dY[token][n] WprojT[h*64 + c][n]: wave w owns channel tile w & 3 and K half w >> 2, fragments straight
+//      from global memory in batches of four K-steps, the two halves meet in LDS; fp16 (the stored gradient map of the three-launch
+//      form) to the dA scratch -- all 12 parts of a head write the same 8 KB;
+//   B. waves 0-3: attention backward of the head's single tile, both roles one after the other, by the SAME device functions the
+//      stand-alone kernel runs (attn_bwd_dq_body / attn_bwd_dkv_body with one team): they read q, k, v, a, lse and this workgroup's
+//      own dA, and write dq | dk | dv to the dqkv scratch (again the same bytes from every part);
+//   C. this part's 16-column tiles of the head's K slice of d(GroupNorm output): out_h[token][c] = sum_{n in head} dqkv[token][n]
+//      WqkvT[c][n] (K = 192), fp32, left as a pending slice for the group-local GroupNorm-backward kernel.
+// Nothing is handed between workgroups, so the kernel needs no tenancy and no bounded wait.
+constexpr int A8B_PARTS = 12;
+__global__ __launch_bounds__(512) void attn8_bwd_fused_kernel(Attn8BwdArgs a) {
+  constexpr int D = 64, RS = D + 8;
+  extern __shared__ __attribute__((aligned(16))) char a8b_smem[];          // 32 KB: phase A partials, then the bodies' tiles
+  f32x4 (*red)[4][64] = reinterpret_cast<f32x4 (*)[4][64]>(a8b_smem);     // [4 channel tiles][4 token sub-tiles][64 lanes]: K half 1's partials
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, col = lane & 15;
+  const int h = blockIdx.x / A8B_PARTS, part = blockIdx.x - h * A8B_PARTS, n = blockIdx.y;
+  const int C = a.C, ld3 = 3 * C;
+  // ---- phase A ----
+  {
+    const int ct = wave & 3, kh = wave >> 2;
+    const int ks = C / 64, half_steps = (ks + 1) / 2, s0 = kh * half_steps, s1 = min(ks, s0 + half_steps);
+    const half_t* wrow = a.wprojT + (long long)(h * D + ct * 16 + col) * a.ldp + 8 * g;
+    const half_t* yrow = a.dy + (long long)n * 64 * C + (long long)col * C + 8 * g;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    struct Frag { half8 w[2]; half8 x[4][2]; };
+    Frag ring[4];
+    for (int sb = s0; sb < s1; sb += 4) {
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd)
+        if (sb + dd < s1) {
+          const int s = sb + dd;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) ring[dd].w[kk] = *reinterpret_cast<const half8*>(wrow + s * 64 + kk * 32);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+              ring[dd].x[j][kk] = *reinterpret_cast<const half8*>(yrow + (long long)(j * 16) * C + s * 64 + kk * 32);
+        }
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd)
+        if (sb + dd < s1) {
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[dd].w[kk], ring[dd].x[j][kk], acc[j], 0, 0, 0);
+        }
+    }
+    if (kh == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[ct][j][lane] = acc[j];
+    }
+    __syncthreads();
+    if (kh == 0) {
+      half_t* drow = a.dA + (long long)n * 64 * C + h * D + ct * 16 + 4 * g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 v = acc[j] + red[ct][j][lane];                       // K half 0 + K half 1 (fixed order)
+        const half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<half4*>(drow + (long long)(j * 16 + col) * C) = o;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this workgroup's dA is in memory before anyone reads it back
+  __syncthreads();
+  // ---- phase C operands: requested now, used after phase B.  Waves 0-3 take the even tiles of the part, waves 4-7 the odd ones ----
+  const int role = wave >> 2, ms = wave & 3;
+  const int ntile = C / 16;
+  const int tper = ntile / A8B_PARTS, trem = ntile - tper * A8B_PARTS;
+  const int t0 = part * tper + (part < trem ? part : trem), tcnt = tper + (part < trem ? 1 : 0);
+  constexpr int TMAX = 3, KC = 3 * D / 32;                                // <= 6 tiles per part, every other one per wave group; six 32-deep K pieces
+  half8 wq[TMAX][KC];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t)
+    if (2 * t + role < tcnt) {
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk)
+        wq[t][kk] = *reinterpret_cast<const half8*>(a.wqkvT + (long long)((t0 + 2 * t + role) * 16 + col) * a.ldq + h * 3 * D + kk * 32 + 8 * g);
+    }
+  // ---- phase B: the stand-alone kernel's two roles side by side, one team each (both bodies pass exactly two barriers) ----
+  AttnArgs aa;
+  aa.qkv = a.qkv; aa.out = const_cast<half_t*>(a.aout); aa.dout = a.dA; aa.dqkv = a.dqkv; aa.lse = const_cast<float*>(a.lse);
+  aa.N = a.N; aa.T = 64; aa.C = C; aa.heads = a.heads; aa.d = D; aa.alpha = a.alpha;
+  half_t* const s0p = reinterpret_cast<half_t*>(a8b_smem) + role * (2 * 64 * RS + 256);      // + 256 halfs = the dK/dV role's 128 floats
+  half_t* const s1p = s0p + 64 * RS;
+  float* const sD = reinterpret_cast<float*>(s1p + 64 * RS);
+  float* const mrg = reinterpret_cast<float*>(a8b_smem);                  // unused with one team
+  if (role == 0) attn_bwd_dq_body<D, 1>(aa, n, 0, h, 0, s0p, s1p, mrg);
+  else attn_bwd_dkv_body<D, 1>(aa, n, 0, h, 0, s0p, s1p, sD, mrg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---- phase C: wave = (token sub-tile, tile parity) ----
+  half8 df[KC];
+  const half_t* drow = a.dqkv + ((long long)n * 64 + ms * 16 + col) * ld3 + h * 3 * D + 8 * g;
+#pragma unroll
+  for (int kk = 0; kk < KC; ++kk) df[kk] = *reinterpret_cast<const half8*>(drow + kk * 32);
+  float* const slice = a.slices + ((long long)h * a.N + n) * 64 * C;
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t)
+    if (2 * t + role < tcnt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[t][kk], df[kk], acc, 0, 0, 0);
+      *reinterpret_cast<f32x4*>(slice + (long long)(ms * 16 + col) * C + (t0 + 2 * t + role) * 16 + 4 * g) = acc;
+    }
+}
+
+bool attn8_bwd_applicable(int N, int T, int C, int d) {
+  static const int on = [] { const char* e = getenv("ISHAP_ATTN8_BWD"); return e ? atoi(e) : 0; }();
+  return on && T == 64 && d == 64 && C % 64 == 0 && C / 16 <= 6 * A8B_PARTS;
+}
+
+int attn8_bwd_fused_launch(const Attn8BwdArgs& a, hipStream_t s) {
+  ISHAP_REQUIRE(a.dy && a.wprojT && a.wqkvT && a.qkv && a.aout && a.lse && a.dA && a.dqkv && a.slices, "attn8 backward: null argument");
+  ISHAP_REQUIRE(a.heads * 64 == a.C && a.C / 16 <= 6 * A8B_PARTS && a.ldp >= a.C && a.ldq >= 3 * a.C, "attn8 backward: shape");
+  constexpr int smem = 40 * 1024;            // phase A's partial tiles (16 KB), then two roles x (two 64 x 72 fp16 tiles + 128 floats)
+  ISHAP_TRY(ishap_set_max_lds((const void*)attn8_bwd_fused_kernel, smem));
+  hipLaunchKernelGGL(attn8_bwd_fused_kernel, dim3(a.heads * A8B_PARTS, a.N), dim3(512), smem, s, a);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

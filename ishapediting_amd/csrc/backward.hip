@@ -120,6 +120,34 @@ static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx, Prefet
   const Tensor& x = sv.x;
   const int N = x.N, T = x.H * x.W, C = L.C, heads = L.heads, d = C / heads;
   const float alpha = 1.f / sqrtf((float)d);
+  if (attn8_bwd_applicable(N, T, C, d) && local_gn_bwd(T, C, GB_SAME) && L.proj.cout_pad >= C && L.qkv.cout_pad >= 3 * C) {
+    // 8x8 map: d proj_out + attention backward + d qkv in ONE launch (attention.hip, attn8_bwd_fused_kernel); the gradient at the
+    // GroupNorm output leaves as per-head K slices that the group-local GroupNorm-backward kernel adds up (ISHAP_ATTN8_BWD)
+    Tensor dA{nullptr, N, x.H, x.W, C};
+    ISHAP_ALLOC(dA.p, e, dA.numel());
+    Tensor dqkv{nullptr, N, x.H, x.W, 3 * C};
+    ISHAP_ALLOC(dqkv.p, e, dqkv.numel());
+    float* slices = nullptr;
+    ISHAP_ALLOC(slices, e, (size_t)heads * N * T * C);
+    Tensor dn{nullptr, N, x.H, x.W, C};
+    ISHAP_ALLOC(dn.p, e, dn.numel());
+    dn.pend.ws = slices; dn.pend.nslab = heads; dn.pend.zstride = (long long)N * T * C;
+    if (!e.dry) {
+      Attn8BwdArgs g;
+      g.dy = dy.p; g.wprojT = L.proj.wT; g.ldp = L.proj.cout_pad; g.wqkvT = L.qkv.wT; g.ldq = L.qkv.cout_pad;
+      g.qkv = sv.qkv.p; g.aout = sv.a.p; g.lse = sv.lse; g.dA = dA.p; g.dqkv = dqkv.p; g.slices = slices;
+      g.N = N; g.C = C; g.heads = heads; g.alpha = alpha;
+      ISHAP_TRY(attn8_bwd_fused_launch(g, e.s));
+    }
+    dx = x;
+    GnBwdArgs g;
+    g.x = x.p; g.stats = sv.stats; g.gamma = L.n.gamma; g.beta = L.n.beta;
+    g.N = N; g.H = x.H; g.W = x.W; g.C = C; g.film = 0; g.act = 0; g.gmode = GB_SAME;
+    ISHAP_ALLOC(dx.p, e, x.numel());
+    g.g = dn.p; g.add = dy.p; g.dx = dx.p;
+    g.pf = next;
+    return gn_bwd_local_op(e, g, dn);
+  }
   Tensor dA;
   ISHAP_TRY(dgrad_op(e, L.proj, dy, dA, C));
   Tensor dqkv{nullptr, N, x.H, x.W, 3 * C};
