@@ -11,7 +11,18 @@ struct AttnArgs {
   int N = 1, T = 0, C = 0, heads = 0, d = 0;
   float alpha = 1.f;             // 1/sqrt(d)  (= s*s with s = d^-1/4, unet.py:348-351)
   int xcd_map = 1;               // XCD-aware workgroup -> (tile, head) mapping (attention.hip: attn_xcd_item); set by the launchers
+  // forward only, proj_parts > 0 (round 5): proj_out (unet.py:304) leaves the attention launch as per-head fp32 K slices
+  // slices[h][n * T + q][c] = sum_d a[q][h*d + d'] Wproj[c][h*d + d'] -- the consuming GroupNorm pass adds the heads up with proj's
+  // bias and the residual (common.h SlabSrc).  Every query tile is then computed by `proj_parts` workgroups that differ only in
+  // the C / proj_parts output columns of the slice they produce (the attention itself is recomputed: T <= 256, it is latency).
+  const half_t* wproj = nullptr; // [C rows (c_out, padded)][ldp]
+  int ldp = 0;
+  float* slices = nullptr;       // [heads][N * T][C]
+  int proj_parts = 0;
 };
+// proj_parts with which attn_forward_launch emits proj_out as per-head slices for this shape, 0 = it cannot
+// (ISHAP_ATTN_PROJ: 0 = never, the default -- measured, no gain; 1 = wherever built; 256 = only up to 256 tokens)
+int attn_proj_parts(int N, int T, int C, int d);
 int attn_forward_launch(const AttnArgs& a, hipStream_t s);
 int attn_backward_launch(const AttnArgs& a, hipStream_t s);
 

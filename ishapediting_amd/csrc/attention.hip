@@ -79,7 +79,11 @@ __device__ __forceinline__ int attn_xcd_item(int lin, int total, int on) {
 // four-wave workgroup per CU (T = 1024, 8 heads: 128 workgroups) every global -> LDS -> MFMA round trip of a tile was
 // exposed; two waves per SIMD on interleaved tiles hide them (T = 1024: 19.9 -> ~11 us).
 // TEAMS = 2 or 4 (round 3: four teams = 1024 threads when the sequence has >= 8 key tiles, so that a team walks T / 256 of them)
-template <int D, int TEAMS>
+// NT > 0 (round 5, T <= 256): proj_out as per-head fp32 slices from the same launch (attention.h, AttnArgs::proj_parts).  The query
+// tile's a (64 x D, fp16 like the tensor the backward reads) goes through LDS to all 4 * TEAMS waves; wave w multiplies the 16 queries
+// of block w & 3 with NT 16-row panels of Wproj[:, h D .. h D + D) -- A fragments straight from global memory, requested before the
+// team merge -- and stores slice^T accumulators, whose 4 rows per lane are 4 consecutive output channels of one query (16-byte stores).
+template <int D, int TEAMS, int NT = 0>
 __global__ __launch_bounds__(256 * TEAMS) void attn_fwd_kernel(const void* h_qkv, void* h_out, float* h_lse, int h_T, int h_C, AttnArgs a0) {
   // leading scalar parameters are preloaded into SGPRs at dispatch (common.h, IgemmHot); the block `a0` arrives by s_load
   AttnArgs a = a0;
@@ -98,7 +102,10 @@ __global__ __launch_bounds__(256 * TEAMS) void attn_fwd_kernel(const void* h_qkv
   half_t* const sV = sV2 + team * 64 * VS;
   // item = tile + ntile * (head + heads * image)
   const int item = attn_xcd_item(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z, a0.xcd_map);
-  const int q0 = (item % (int)gridDim.x) * 64, h = (item / (int)gridDim.x) % (int)gridDim.y, n = item / (int)(gridDim.x * gridDim.y);
+  constexpr bool PROJ = NT > 0;
+  // PROJ: gridDim.x = tiles * parts, the parts of a tile adjacent (they read the same q, K and V)
+  const int xi = item % (int)gridDim.x, part = PROJ ? xi % a0.proj_parts : 0;
+  const int q0 = (PROJ ? xi / a0.proj_parts : xi) * 64, h = (item / (int)gridDim.x) % (int)gridDim.y, n = item / (int)(gridDim.x * gridDim.y);
   const int ld = 3 * a.C;
   const int g = lane >> 4, col = lane & 15;
   const half_t* base = a.qkv + (long long)n * a.T * ld + h * 3 * D;
@@ -174,6 +181,17 @@ __global__ __launch_bounds__(256 * TEAMS) void attn_fwd_kernel(const void* h_qkv
       }
     }
   }
+  // PROJ: this wave's Wproj fragments, in flight across the merge
+  const int pw = threadIdx.x >> 6, qb = pw & 3;
+  const int c_base = PROJ ? (part * 4 * TEAMS + (pw >> 2) * 4) * NT * 4 : 0;      // (part, wave >> 2) -> NT * 16 consecutive output channels
+  half8 wf[PROJ ? NT : 1][KK];
+  if constexpr (PROJ) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+        wf[t][kk] = *reinterpret_cast<const half8*>(a0.wproj + (long long)(c_base + t * 16 + col) * a0.ldp + h * D + kk * 32 + 8 * g);
+  }
   // merge the teams' states (teams 1 .. -> LDS -> team 0, in team order): m' = max, sums rescaled by exp(m - m')
   __syncthreads();                           // every team is done with its tiles: the states go where the tiles were
   if (team > 0) {
@@ -186,28 +204,48 @@ __global__ __launch_bounds__(256 * TEAMS) void attn_fwd_kernel(const void* h_qkv
       for (int r = 0; r < 4; ++r) dst[2 + i * 4 + r] = ot[i][r];
   }
   __syncthreads();
-  if (team > 0) return;
+  if (!PROJ && team > 0) return;
+  // PROJ: the tile's a for every wave, behind the merge states (which team 0 is still reading)
+  half_t* const sO = reinterpret_cast<half_t*>(attn_smem + (TEAMS - 1) * 256 * MRG * 4);
+  static_assert(!PROJ || (TEAMS - 1) * 256 * MRG * 4 + 64 * RS * 2 <= TEAMS * 64 * (RS + VS) * 2, "the output tile fits behind the merge states");
+  if (team == 0) {
 #pragma unroll
-  for (int t = 1; t < TEAMS; ++t) {
-    const float* src = mrg + ((t - 1) * 256 + tid) * MRG;
-    const float m1 = src[0], l1 = src[1];
-    const float mn = fmaxf(m, m1);
-    const float c0 = __expf(m - mn), c1 = __expf(m1 - mn);
-    lsum = lsum * c0 + l1 * c1;
+    for (int t = 1; t < TEAMS; ++t) {
+      const float* src = mrg + ((t - 1) * 256 + tid) * MRG;
+      const float m1 = src[0], l1 = src[1];
+      const float mn = fmaxf(m, m1);
+      const float c0 = __expf(m - mn), c1 = __expf(m1 - mn);
+      lsum = lsum * c0 + l1 * c1;
 #pragma unroll
-    for (int i = 0; i < DS; ++i)
+      for (int i = 0; i < DS; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ot[i][r] = ot[i][r] * c0 + src[2 + i * 4 + r] * c1;
-    m = mn;
+        for (int r = 0; r < 4; ++r) ot[i][r] = ot[i][r] * c0 + src[2 + i * 4 + r] * c1;
+      m = mn;
+    }
+    const int q = q0 + wave * 16 + col;
+    const float inv = 1.f / lsum;
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+      const half4 o4 = {(half_t)(ot[i][0] * inv), (half_t)(ot[i][1] * inv), (half_t)(ot[i][2] * inv), (half_t)(ot[i][3] * inv)};
+      if (part == 0) *reinterpret_cast<half4*>(a.out + ((long long)n * a.T + q) * a.C + h * D + i * 16 + 4 * g) = o4;
+      if constexpr (PROJ) *reinterpret_cast<half4*>(sO + (wave * 16 + col) * RS + i * 16 + 4 * g) = o4;
+    }
+    if (g == 0 && part == 0) a.lse[((long long)n * a.heads + h) * a.T + q] = m + __logf(lsum);
   }
-  const int q = q0 + wave * 16 + col;
-  const float inv = 1.f / lsum;
+  if constexpr (PROJ) {
+    __syncthreads();
+    half8 of[KK];
 #pragma unroll
-  for (int i = 0; i < DS; ++i) {
-    const half4 o4 = {(half_t)(ot[i][0] * inv), (half_t)(ot[i][1] * inv), (half_t)(ot[i][2] * inv), (half_t)(ot[i][3] * inv)};
-    *reinterpret_cast<half4*>(a.out + ((long long)n * a.T + q) * a.C + h * D + i * 16 + 4 * g) = o4;
+    for (int kk = 0; kk < KK; ++kk) of[kk] = ld_frag(sO, RS, qb * 16, kk * 32, lane);
+    float* dst = a0.slices + (((long long)h * a.N + n) * a.T + q0 + qb * 16 + col) * a.C + c_base + 4 * g;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][kk], of[kk], acc, 0, 0, 0);
+      *reinterpret_cast<f32x4*>(dst + t * 16) = acc;          // rows 4g .. 4g+3 of slice^T = 4 consecutive channels of query `col`
+    }
   }
-  if (g == 0) a.lse[((long long)n * a.heads + h) * a.T + q] = m + __logf(lsum);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -475,6 +513,29 @@ static int check_attn(const AttnArgs& a) {
   return 0;
 }
 
+// teams of the forward launch: four once a team of two would walk >= 4 key tiles (ISHAP_ATTN_TEAMS=2 keeps two; =4: four from 4 tiles on)
+static int attn_fwd_teams(int ntile) {
+  static const int teams_env = [] { const char* e = getenv("ISHAP_ATTN_TEAMS"); return e ? atoi(e) : 0; }();
+  const bool four = teams_env == 2 ? false : (teams_env == 4 ? ntile >= 4 : ntile >= 8);
+  return four ? 4 : 2;
+}
+static bool attn_proj_nt_built(int teams, int nt) { return teams == 2 ? (nt >= 1 && nt <= 4) || nt == 6 || nt == 8 : nt >= 1 && nt <= 4; }
+
+int attn_proj_parts(int N, int T, int C, int d) {
+  static const int on = [] { const char* e = getenv("ISHAP_ATTN_PROJ"); return e ? atoi(e) : 0; }();
+  // NOT the default (ISHAP_ATTN_PROJ=1 | 256 = only up to 256 tokens): measured in situ (profiles/round5_ab_attn_proj.txt) the launch
+  // it removes (6.7 us + a boundary) is paid back by the slices -- heads x the tensor in fp32: 9.4 MB at 16 x 16, 16.8 MB at 32 x 32 --
+  // which the attention launch writes (6.1 -> 11.4 us, 12.3 -> 18.8 us) and the consuming GroupNorm pass reads (+1.2 ... 4 us).
+  // Shapes: batch 1-2 on maps up to 16 x 16 in four parts (48 -> 192 workgroups at 12 heads), batch 1 on the 32 x 32 maps in two
+  // (128 -> 256 workgroups).  The 8 x 8 maps take attn8_fused_kernel when it applies and come here otherwise.
+  if (!on || d != 64 || T % 64 != 0) return 0;
+  const int parts = T <= 256 ? 4 : 2;
+  if (T <= 256 ? N * T > 512 : (T != 1024 || N != 1 || on == 256)) return 0;
+  const int per_wave = parts * attn_fwd_teams(T / 64) * 16;
+  if (C % per_wave != 0 || !attn_proj_nt_built(attn_fwd_teams(T / 64), C / per_wave)) return 0;
+  return parts;
+}
+
 static int attn_xcd_on() {
   static const int on = [] { const char* e = getenv("ISHAP_ATTN_XCD"); return e ? atoi(e) : 1; }();
   return on;
@@ -485,10 +546,8 @@ int attn_forward_launch(const AttnArgs& a_in, hipStream_t s) {
   a.xcd_map = attn_xcd_on();
   ISHAP_TRY(check_attn(a));
   dim3 g(a.T / 64, a.heads, a.N);
-  // four teams once a team of two would walk >= 4 key tiles (ISHAP_ATTN_TEAMS=2 keeps two; =4 forces four from 4 tiles on)
-  static const int teams_env = [] { const char* e = getenv("ISHAP_ATTN_TEAMS"); return e ? atoi(e) : 0; }();
   const int ntile = a.T / 64;
-  const bool four = teams_env == 2 ? false : (teams_env == 4 ? ntile >= 4 : ntile >= 8);
+  const bool four = attn_fwd_teams(ntile) == 4;
 #define ATTN_FWD(Dv, TM)                                                                                          \
   do {                                                                                                            \
     auto kern = attn_fwd_kernel<Dv, TM>;                                                                          \
@@ -496,7 +555,28 @@ int attn_forward_launch(const AttnArgs& a_in, hipStream_t s) {
     ISHAP_TRY(ishap_set_max_lds((const void*)kern, smem));                                                        \
     hipLaunchKernelGGL(kern, g, dim3(256 * TM), smem, s, (const void*)a.qkv, (void*)a.out, a.lse, a.T, a.C, a);    \
   } while (0)
-  if (a.d == 64) { if (four) ATTN_FWD(64, 4); else ATTN_FWD(64, 2); }
+  if (a.proj_parts > 0) {
+    // proj_out as per-head slices: every wave NT = C / (parts * teams * 16) panels of 16 output channels
+    const int teams = four ? 4 : 2;
+    ISHAP_REQUIRE(a.d == 64 && a.wproj && a.slices && a.ldp >= a.C && a.C % (a.proj_parts * teams * 16) == 0, "attention + proj_out: shape");
+    g.x = ntile * a.proj_parts;
+    const int nt = a.C / (a.proj_parts * teams * 16);
+    ISHAP_REQUIRE(attn_proj_nt_built(teams, nt), "attention + proj_out: channel count");
+#define ATTN_FWD_PROJ(TM, NTv)                                                                                    \
+  do {                                                                                                            \
+    auto kern = attn_fwd_kernel<64, TM, NTv>;                                                                     \
+    const int smem = TM * 64 * ((64 + 8) + (64 + 16)) * (int)sizeof(half_t);                                      \
+    ISHAP_TRY(ishap_set_max_lds((const void*)kern, smem));                                                        \
+    hipLaunchKernelGGL(kern, g, dim3(256 * TM), smem, s, (const void*)a.qkv, (void*)a.out, a.lse, a.T, a.C, a);    \
+  } while (0)
+    if (four) {
+      if (nt == 1) ATTN_FWD_PROJ(4, 1); else if (nt == 2) ATTN_FWD_PROJ(4, 2); else if (nt == 3) ATTN_FWD_PROJ(4, 3); else ATTN_FWD_PROJ(4, 4);
+    } else {
+      if (nt == 1) ATTN_FWD_PROJ(2, 1); else if (nt == 2) ATTN_FWD_PROJ(2, 2); else if (nt == 3) ATTN_FWD_PROJ(2, 3);
+      else if (nt == 4) ATTN_FWD_PROJ(2, 4); else if (nt == 6) ATTN_FWD_PROJ(2, 6); else ATTN_FWD_PROJ(2, 8);
+    }
+#undef ATTN_FWD_PROJ
+  } else if (a.d == 64) { if (four) ATTN_FWD(64, 4); else ATTN_FWD(64, 2); }
   else { if (four) ATTN_FWD(32, 4); else ATTN_FWD(32, 2); }
 #undef ATTN_FWD
   ISHAP_CHECK_HIP(hipGetLastError());

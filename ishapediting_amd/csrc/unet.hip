@@ -562,17 +562,30 @@ static int attn_forward(Exec& e, AttnL& L, Tensor x, Tensor& y) {
                     IG_OUT_F16, 0, 0));
   Tensor a = x;
   ISHAP_ALLOC(a.p, e, x.numel());
+  // proj_out from the attention launch as per-head slices (attention.hip, attn_fwd_kernel<.., NT>): small maps only -- the
+  // consumer must be a GroupNorm pass that adds pending slices up (opt-in: ISHAP_ATTN_PROJ=1)
+  const int proj_parts = L.proj.kpad >= C && small_map(T) ? attn_proj_parts(N, T, C, d) : 0;
+  const bool proj_slices = proj_parts > 0;
+  float* slices = nullptr;
+  if (proj_slices) ISHAP_ALLOC(slices, e, (size_t)heads * N * T * C);
   if (!e.dry) {
     // fused flash-style attention: w = softmax((q*s)^T (k*s)), a = w v   (unet.py:347-353)
     AttnArgs g;
     g.qkv = qkv.p; g.out = a.p; g.lse = lse; g.N = N; g.T = T; g.C = C; g.heads = heads; g.d = d;
     g.alpha = 1.f / sqrtf((float)d);
+    if (proj_slices) { g.wproj = L.proj.w; g.ldp = L.proj.kpad; g.slices = slices; g.proj_parts = proj_parts; }
     ISHAP_TRY(attn_forward_launch(g, e.s));
   }
   y = x;
   y.pend = SlabSrc{};
   ISHAP_ALLOC(y.p, e, x.numel());
   y.sums = nullptr;
+  if (proj_slices) {
+    y.pend.ws = slices; y.pend.nslab = heads; y.pend.zstride = (long long)N * T * C;
+    y.pend.bias = L.proj.bias; y.pend.res = x.p; y.pend.ldr = C;
+    L.sv.x = x; L.sv.qkv = qkv; L.sv.a = a; L.sv.stats = st; L.sv.lse = lse; L.sv.P = nullptr;
+    return 0;
+  }
   const bool nosum = small_map(T);
   if (!nosum) ISHAP_SALLOC(y.sums, e, (size_t)N * C * 2);
   ISHAP_TRY(conv_op(e, a.p, N, x.H, x.W, C, L.proj.w, L.proj.kpad, 1, C, L.proj.bias, x.p, C, y.p, C, IG_OUT_F16, 0, 0,

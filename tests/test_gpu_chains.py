@@ -604,10 +604,11 @@ def test_runtime_switches_keep_the_results(tmp_path):
             "ISHAP_GN_XCD=0": {"ISHAP_GN_XCD": "0"}, "ISHAP_GN_XCD=2": {"ISHAP_GN_XCD": "2"},
             "ISHAP_IG4_NOUTER=0": {"ISHAP_IG4_NOUTER": "0"}, "ISHAP_IG4_NOUTER=1": {"ISHAP_IG4_NOUTER": "1"},
             "ISHAP_EVENT_FENCE=1": {"ISHAP_EVENT_FENCE": "1"}, "ISHAP_ATTN8=0": {"ISHAP_ATTN8": "0"},
-            "ISHAP_ATTN8_BWD=1": {"ISHAP_ATTN8_BWD": "1"}}
+            "ISHAP_ATTN8_BWD=1": {"ISHAP_ATTN8_BWD": "1"}, "ISHAP_ATTN_PROJ=1": {"ISHAP_ATTN_PROJ": "1"},
+            "ISHAP_ATTN8=0 ISHAP_ATTN_PROJ=1": {"ISHAP_ATTN8": "0", "ISHAP_ATTN_PROJ": "1"}}
     res = {}
     for name, env in runs.items():
-        path = str(tmp_path / (name.replace("=", "_") + ".npz"))
+        path = str(tmp_path / (name.replace("=", "_").replace(" ", "_") + ".npz"))
         e = dict(os.environ)
         e.update(env)
         r = subprocess.run([sys.executable, "-c", _SWITCH_WORKER.format(root=root, out=path)], env=e, capture_output=True,

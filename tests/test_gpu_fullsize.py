@@ -591,11 +591,13 @@ def test_igemm4_against_igemm2_on_every_full_size_shape(tmp_path):
     products, another summation order inside fp32 accumulators: relative L2 <= 2e-3 forward, 5e-3 gradient (fp16 maps; measured 0.9e-3 / 1.1e-3 / 1.9e-3 -- the two-team form alone moves them by 0.5-1.4e-3); the two-team
     form off (ISHAP_IG4_TEAMS=0) likewise, and the sliced 8x8-map launches back on conv3_small (ISHAP_IG4_W8=0) / the sliced
     long-K 1x1 GEMMs of that level back on the skinny kernel (ISHAP_G1_SLICES=0); the attention backward of the 32^2 and 16^2
-    levels with four teams instead of two (ISHAP_ATTN_BWD_TEAMS=4: another merge order of the same tile sums)."""
+    levels with four teams instead of two (ISHAP_ATTN_BWD_TEAMS=4: another merge order of the same tile sums); proj_out of the
+    16^2 and 32^2 levels' AttentionBlocks as per-head fp32 slices from the attention launch (ISHAP_ATTN_PROJ=1, opt-in:
+    attn_fwd_kernel<64, 2, 6> / <64, 4, 4>, attention.hip) instead of a GEMM launch."""
     ref = _run_fullsize_worker(tmp_path, "default", {})
     for name, env in (("igemm2", {"ISHAP_IGEMM4": "0"}), ("oneteam", {"ISHAP_IG4_TEAMS": "0", "ISHAP_IG4_TALL": "0"}),
                       ("small3", {"ISHAP_IG4_W8": "0"}), ("skinny", {"ISHAP_G1_SLICES": "0"}),
-                      ("attn4teams", {"ISHAP_ATTN_BWD_TEAMS": "4"})):
+                      ("attn4teams", {"ISHAP_ATTN_BWD_TEAMS": "4"}), ("proj_slices", {"ISHAP_ATTN_PROJ": "1"})):
         got = _run_fullsize_worker(tmp_path, name, env)
         errs = {k: rel(torch.from_numpy(got[k]), torch.from_numpy(ref[k])) for k in ("out", "tap", "gx")}
         print(f"{name}: " + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
