@@ -34,7 +34,8 @@ int ishap_device_status(void);
  * ishap_rendezvous_would_grant: diagnostic, no side effects -- 1 if a launch sequence of `owner` (a model context, or NULL
  * for the stand-alone operator calls) on `stream` would be allowed in-launch rendezvous right now. */
 int ishap_rendezvous_would_grant(const void* owner, void* stream);
-int ishap_version(void);   /* 2 since ishap_mesh_smooth takes (and checks) the size of its scratch buffer */
+int ishap_version(void);   /* 2 since ishap_mesh_smooth takes (and checks) the size of its scratch buffer; 3 since ishap_step_coefs
+                            * ends with rng / rng_seed / rng_offset / noise_out */
 
 /* ---------------------------------------------------------------- UNet (gd/unet.py:396-671) */
 typedef struct ishap_unet ishap_unet;
@@ -166,8 +167,16 @@ typedef struct {
   float ddim_a;         /* sqrt(alphas_cumprod_prev[t]) */
   float ddim_b;         /* sqrt(1 - alphas_cumprod_prev[t] - sigma^2) */
   float ddim_sigma;     /* eta * sqrt((1-abar_prev)/(1-abar)) * sqrt(1 - abar/abar_prev) */
+  /* round 5: the step draws its own noise (the reference's th.randn_like(x), gaussian_diffusion.py:443 / :493) when rng != 0 and
+   * `noise` is NULL -- no randn launch and no noise tensor in front of the step.  Philox4x32-10 (Salmon et al., Random123) with
+   * key = rng_seed ^ 0x9E3779B97F4A7C15 and counter = {index of the 4-float vector in x (64 bit), rng_offset (64 bit)}; the four
+   * words become four standard normals by two Box-Muller pairs (u = ((w >> 8) + 0.5) * 2^-24): element 4 i + j of x takes normal j
+   * of vector i.  noise_out: optional [N][C][HW] that receives the noise used (the dict's "noise"). */
+  int rng;
+  unsigned long long rng_seed, rng_offset;
+  float* noise_out;
 } ishap_step_coefs;
-/* any of sample / pred_xstart / variance / mean may be NULL; noise NULL = zeros; variance_in optional */
+/* any of sample / pred_xstart / variance / mean may be NULL; noise NULL = zeros (or drawn, ishap_step_coefs::rng); variance_in optional */
 int ishap_ddpm_step(const float* x, const float* model_out, const float* noise, const float* variance_in,
                     const ishap_step_coefs* k, int N, int C, int HW,
                     float* sample, float* pred_xstart, float* variance, float* mean, void* stream);

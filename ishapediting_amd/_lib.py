@@ -26,7 +26,8 @@ class StepCoefs(C.Structure):
     _fields_ = [("min_log", C.c_float), ("max_log", C.c_float), ("sqrt_recip", C.c_float),
                 ("sqrt_recipm1", C.c_float), ("coef1", C.c_float), ("coef2", C.c_float),
                 ("nonzero", C.c_float), ("clip_denoised", C.c_int), ("mode", C.c_int),
-                ("ddim_a", C.c_float), ("ddim_b", C.c_float), ("ddim_sigma", C.c_float)]
+                ("ddim_a", C.c_float), ("ddim_b", C.c_float), ("ddim_sigma", C.c_float),
+                ("rng", C.c_int), ("rng_seed", C.c_ulonglong), ("rng_offset", C.c_ulonglong), ("noise_out", c_void_p)]
 
 
 class DragArgsC(C.Structure):
@@ -130,6 +131,8 @@ def lib():
             fn = getattr(l, name)     # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if l.ishap_version() < 3:     # 3: ishap_step_coefs ends with the rng fields this module's StepCoefs declares
+            raise RuntimeError(f"{LIB_PATH} is an older build (ABI {l.ishap_version()} < 3): rebuild with `python -m ishapediting_amd.build`")
         _lib = l
     return _lib
 

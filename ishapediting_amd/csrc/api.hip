@@ -150,6 +150,7 @@ int ishap_ddpm_step(const float* x, const float* model_out, const float* noise, 
   a.min_log = k->min_log; a.max_log = k->max_log; a.sqrt_recip = k->sqrt_recip; a.sqrt_recipm1 = k->sqrt_recipm1;
   a.coef1 = k->coef1; a.coef2 = k->coef2; a.nonzero = k->nonzero; a.clip = k->clip_denoised; a.mode = k->mode;
   a.ddim_a = k->ddim_a; a.ddim_b = k->ddim_b; a.ddim_sigma = k->ddim_sigma;
+  a.rng = k->rng; a.rng_seed = k->rng_seed; a.rng_offset = k->rng_offset; a.noise_out = k->noise_out;
   return ddpm_step_launch(a, (hipStream_t)stream);
 }
 
@@ -165,6 +166,7 @@ int ishap_ddpm_step_guided(const float* x, const float* model_out, const float* 
   a.min_log = k->min_log; a.max_log = k->max_log; a.sqrt_recip = k->sqrt_recip; a.sqrt_recipm1 = k->sqrt_recipm1;
   a.coef1 = k->coef1; a.coef2 = k->coef2; a.nonzero = k->nonzero; a.clip = k->clip_denoised; a.mode = k->mode;
   a.guide_grad = grad; a.guide_scale = scale; a.guide_mul = grad_mul_dev; a.guided = guided;
+  a.rng = k->rng; a.rng_seed = k->rng_seed; a.rng_offset = k->rng_offset; a.noise_out = k->noise_out;
   return ddpm_step_launch(a, (hipStream_t)stream);
 }
 

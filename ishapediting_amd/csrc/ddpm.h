@@ -25,6 +25,10 @@ struct DdpmStepArgs {
   const float* guide_mul = nullptr;    // optional device scalar (1 / loss scale of the fp16 backward pass)
   float guide_scale = 0.f;
   float* guided = nullptr;
+  // in-kernel noise (include/ishap.h, ishap_step_coefs::rng): used when rng != 0 and noise == nullptr
+  int rng = 0;
+  unsigned long long rng_seed = 0, rng_offset = 0;
+  float* noise_out = nullptr;
 };
 int ddpm_step_launch(const DdpmStepArgs& a, hipStream_t s);
 int guided_update_launch(const float* sample, const float* variance, const float* grad, float* out, float scale,

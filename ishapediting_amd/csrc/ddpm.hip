@@ -6,6 +6,36 @@
 // is written once (float4 per lane).
 #include "ddpm.h"
 
+// Philox4x32-10 (J. Salmon, M. Moraes, R. Dror, D. Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; the generator
+// behind torch's CUDA randn as well, here with a counter layout of its own): ten rounds of two 32 x 32 -> 64 multiplies.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+// four standard normals for the 4-float vector `vec` of the tensor: two Box-Muller pairs
+__device__ __forceinline__ f32x4 step_noise4(unsigned long long vec, unsigned long long seed, unsigned long long offset) {
+  const unsigned long long key = seed ^ 0x9E3779B97F4A7C15ull;      // not torch's own stream of the same seed
+  unsigned w[4];
+  philox4x32_10((unsigned)vec, (unsigned)(vec >> 32), (unsigned)offset, (unsigned)(offset >> 32), (unsigned)key, (unsigned)(key >> 32), w);
+  f32x4 n;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u0 = ((float)(w[2 * h] >> 8) + 0.5f) * 0x1p-24f, u1 = ((float)(w[2 * h + 1] >> 8) + 0.5f) * 0x1p-24f;   // in (0, 1)
+    const float rad = sqrtf(-2.f * logf(u0));
+    float sn, cs;
+    sincosf(6.283185307179586f * u1, &sn, &cs);
+    n[2 * h] = rad * cs;
+    n[2 * h + 1] = rad * sn;
+  }
+  return n;
+}
+
 __global__ __launch_bounds__(256) void ddpm_step_kernel(DdpmStepArgs a) {
   const float gm = (a.guided && a.guide_mul) ? *a.guide_mul : 1.f;
   const long long per_img = (long long)a.C * a.HW;           // floats per image in x
@@ -19,6 +49,10 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(DdpmStepArgs a) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(a.model_out + n * 2 * per_img + per_img + r);
     f32x4 nz = {0.f, 0.f, 0.f, 0.f};
     if (a.noise) nz = *reinterpret_cast<const f32x4*>(a.noise + e);
+    else if (a.rng) {
+      nz = step_noise4((unsigned long long)i, a.rng_seed, a.rng_offset);
+      if (a.noise_out) *reinterpret_cast<f32x4*>(a.noise_out + e) = nz;
+    }
     f32x4 var_in = {0.f, 0.f, 0.f, 0.f};
     if (a.variance_in) var_in = *reinterpret_cast<const f32x4*>(a.variance_in + e);
     f32x4 gr = {0.f, 0.f, 0.f, 0.f};

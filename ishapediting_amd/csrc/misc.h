@@ -2,7 +2,8 @@
 #include "common.h"
 #include <algorithm>
 
-int nchw_f32_to_nhwc_f16(const float* src, half_t* dst, int N, int C, int HW, int Cpad, hipStream_t s);
+// zero / zero_bytes: a range the same launch sets to zero (16-byte granules), or null
+int nchw_f32_to_nhwc_f16(const float* src, half_t* dst, int N, int C, int HW, int Cpad, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0);
 int nhwc_f16_to_nchw(const half_t* src, void* dst, int out_f32, int N, int C, int HW, int ld, hipStream_t s);
 int nchw_to_nhwc_f16_scaled(const void* src, int src_f32, half_t* dst, int N, int C, int HW, int ld, float mul, hipStream_t s);
 int concat2(const half_t* a, const half_t* b, half_t* o, long long M, int Ca, int Cb, hipStream_t s,

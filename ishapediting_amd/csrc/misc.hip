@@ -6,10 +6,18 @@
 
 // --------------------------- NCHW fp32 -> NHWC fp16 (channel-padded) ---------------------------
 // tile transpose through LDS: reads coalesced along HW, writes coalesced along C
+// Blocks with blockIdx.y >= ytiles do not convert: together they zero `zero_n16` 16-byte words at `zero` (the UNet forward's
+// statistics arena, which used to be a hipMemsetAsync launch of its own in front of this kernel -- one launch and boundary fewer per step).
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, half_t* __restrict__ dst,
-                                                           int C, int HW, int Cpad) {
+                                                           int C, int HW, int Cpad, int ytiles, uint4* __restrict__ zero, long long zero_n16) {
   __shared__ float tile[32][33];
   const int n = blockIdx.z;
+  if ((int)blockIdx.y >= ytiles) {
+    const long long nb = (long long)gridDim.x * (gridDim.y - ytiles) * gridDim.z;
+    const long long b = blockIdx.x + (long long)gridDim.x * ((blockIdx.y - ytiles) + (long long)(gridDim.y - ytiles) * blockIdx.z);
+    for (long long i = b * 256 + threadIdx.x; i < zero_n16; i += nb * 256) zero[i] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
   const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   for (int j = ty; j < 32; j += 8) {
@@ -22,9 +30,16 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     if (p < HW && c < Cpad) dst[((long long)n * HW + p) * Cpad + c] = (half_t)tile[tx][j];
   }
 }
-int nchw_f32_to_nhwc_f16(const float* src, half_t* dst, int N, int C, int HW, int Cpad, hipStream_t s) {
-  dim3 g(ceil_div(HW, 32), ceil_div(Cpad, 32), N);
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, g, dim3(256), 0, s, src, dst, C, HW, Cpad);
+int nchw_f32_to_nhwc_f16(const float* src, half_t* dst, int N, int C, int HW, int Cpad, hipStream_t s, void* zero, size_t zero_bytes) {
+  const int ytiles = ceil_div(Cpad, 32);
+  ISHAP_REQUIRE(zero_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(zero) & 15) == 0, "zeroed range: 16-byte granules");
+  // one zeroing block per ~16 KB (4 stores per thread), at most one extra row of tiles per converting row
+  const long long n16 = (long long)(zero_bytes / 16);
+  const int per_row = ceil_div(HW, 32) * N;
+  int zrows = zero && n16 ? (int)((n16 + 1024LL * per_row - 1) / (1024LL * per_row)) : 0;
+  if (zrows > ytiles) zrows = ytiles;
+  dim3 g(ceil_div(HW, 32), ytiles + zrows, N);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, g, dim3(256), 0, s, src, dst, C, HW, Cpad, ytiles, reinterpret_cast<uint4*>(zero), zrows ? n16 : 0LL);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }

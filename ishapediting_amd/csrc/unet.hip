@@ -781,7 +781,10 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
   }
   u->arena.reset();
   u->stat_off = 0;
-  if (!dry && u->stat_cap) ISHAP_CHECK_HIP(hipMemsetAsync(u->stat_base, 0, u->stat_cap * sizeof(long long), s));
+  // the statistics arena is zeroed by the layout conversion below (its first use comes after it); ISHAP_STAT_MEMSET=1: by a memset launch
+  static const bool stat_memset = [] { const char* e = getenv("ISHAP_STAT_MEMSET"); return e && atoi(e) != 0; }();
+  const bool zero_in_convert = !stat_memset && (u->stat_cap % 2 == 0) && (reinterpret_cast<uintptr_t>(u->stat_base) & 15) == 0;
+  if (!dry && u->stat_cap && !zero_in_convert) ISHAP_CHECK_HIP(hipMemsetAsync(u->stat_base, 0, u->stat_cap * sizeof(long long), s));
   u->have_saved = false;
   const int S = cfg.image_size, HW = S * S;
   // ---- timestep embedding -> emb -> every ResBlock's (scale | shift)   (unet.py:651, :245-250) ----
@@ -810,7 +813,8 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
   // ---- x: NCHW fp32 -> NHWC fp16 (h = x.type(self.dtype), unet.py:657) ----
   Tensor h{nullptr, N, S, S, u->in_pad};
   ISHAP_ALLOC(h.p, e, h.numel());
-  if (!dry) ISHAP_TRY(nchw_f32_to_nhwc_f16(x, h.p, N, cfg.in_channels, HW, u->in_pad, s));
+  if (!dry) ISHAP_TRY(nchw_f32_to_nhwc_f16(x, h.p, N, cfg.in_channels, HW, u->in_pad, s, zero_in_convert ? u->stat_base : nullptr,
+                                           zero_in_convert ? u->stat_cap * sizeof(long long) : 0));
   u->x0 = h;
   std::vector<Tensor> hs;
   for (auto& b : u->in_blocks) {
@@ -890,7 +894,7 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int ishap_version(void) { return 2; }   // 2: ishap_mesh_smooth takes the scratch size
+int ishap_version(void) { return 3; }   // 2: ishap_mesh_smooth takes the scratch size; 3: ishap_step_coefs carries the rng fields
 
 int ishap_unet_create(const ishap_unet_config* cfg, int device, ishap_unet** out) {
   ISHAP_REQUIRE(cfg && out, "null argument");

@@ -301,7 +301,7 @@ class DragStuff:
             keep = i < self.args.w_time
             outs = self.diffusion.p_sample_guidance(self.model, img, i, feat_layer=self.args.feat_layer,
                                                     clip_denoised=self.args.clip_denoised, want_inter_feat=False,
-                                                    noise=self._noise(i, img), **kwargs)
+                                                    noise=self._noise(i, img), want_noise=False, **kwargs)
             img = outs["sample"]
             if i == self.args.w_time:
                 self.w = img.clone().detach()
@@ -320,7 +320,7 @@ class DragStuff:
             for i in range(t - 1, -1, -1):
                 outs = self.diffusion.p_sample_guidance(self.model, img, i, feat_layer=self.args.feat_layer,
                                                         clip_denoised=self.args.clip_denoised, want_inter_feat=False,
-                                                        noise=self._noise(i, img))
+                                                        noise=self._noise(i, img), want_noise=False)
                 img = outs["sample"]
             tri_feat = img
         self.tri_feat = tri_feat
@@ -371,7 +371,7 @@ class DragStuff:
             outs = self.diffusion.p_sample_guidance(self.model, img, i, feat_layer=self.args.feat_layer,
                                                     keep_for_backward=True, want_inter_feat=False,
                                                     noise=self._noise(i, img), between=loss_and_backward, overlap=_OVERLAP_TAIL,
-                                                    guided_scale=float(scale) if _FUSED_UPDATE else None)
+                                                    guided_scale=float(scale) if _FUSED_UPDATE else None, want_noise=False)
             if _FUSED_UPDATE:
                 img = outs["guided"]
             else:
@@ -428,7 +428,7 @@ class DragStuff:
         scale2 = th.ones(2, dtype=th.float32, device=self.device)
         self.last_losses = []
         for i in (steps if steps is not None else range(self.args.num_steps - 1, -1, -1)):
-            outs = d.p_sample_guidance(self.model, img, i, keep_for_backward=True, noise=self._noise(i, img))
+            outs = d.p_sample_guidance(self.model, img, i, keep_for_backward=True, noise=self._noise(i, img), want_noise=False)
             if batch_fn is not None:
                 coord, gt = batch_fn(i)
             else:     # DataLoader(shuffle=True, batch_size=40000); next(iter(...)) -> a fresh random batch each step (:453)

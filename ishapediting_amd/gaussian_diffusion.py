@@ -9,12 +9,15 @@ SURVEY 8f rank 4) is mode 3 of the same kernel.  Training losses and the VLB are
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
 import torch
 
 from . import _lib
+
+_STEP_RNG = os.environ.get("ISHAP_STEP_RNG", "1") != "0"      # the step kernel draws its own noise (GaussianDiffusion._draw)
 
 
 def get_named_beta_schedule(schedule_name: str, num_diffusion_timesteps: int) -> np.ndarray:
@@ -123,12 +126,31 @@ class SpacedDiffusion:
             return model(x, ts, **model_kwargs), None
         return model(x, ts, feat_layer=feat_layer, **model_kwargs)
 
-    def _step(self, x, model_output, t, noise, variance_in, clip_denoised, mode, want=("sample",), eta=0.0, guide=None):
+    def _draw(self, x, want_tensor):
+        """The noise of one step when the caller injected none (the reference's th.randn_like(x), gaussian_diffusion.py:443 /
+        :493 / :702).  Default: the step kernel draws it itself (include/ishap.h, ishap_step_coefs::rng -- Philox4x32-10 keyed by
+        the device's default torch generator seed, counter offset taken from and advanced on that generator, so torch.manual_seed
+        makes runs repeatable as with randn_like; the VALUES are not those torch.randn would give, as they are not the reference's
+        on another device either) -- one launch and two 6.3 MB tensor passes fewer per step.  Returns (noise tensor or None,
+        (seed, offset, noise_out tensor or None) or None).  ISHAP_STEP_RNG=0: torch.randn_like."""
+        if _STEP_RNG and x.is_cuda:
+            g = torch.cuda.default_generators[x.device.index]
+            if hasattr(g, "get_offset"):
+                seed, off = int(g.initial_seed()) & ((1 << 64) - 1), int(g.get_offset())
+                g.set_offset(off + 4)
+                return None, (seed, off, torch.empty_like(x) if want_tensor else None)
+        return torch.randn_like(x), None
+
+    def _step(self, x, model_output, t, noise, variance_in, clip_denoised, mode, want=("sample",), eta=0.0, guide=None, rng=None):
         N, Cc = x.shape[:2]
         HW = int(np.prod(x.shape[2:]))
         assert model_output.shape[1] == 2 * Cc
         outs = {k: torch.empty_like(x) for k in want}
         k = self._coefs(t, clip_denoised, mode, eta)
+        if rng is not None:                   # (seed, offset, noise_out): the kernel draws the noise (noise must be None)
+            assert noise is None
+            k.rng, k.rng_seed, k.rng_offset = 1, rng[0], rng[1]
+            k.noise_out = None if rng[2] is None else rng[2].data_ptr()
         if guide is not None:                 # (d loss / d x, scale): the guided update in the same pass
             grad, scale = guide
             assert grad.shape == x.shape and grad.dtype == torch.float32 and grad.is_contiguous()
@@ -177,14 +199,16 @@ class SpacedDiffusion:
     # ------------------------------------------------------------------ reference surface
     def p_sample_guidance(self, model, x, t, noise=None, variance=None, variance_noise=None, clip_denoised=True,
                           denoised_fn=None, cond_fn=None, model_kwargs=None, feat_layer=-1, keep_for_backward=False,
-                          want_inter_feat=True, between=None, overlap=True, guided_scale=None):
+                          want_inter_feat=True, between=None, overlap=True, guided_scale=None, want_noise=True):
         """gaussian_diffusion.py:446-510.  Returns the same dict keys.
         `between`: a callable run after the model call and before the step arithmetic -- the drag loop passes its loss +
         backward here; with `overlap` the model then runs the part of the network those do not need (everything after the tap)
         beside them, and the step arithmetic waits for it.  Results are identical with and without it.
         `guided_scale` (with a `between` that returns d loss / d x): the drag loop's update `sample + variance * scale * grad`
         (drag_utils.py:384-392) is formed by the step kernel itself and returned as "guided" -- one launch instead of two, the
-        intermediate sample / variance tensors are not written."""
+        intermediate sample / variance tensors are not written.
+        `want_noise=False`: the dict's "noise" may be None when the step drew the noise itself (`_draw`); the drag loop does
+        not read it."""
         assert denoised_fn is None and cond_fn is None, "not used on the path"
         ti = self._t_index(t)
         if torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled() and hasattr(model, "backward_from_output"):
@@ -206,19 +230,24 @@ class SpacedDiffusion:
                     model.run_tail()          # a tail the forward only planned (deferred form); no-op otherwise
                 model.join_tail()
         if guided_scale is not None and grad is not None and variance_noise is None:
-            noise = self._prep(noise if noise is not None else torch.randn_like(x))
+            rng = None
+            if noise is None:
+                noise, rng = self._draw(x, want_noise)
+            noise = None if noise is None else self._prep(noise)
             vin = None if variance is None else self._prep(variance)
-            o = self._step(x, mo, ti, noise, vin, clip_denoised, 0, (), guide=(grad, float(guided_scale)))
-            return {"guided": o["guided"], "inter_feat": inter, "noise": noise}
+            o = self._step(x, mo, ti, noise, vin, clip_denoised, 0, (), guide=(grad, float(guided_scale)), rng=rng)
+            return {"guided": o["guided"], "inter_feat": inter, "noise": noise if rng is None else rng[2]}
         if variance_noise is not None:
             o = self._step(x, mo, ti, self._prep(variance_noise), None, clip_denoised, 2, ("sample", "variance"))
             return {"sample": o["sample"], "inter_feat": inter, "variance": o["variance"]}
-        noise = noise if noise is not None else torch.randn_like(x)
-        noise = self._prep(noise)
+        rng = None
+        if noise is None:
+            noise, rng = self._draw(x, want_noise)
+        noise = None if noise is None else self._prep(noise)
         vin = None if variance is None else self._prep(variance)
-        o = self._step(x, mo, ti, noise, vin, clip_denoised, 0, ("sample", "pred_xstart", "variance", "mean"))
+        o = self._step(x, mo, ti, noise, vin, clip_denoised, 0, ("sample", "pred_xstart", "variance", "mean"), rng=rng)
         return {"sample": o["sample"], "pred_xstart": o["pred_xstart"], "inter_feat": inter,
-                "model_output": mo[:, :x.shape[1]], "noise": noise,
+                "model_output": mo[:, :x.shape[1]], "noise": noise if rng is None else rng[2],
                 "variance": o["variance"] if variance is None else variance, "mean": o["mean"]}
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, noise=None):
@@ -227,8 +256,11 @@ class SpacedDiffusion:
         ti = self._t_index(t)
         x = self._prep(x)
         mo, _ = self._model(model, x, ti, -1, **(model_kwargs or {}))
-        noise = self._prep(noise if noise is not None else torch.randn_like(x))
-        o = self._step(x, mo, ti, noise, None, clip_denoised, 1, ("sample", "pred_xstart"))
+        rng = None
+        if noise is None:
+            noise, rng = self._draw(x, False)
+        noise = None if noise is None else self._prep(noise)
+        o = self._step(x, mo, ti, noise, None, clip_denoised, 1, ("sample", "pred_xstart"), rng=rng)
         return {"sample": o["sample"], "pred_xstart": o["pred_xstart"]}
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
@@ -268,8 +300,11 @@ class SpacedDiffusion:
         ti = self._t_index(t)
         x = self._prep(x)
         mo, inter = self._model(model, x, ti, feat_layer, **(model_kwargs or {}))
-        noise = self._prep(noise if noise is not None else torch.randn_like(x))
-        o = self._step(x, mo, ti, noise, None, clip_denoised, 3, ("sample", "pred_xstart"), eta=eta)
+        rng = None
+        if noise is None:
+            noise, rng = self._draw(x, False)
+        noise = None if noise is None else self._prep(noise)
+        o = self._step(x, mo, ti, noise, None, clip_denoised, 3, ("sample", "pred_xstart"), eta=eta, rng=rng)
         return {"sample": o["sample"], "pred_xstart": o["pred_xstart"], "inter_feat": inter,
                 "model_output": mo[:, :x.shape[1]]}
 

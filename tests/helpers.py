@@ -53,3 +53,15 @@ def redraw_ddim_noise(g):
     got = np.array([float(init.double().sum()), float(steps.double().pow(2).sum()), float(steps[-1, -1, -1, -1, -1])])
     np.testing.assert_allclose(got, g["noise_check"], rtol=1e-12, atol=0, err_msg="torch's CPU RNG stream differs from the fixture's")
     return init, steps
+
+
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 on numpy uint32 arrays (Salmon et al., SC'11): ctr = 4 arrays, key = 2 scalars.  Test-side restatement."""
+    c = [np.asarray(v, dtype=np.uint64) for v in ctr]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & MASK, p1 & MASK, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & MASK, p0 & MASK]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & MASK, (k1 + np.uint64(0xBB67AE85)) & MASK
+    return [v.astype(np.uint32) for v in c]

@@ -100,6 +100,67 @@ def test_ddpm_step_vs_golden(gold):
         np.testing.assert_allclose(o4["sample"].cpu().numpy(), g[f"t{t}_psample"], rtol=2e-5, atol=2e-6)
 
 
+def test_step_draws_its_own_noise(gold):
+    """ishap_step_coefs::rng (include/ishap.h): with no injected noise the step kernel draws th.randn_like(x) itself
+    (gaussian_diffusion.py:493).  The noise it reports equals the documented construction -- Philox4x32-10, key = seed ^
+    0x9E3779B97F4A7C15, counter = {vector index, offset}, two Box-Muller pairs -- to fp32 rounding of log / sin / cos (2e-5 abs);
+    the step's outputs are BITWISE those of the same step with that noise injected; torch.manual_seed repeats it, consecutive
+    steps differ; the moments are a standard normal's."""
+    from ishapediting_amd import gaussian_diffusion as gdm
+    assert gdm._STEP_RNG
+    g = gold("g2_steps")
+    d = gdm.create_gaussian_diffusion(timestep_respacing="40")
+    x, mo = (T(g[k]).to(dev()) for k in ("x", "model_output"))
+
+    class Fixed:
+        def __call__(self, x, ts, feat_layer=-1, **kw):
+            return (mo, None) if feat_layer >= 0 else mo
+    torch.manual_seed(4242)
+    gen = torch.cuda.default_generators[dev().index]
+    seed, off = gen.initial_seed(), gen.get_offset()
+    o = d.p_sample_guidance(Fixed(), x, torch.tensor([17]))
+    assert gen.get_offset() == off + 4
+    noise = o["noise"].cpu().numpy().reshape(-1)
+    n4 = noise.size // 4
+    vec = np.arange(n4, dtype=np.uint64)
+    key = seed ^ 0x9E3779B97F4A7C15
+    from tests.helpers import philox4x32_10
+    w = philox4x32_10([vec & 0xFFFFFFFF, vec >> 32, np.full(n4, off & 0xFFFFFFFF), np.full(n4, off >> 32)], (key & 0xFFFFFFFF, key >> 32))
+    u = [((v >> 8).astype(np.float64) + 0.5) * 2.0 ** -24 for v in w]
+    want = np.empty((n4, 4))
+    for h in range(2):
+        rad = np.sqrt(-2.0 * np.log(u[2 * h]))
+        want[:, 2 * h] = rad * np.cos(2 * np.pi * u[2 * h + 1])
+        want[:, 2 * h + 1] = rad * np.sin(2 * np.pi * u[2 * h + 1])
+    np.testing.assert_allclose(noise, want.reshape(-1), rtol=0, atol=2e-5)
+    o_inj = d.p_sample_guidance(Fixed(), x, torch.tensor([17]), noise=o["noise"])
+    for k in ("sample", "pred_xstart", "variance", "mean"):
+        assert torch.equal(o[k], o_inj[k]), k
+    o_next = d.p_sample_guidance(Fixed(), x, torch.tensor([17]))
+    assert not torch.equal(o_next["noise"], o["noise"])
+    torch.manual_seed(4242)
+    o_again = d.p_sample_guidance(Fixed(), x, torch.tensor([17]))
+    assert torch.equal(o_again["noise"], o["noise"]) and torch.equal(o_again["sample"], o["sample"])
+    # p_sample / want_noise=False: no noise tensor, same values (same seed and offset)
+    torch.manual_seed(4242)
+    o_quiet = d.p_sample_guidance(Fixed(), x, torch.tensor([17]), want_noise=False)
+    assert o_quiet["noise"] is None and torch.equal(o_quiet["sample"], o["sample"])
+    # moments over 1.5 M draws of a full-size latent
+    xb = torch.zeros(1, 96, 128, 128, device=dev())
+    mb = torch.zeros(1, 192, 128, 128, device=dev())
+
+    class Zero:
+        def __call__(self, x, ts, feat_layer=-1, **kw):
+            return (mb, None) if feat_layer >= 0 else mb
+    z = d.p_sample_guidance(Zero(), xb, torch.tensor([20]))["noise"].double().reshape(-1)
+    n = z.numel()
+    assert abs(float(z.mean())) < 5.0 / n ** 0.5
+    assert abs(float(z.var()) - 1.0) < 5.0 * (2.0 / n) ** 0.5
+    assert abs(float((z ** 3).mean())) < 5.0 * (15.0 / n) ** 0.5
+    assert abs(float((z ** 4).mean()) - 3.0) < 5.0 * (96.0 / n) ** 0.5
+    assert float(z.abs().max()) < 6.5
+
+
 # ---------------------------------------------------------------------------------------------- decoder
 def test_decoder_points_vs_golden(gold):
     """fp32 MFMA decode vs the reference MultiTriplane (incl. border and out-of-range coords).

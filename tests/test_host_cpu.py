@@ -19,7 +19,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/ishap.h but not exported"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert L.ishap_version() >= 2        # 2: ishap_mesh_smooth(..., scratch, scratch_bytes, stream)
+    assert L.ishap_version() >= 3        # 2: ishap_mesh_smooth(..., scratch, scratch_bytes, stream); 3: ishap_step_coefs rng fields
 
 
 def test_product_never_imports_the_oracle():
@@ -203,3 +203,15 @@ def test_bench_counts_gpus_without_loading_hip(monkeypatch):
     assert n is not None and n <= 3
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
     assert bench.visible_gpu_count() == 0
+
+
+def test_philox_restatement_known_answers():
+    """Random123's known-answer vectors for philox4x32-10 pin the test-side generator (tests/helpers.py) that the step kernel's
+    in-launch noise is compared with on the GPU (test_gpu_parity.py::test_step_draws_its_own_noise)."""
+    from tests.helpers import philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = philox4x32_10([np.array([v]) for v in ctr], key)
+        assert tuple(int(g[0]) for g in got) == want
