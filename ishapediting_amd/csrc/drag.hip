@@ -80,6 +80,9 @@ __device__ __forceinline__ void drag_motion_body(const DragArgs& a, int blk, int
     int xcur = 0, ycur = 0;
     bool open = false;
     auto flush_col = [&](int x, float v0, float v1) {
+#ifdef DRAG_ABL_NOATOM      // timing ablation (tools/build_variant.sh): the scatter's atomics left out -- wrong gradients
+      if (v0 != 12345.f) return;
+#endif
       if (!live || x < 0 || x >= a.W) return;
       if (ycur >= 0 && ycur < a.W) fx_add(a.gfx + ((long long)ycur * a.W + x) * a.ld + ch, v0, DRAG_FX_SCALE);
       if (ycur + 1 >= 0 && ycur + 1 < a.W) fx_add(a.gfx + ((long long)(ycur + 1) * a.W + x) * a.ld + ch, v1, DRAG_FX_SCALE);
