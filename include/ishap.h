@@ -95,6 +95,11 @@ int ishap_unet_join_tail(ishap_unet* u, void* stream);
  * output blocks (or behind the tap when no backward ran).  No-op when nothing is planned; ishap_unet_join_tail runs a plan that
  * was never enqueued. */
 int ishap_unet_run_tail(ishap_unet* u);
+/* Diagnostics (contexts created with ISHAP_BWD_MARKS=1 in the environment; otherwise returns 0): elapsed milliseconds from the start of
+ * the last backward pass to the timing event recorded after each of its blocks -- tags: 0 start, 100 + i after output block i, 200
+ * after the middle block, 300 + i after input block i, 999 end -- and to the begin / end of the forward tail that ran beside it on the
+ * context's side stream (-1 when none did).  Returns the number of marks written (<= cap); synchronises with the device. */
+int ishap_unet_marks(ishap_unet* u, int* tags, float* ms, int cap, float* tail_begin_ms, float* tail_end_ms);
 /* copy it into a caller buffer of N*S_tap^2*C_tap halfs (the guidance cache of drag_utils.py:275-276, kept
  * on the device in the tap's own layout instead of resized fp32 copies on the host) */
 int ishap_unet_copy_tap(const ishap_unet* u, void* dst, void* stream);

@@ -70,6 +70,7 @@ SYMBOLS = {
     "ishap_unet_workspace_bytes": (C.c_longlong, [c_void_p]),
     "ishap_unet_join_tail": (C.c_int, [c_void_p, c_void_p]),
     "ishap_unet_run_tail": (C.c_int, [c_void_p]),
+    "ishap_unet_marks": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p]),
     "ishap_unet_prepare_timesteps": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p]),
     "ishap_unet_backward_input": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ishap_unet_backward_from_output": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p]),

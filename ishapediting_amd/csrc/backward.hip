@@ -207,6 +207,22 @@ static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out, int split =
   return 0;
 }
 
+// ISHAP_BWD_MARKS=1: a timing event on the backward's stream, tagged (0 start, 100 + i after output block i, 200 after the middle
+// block, 300 + i after input block i, 999 end); read back by ishap_unet_marks
+static int bwd_mark(ishap_unet* u, hipStream_t s, int tag, bool dry) {
+  if (dry || !u->marks_on) return 0;
+  if (tag == 0) { u->marks_n = 0; u->mark_tail_set = false; }
+  if ((size_t)u->marks_n == u->marks.size()) {
+    hipEvent_t ev;
+    ISHAP_CHECK_HIP(hipEventCreate(&ev));
+    u->marks.push_back(ev);
+    u->mark_tags.push_back(0);
+  }
+  u->mark_tags[u->marks_n] = tag;
+  ISHAP_CHECK_HIP(hipEventRecord(u->marks[u->marks_n++], s));
+  return 0;
+}
+
 int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out, int cot_out_f16, const float* scale2,
                        float* dx, hipStream_t s, bool dry) {
   Exec e{u, s, dry};
@@ -219,6 +235,7 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
     if (u->bwd_since_fwd++ > 0 && u->stat_cap > u->stat_fwd_mark)   // a second backward on the same forward: fresh zeros
       ISHAP_CHECK_HIP(hipMemsetAsync(u->stat_base + u->stat_fwd_mark, 0, (u->stat_cap - u->stat_fwd_mark) * sizeof(long long), s));
   }
+  ISHAP_TRY(bwd_mark(u, s, 0, dry));
   const ishap_unet_config& cfg = u->cfg;
   const int N = u->last_N;            // dry runs follow a dry forward of the same batch size
   const int n_in = (int)u->in_blocks.size(), n_out = (int)u->out_blocks.size();
@@ -262,6 +279,7 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
     ISHAP_TRY(block_backward(e, b, g, gh, Ch, &gs));       // the first ResBlock writes d/d[h | skip] as two tensors
     skipgrad[n_in - 1 - i] = gs;     // hs.pop() order (unet.py:663)
     g = gh;
+    ISHAP_TRY(bwd_mark(u, s, 100 + i, dry));
     // a deferred forward tail starts behind this point: the backward's first (chip-filling) blocks have the GPU to themselves.
     // Default: once the first output block on a map of at most 16 x 16 pixels has been differentiated (the real model: after
     // out8 ... out5, i.e. four blocks -- in-situ sweep of the count, profiles/round5_overlap_tail_ab.txt 7); ISHAP_TAIL_MID=k: after
@@ -287,6 +305,7 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
   const half_t* pending = nullptr;
   e.next_block_pf = n_in > 0 ? first_bwd_weights(u, u->in_blocks[n_in - 1].layers.back()) : PrefetchHint{};
   ISHAP_TRY(run(u->mid, n_in > 0 ? skipgrad[n_in - 1].p : nullptr, pending));
+  ISHAP_TRY(bwd_mark(u, s, 200, dry));
   for (int i = n_in - 1; i >= 0; --i) {
     e.next_block_pf = i > 0 ? first_bwd_weights(u, u->in_blocks[i - 1].layers.back()) : PrefetchHint{};
     if (pending) {                       // fall-back: a separate add
@@ -296,11 +315,34 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
       g = sum;
     }
     ISHAP_TRY(run(u->in_blocks[i], i > 0 ? skipgrad[i - 1].p : nullptr, pending));
+    ISHAP_TRY(bwd_mark(u, s, 300 + i, dry));
   }
   if (!dry)
     ISHAP_TRY(nhwc_f16_to_nchw_f32_scaled(g.p, dx, N, cfg.in_channels, cfg.image_size * cfg.image_size, u->in_pad,
                                           scale2 ? scale2 + 1 : nullptr, s));
+  ISHAP_TRY(bwd_mark(u, s, 999, dry));
   return 0;
+}
+
+// elapsed milliseconds from the start mark of the last backward to each of its marks, and to the begin / end of the forward tail
+// that ran beside it on the side stream (-1: no deferred tail ran).  Synchronises with the device.
+extern "C" int ishap_unet_marks(ishap_unet* u, int* tags, float* ms, int cap, float* tail_begin_ms, float* tail_end_ms) {
+  ISHAP_REQUIRE(u && tags && ms && cap > 0, "null argument");
+  ISHAP_CHECK_HIP(hipSetDevice(u->device));
+  if (tail_begin_ms) *tail_begin_ms = -1.f;
+  if (tail_end_ms) *tail_end_ms = -1.f;
+  if (u->marks_n == 0) return 0;
+  ISHAP_CHECK_HIP(hipDeviceSynchronize());
+  const int n = u->marks_n < cap ? u->marks_n : cap;
+  for (int k = 0; k < n; ++k) {
+    tags[k] = u->mark_tags[k];
+    ISHAP_CHECK_HIP(hipEventElapsedTime(&ms[k], u->marks[0], u->marks[k]));
+  }
+  if (u->mark_tail_set) {
+    if (tail_begin_ms) ISHAP_CHECK_HIP(hipEventElapsedTime(tail_begin_ms, u->marks[0], u->mark_tail_begin));
+    if (tail_end_ms) ISHAP_CHECK_HIP(hipEventElapsedTime(tail_end_ms, u->marks[0], u->mark_tail_end));
+  }
+  return n;
 }
 
 extern "C" int ishap_unet_backward_input(ishap_unet* u, const void* cot, const float* scale2, float* dx, void* stream) {

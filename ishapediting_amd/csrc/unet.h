@@ -161,6 +161,14 @@ struct ishap_unet {
   // behind them; the next forward / a full-depth backward / a block read-out joins by itself.
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_tail = nullptr, ev_mid = nullptr;
+  // diagnostic time marks (ISHAP_BWD_MARKS=1; include/ishap.h, ishap_unet_marks): timing events after every block of the backward
+  // pass and around the deferred forward tail on the side stream -- un-traced per-segment durations of the overlapped step
+  bool marks_on = false;
+  std::vector<hipEvent_t> marks;
+  std::vector<int> mark_tags;
+  int marks_n = 0;
+  hipEvent_t mark_tail_begin = nullptr, mark_tail_end = nullptr;
+  bool mark_tail_set = false;
   bool tail_pending = false;
   // deferred tail (ISHAP_TAIL_DEFER): planned by the forward, enqueued by ishap_unet_run_tail behind ev_mid (recorded by the
   // backward after its first output blocks)

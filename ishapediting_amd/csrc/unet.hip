@@ -713,6 +713,10 @@ int unet_run_tail(ishap_unet* u) {
   u->arena.off = u->tail.arena_off;
   u->stat_off = u->tail.stat_off;
   ISHAP_CHECK_HIP(hipStreamWaitEvent(u->side, u->mid_recorded ? u->ev_mid : u->ev_fork, 0));
+  if (u->marks_on && u->marks_n > 0) {           // diagnostic marks (unet.h): the tail's span on the side stream
+    if (!u->mark_tail_begin) { ISHAP_CHECK_HIP(hipEventCreate(&u->mark_tail_begin)); ISHAP_CHECK_HIP(hipEventCreate(&u->mark_tail_end)); }
+    ISHAP_CHECK_HIP(hipEventRecord(u->mark_tail_begin, u->side));
+  }
   Exec e{u, u->side, false};
   e.tenant = false;
   e.keep = u->tail.keep;
@@ -735,6 +739,10 @@ int unet_run_tail(ishap_unet* u) {
     ISHAP_TRY(out_blocks_range(e, u, cut, n_out, h, hs, u->last_feat));
   }
   ISHAP_TRY(forward_head(e, u, h, u->tail.N, u->tail.out));
+  if (u->marks_on && u->marks_n > 0 && u->mark_tail_begin) {
+    ISHAP_CHECK_HIP(hipEventRecord(u->mark_tail_end, u->side));
+    u->mark_tail_set = true;
+  }
   ISHAP_CHECK_HIP(hipEventRecord(u->ev_tail, u->side));
   u->tail_pending = true;
   ISHAP_REQUIRE(u->arena.off == u->fwd_mark && u->stat_off == u->stat_fwd_mark, "the deferred tail allocated differently from its plan");
@@ -909,6 +917,7 @@ int ishap_unet_create(const ishap_unet_config* cfg, int device, ishap_unet** out
   ISHAP_CHECK_HIP(hipSetDevice(device));
   ishap_unet* u = new ishap_unet();
   u->cfg = *cfg;
+  { const char* v = getenv("ISHAP_BWD_MARKS"); u->marks_on = v && atoi(v) != 0; }
   u->device = device;
   int r = unet_build(u);
   if (r) { delete u; return r; }
@@ -953,6 +962,9 @@ void ishap_unet_destroy(ishap_unet* u) {
   if (u->ev_fork) (void)hipEventDestroy(u->ev_fork);
   if (u->ev_tail) (void)hipEventDestroy(u->ev_tail);
   if (u->ev_mid) (void)hipEventDestroy(u->ev_mid);
+  for (hipEvent_t ev : u->marks) (void)hipEventDestroy(ev);
+  if (u->mark_tail_begin) (void)hipEventDestroy(u->mark_tail_begin);
+  if (u->mark_tail_end) (void)hipEventDestroy(u->mark_tail_end);
   fr(u->arena.base); fr(u->ws); fr(u->gn_partial); fr(u->attn_D); fr(u->stat_base);
   delete u;
 }
