@@ -625,3 +625,58 @@ def test_runtime_switches_keep_the_results(tmp_path):
         # extra workgroups that only touch weights / another placement of the same workgroups / other event flags: bitwise the same
         if name in ("ISHAP_PREFETCH=1", "ISHAP_GN_XCD=0", "ISHAP_GN_XCD=2", "ISHAP_IG4_NOUTER=0", "ISHAP_IG4_NOUTER=1", "ISHAP_EVENT_FENCE=1"):
             assert r_out == 0.0 and r_tap == 0.0 and r_gx == 0.0, name
+
+
+# ------------------------------------------------------------------------------------------ diagnostics
+_MARKS_WORKER = r"""
+import sys, ctypes as C, numpy as np, torch
+sys.path.insert(0, {root!r})
+from ishapediting_amd import synthetic, _lib
+from ishapediting_amd.unet import UNetModel
+from ishapediting_amd.unet_spec import UNetConfig, build_spec
+cfg = UNetConfig(image_size=32, in_channels=6, model_channels=64, out_channels=12, num_res_blocks=1,
+                 attention_resolutions="16,8", channel_mult=(1, 2, 4), num_head_channels=64)
+dev = torch.device("cuda", 0)
+m = UNetModel(cfg, dev)
+m.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 91)))
+x = torch.randn(1, 6, 32, 32, generator=torch.Generator().manual_seed(21)).to(dev)
+spec = build_spec(cfg)
+k = len(spec.output_blocks) - 2
+ch, sz = m.tap_shape(k)
+cot = (torch.randn(1, sz * sz, ch, generator=torch.Generator().manual_seed(5)) * 0.1).half().to(dev)
+m(x, [617.0], feat_layer=k, keep_for_backward=True)
+gx = m.backward_input(cot)
+tags, ms = (C.c_int * 64)(), (C.c_float * 64)()
+tb, te = C.c_float(), C.c_float()
+n = _lib.lib().ishap_unet_marks(m._h, tags, ms, 64, C.byref(tb), C.byref(te))
+import json
+print("MARKS " + json.dumps(dict(n=n, n_in=len(spec.input_blocks), k=k, tags=list(tags[:max(n, 0)]), ms=[float(v) for v in ms[:max(n, 0)]],
+                                tb=tb.value, te=te.value)))
+"""
+
+
+def test_backward_time_marks():
+    """ISHAP_BWD_MARKS=1 (include/ishap.h, ishap_unet_marks; tools/overlap_segments.py): a timing event after every block of the
+    backward pass.  With the switch: the tags come in the order the blocks are differentiated -- start, output blocks k ... 0, the
+    middle block, input blocks n-1 ... 0, end -- and the times do not decrease; without it the call returns 0 and records nothing."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for on in (True, False):
+        e = dict(os.environ)
+        e.pop("ISHAP_BWD_MARKS", None)
+        if on:
+            e["ISHAP_BWD_MARKS"] = "1"
+        r = subprocess.run([sys.executable, "-c", _MARKS_WORKER.format(root=root)], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("MARKS")][-1]
+        import json
+        d = json.loads(line[len("MARKS "):])
+        n, n_in, k, tags, ms, tb, te = d["n"], d["n_in"], d["k"], d["tags"], d["ms"], d["tb"], d["te"]
+        if not on:
+            assert n == 0
+            continue
+        want = [0] + [100 + i for i in range(k, -1, -1)] + [200] + [300 + i for i in range(n_in - 1, -1, -1)] + [999]
+        assert tags == want, (tags, want)
+        assert all(b >= a for a, b in zip(ms, ms[1:])) and ms[0] == 0.0 and ms[-1] > 0.0
+        assert tb == -1.0 and te == -1.0          # no deferred tail ran beside this backward
