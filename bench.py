@@ -85,11 +85,11 @@ def _cpu_info():
     return model, logical, usable
 
 
-def cpu_baseline(seed, reps=3):
+def cpu_baseline(seed, reps=5):
     """The oracle (torch-CPU restatement of the reference path, fp32) on every core this process may use, bounded
     sample: `reps` guided steps (forward + drag loss + autograd backward to the latent), `reps` unguided
-    steps and `reps` 64^3 decodes, each kind averaged, then extrapolated linearly to C3 = 40 guided steps + a 256^3
-    decode (x64 points)."""
+    steps and `reps` 64^3 decodes -- each kind after one discarded run, the MEDIAN taken -- then extrapolated linearly to
+    C3 = 40 guided steps + a 256^3 decode (x64 points)."""
     from oracle import ref_cpu as O
     from ishapediting_amd import synthetic
     from ishapediting_amd.unet_spec import build_spec, full_config
@@ -107,34 +107,39 @@ def cpu_baseline(seed, reps=3):
     orig = O.resize_feat_align(o["inter_feat"])
     setup = O.DragSetup(src, tgt, 12, 2.0 / RES, orig.shape[-1])
     print("[bench] cpu baseline: warm-up forward done", file=sys.stderr, flush=True)
+    # every kind: one UNTIMED first run (the first autograd pass builds its graph buffers and the allocator / thread pool are
+    # still warming: round 5's samples read 1.27 / 0.95 / 0.62 s), then `reps` timed runs whose MEDIAN is reported
     t_fwd, t_guided, t_dec = [], [], []
-    for r in range(reps):
+    for r in range(reps + 1):
         t0 = time.time()
         with torch.no_grad():
             diff.p_sample_guidance(net, img, GUIDED_STEPS - 1 - r, noise=torch.zeros_like(img), feat_layer=8)
-        t_fwd.append(time.time() - t0)
-    for r in range(reps):
+        if r > 0: t_fwd.append(time.time() - t0)
+    for r in range(reps + 1):
         t0 = time.time()
         x = img.clone().requires_grad_(True)
         o = diff.p_sample_guidance(net, x, GUIDED_STEPS - 1 - r, noise=torch.zeros_like(img), feat_layer=8)
         loss = O.drag_loss(O.resize_feat_align(o["inter_feat"]), orig + 0.01, setup, 0.4)
         torch.autograd.grad(loss, x)
-        t_guided.append(time.time() - t0)
-        print(f"[bench] cpu baseline: guided step {r}: {t_guided[-1]:.2f}s", file=sys.stderr, flush=True)
+        dt_ = time.time() - t0
+        if r > 0: t_guided.append(dt_)
+        print(f"[bench] cpu baseline: guided step {r}{' (discarded)' if r == 0 else ''}: {dt_:.2f}s", file=sys.stderr, flush=True)
     dec = synthetic.decoder_state_dict(4321)
-    for r in range(reps):
+    for r in range(reps + 1):
         t0 = time.time()
         with torch.no_grad():
             O.decode_volume(dec, img, 1.0, 0.0, 64)
-        t_dec.append(time.time() - t0)
-    mg, mf, md = (sum(v) / len(v) for v in (t_guided, t_fwd, t_dec))
+        if r > 0: t_dec.append(time.time() - t0)
+    med = lambda v: sorted(v)[len(v) // 2]
+    mg, mf, md = med(t_guided), med(t_fwd), med(t_dec)
     est = GUIDED_STEPS * mg + 64 * md
     return {"value": round(est, 2), "unit": "s/shape", "cores": cores, "kind": "port",
             "cpu_model": model, "logical_cpus": logical,
-            "sample": f"{reps} guided steps (mean {mg:.2f}s), {reps} unguided steps (mean {mf:.2f}s), {reps} 64^3 decodes "
-                      f"(mean {md:.2f}s) on {cores} threads of {model} ({logical} logical CPUs), fp32 torch-CPU oracle; "
+            "sample": f"after one discarded run of each kind: {reps} guided steps (median {mg:.2f}s), {reps} unguided steps (median {mf:.2f}s), "
+                      f"{reps} 64^3 decodes (median {md:.2f}s) on {cores} threads of {model} ({logical} logical CPUs), fp32 torch-CPU oracle; "
                       f"extrapolated to {GUIDED_STEPS} guided steps + 64x the decode points (256^3)",
-            "unguided_step_s": round(mf, 3), "guided_step_s": round(mg, 3), "decode64_s": round(md, 3)}
+            "unguided_step_s": round(mf, 3), "guided_step_s": round(mg, 3), "decode64_s": round(md, 3),
+            "guided_step_samples_s": [round(v, 3) for v in t_guided]}
 
 
 def visible_gpu_count():
@@ -488,17 +493,18 @@ def main():
           f"(stream time; rank 0's gather includes waiting for the slowest rank)", file=sys.stderr, flush=True)
 
     # ---- roofline leg: the same edit once more with HIP events around every implicit-GEMM launch ----
-    roofline = None
+    roofline = small_maps = step_breakdown = None
     if rank == 0:
         L = _lib.lib()
         # per-launch durations are measured in the PLAIN launch sequence: in the timed (default) configuration the forward tail
         # shares the chip with loss + backward, and a launch's duration inside that window is not the kernel's own
-        from ishapediting_amd import drag_utils as _du
-        _ov, _du._OVERLAP_TAIL = _du._OVERLAP_TAIL, False
+        ds.overlap_tail = False                  # this DragStuff only (not the module default); restored whatever happens
         L.ishap_profile_begin()
-        one_edit(ds, src, tgt)
-        torch.cuda.synchronize()
-        _du._OVERLAP_TAIL = _ov
+        try:
+            one_edit(ds, src, tgt)
+            torch.cuda.synchronize()
+        finally:
+            ds.overlap_tail = None               # back to the module default
         NV = 13
         out = (C.c_double * (NV * 3))()
         L.ishap_profile_end(out, NV)
@@ -524,12 +530,18 @@ def main():
             small_maps = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
                           "traffic": None, "kernel": "all conv/GEMM launches on the 8x8 and 16x16 maps (M <= 256)",
                           "launches_per_edit": int(sm_launch), "ms_per_edit": round(sm_ms, 2),
-                          "algorithmic_bytes_per_edit": int(sm_bytes)}
+                          "algorithmic_bytes_per_edit": int(sm_bytes), "algorithmic_bytes_per_launch": int(sm_bytes / max(sm_launch, 1))}
+        # the same launches' conv3x3 / 1x1 split per guided step (live, from the event records above)
+        c3_ms = c3_n = g1_ms = g1_n = 0.0
+        for row in shape_csv.strip().splitlines():
+            _M, _N, _K, c3, _tile, _ks, n_, main_ms, red_ms, _gf = (float(v) for v in row.split(","))
+            if c3: c3_ms += main_ms + red_ms; c3_n += n_
+            else: g1_ms += main_ms + red_ms; g1_n += n_
         # one entry per kernel symbol (the name rocprofv3 reports)
         names = ["igemm2_kernel<128, 128, 4, true, 1>", "igemm2_kernel<64, 64, 4, true, 1>",
                  "igemm2_kernel<128, 128, 4, false, 1>", "igemm2_kernel<64, 64, 4, false, 1>",
-                 "igemm2_kernel<64, 64, 4, true, 2>", "igemm_skinny_kernel<*, false>", "igemm_kernel<128, 128, 32, 2, 2, true>",
-                 "conv3_small_kernel<4>", "igemm4_kernel<128, 128, 128, 5, 3, 1>", "igemm4_kernel<64, 64, *, *, 3, 1>",
+                 "igemm2_kernel<64, 64, 4, true, 2>", "igemm_skinny_kernel<*, false>", "igemm_kernel<64, 64, 32, 2, 2, *>",
+                 "(unused)", "igemm4_kernel<128, 128, 128, 5, 3, 1>", "igemm4_kernel<64, 64, *, *, 3, 1>",
                  "igemm4_kernel<64, 64, *, 6, 3, 2>", "igemm4_kernel<64, 64, 8, 4, 3, 1>", "igemm4_kernel<128, 64, 64, 6, 3, 1>"]
         # (the '*'s stand for the map width 16 / 32 / 64 and the weight-ring depth 6 / 4 (4 for slices of 9-12 K-steps); the width-8
         # symbol -- the sliced, weight-streaming launches of the 8x8 maps -- has an entry of its own)
@@ -560,6 +572,21 @@ def main():
             except (KeyError, ValueError, ZeroDivisionError):
                 return None, None
         traffic, mfma_busy = counters(names[v])
+        if small_maps is not None and pj is not None and "small_maps" in pj:
+            small_maps["traffic"] = pj["small_maps"].get("bytes_per_launch")
+            small_maps["traffic_source"] = "committed profiles/pmc_traffic.json, group `small_maps`: " + str(pj["small_maps"].get("what"))
+        # per-class breakdown of one guided step in the plain launch sequence: conv / GEMM classes live (event records of this run,
+        # 40 guided steps + the decode's none), the other classes from the committed kernel trace of the same build
+        step_breakdown = {"conv3x3": {"ms": round(c3_ms / GUIDED_STEPS, 4), "launches": round(c3_n / GUIDED_STEPS, 1)},
+                          "gemm1x1": {"ms": round(g1_ms / GUIDED_STEPS, 4), "launches": round(g1_n / GUIDED_STEPS, 1)},
+                          "source": "conv3x3 / gemm1x1: HIP events on every implicit-GEMM dispatch of this run, per guided step"}
+        try:
+            sb = json.load(open(os.path.join(ROOT, "profiles", "step_breakdown.json")))
+            step_breakdown["trace"] = sb
+            step_breakdown["source"] += "; `trace`: committed profiles/step_breakdown.json (tools/step_timeline.py --json over the rocprofv3 " \
+                                        "kernel trace of tools/final_profile.sh, median guided step, plain sequence: ms and launches per kernel class)"
+        except (OSError, ValueError):
+            pass
         traffic_source = None if traffic is None else (
             "committed profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / MFMA passes of tools/pmc_step.py ("
             + str(pj.get("source", "tools/final_profile.sh")) + "); not collected live (counters cannot be read from inside this process)")
@@ -585,7 +612,7 @@ def main():
                     "top_single_symbol": top_single,
                     "all_variants": {names[i]: {"launches": int(out[i * 3]), "ms": round(out[i * 3 + 1], 3),
                                                 "tflops": round(out[i * 3 + 2] / max(out[i * 3 + 1], 1e-9) / 1e9, 1)}
-                                     for i in range(NV)}}
+                                     for i in range(NV) if out[i * 3] > 0}}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(1234)
@@ -626,7 +653,7 @@ def main():
             "surface_vertices": int(sv.shape[0]), "surface_triangles": int(st.shape[0]),
             "surface_extract_ms": round(surface_ms, 2),
             "surface_extract_ms_sphere256": round(surface_ms_sphere, 2), "sphere256_vertices": int(sv2.shape[0]),
-            "roofline": roofline, "roofline_small_maps": small_maps, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_small_maps": small_maps, "step_breakdown": step_breakdown, "cpu_baseline": cpu,
             "per_rank": per_rank,
         }
         if a.rehearse:

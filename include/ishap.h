@@ -27,7 +27,9 @@ int ishap_device_status(void);
  * one launch (gd/nn.py:16-18 needs group-wide sums); such a grid only completes when all of its workgroups are resident
  * together.  Within one process the library arbitrates: per device, ONE (model context, stream) pair at a time may launch
  * such grids; a call on another context / thread / stream that arrives while the holder's work is still in flight runs the
- * same kernels with one workgroup per group (same values, a few microseconds slower per launch) -- no action needed.
+ * same kernels with one workgroup per group, and the 8x8-map AttentionBlock kernel (which also hands data between workgroups
+ * inside a launch) as two launches of the same code (BITWISE the same values either way, a few microseconds slower per
+ * launch) -- no action needed.
  * The library is otherwise SINGLE-TENANT per GPU: another PROCESS using the same device, or a caller stream created with a
  * compute-unit mask, can keep part of such a grid from becoming resident; the wait is bounded, and the failure is reported
  * as described above (status word, NaN outputs, -3 from the next call), never a hang or a silently wrong result.
@@ -83,17 +85,18 @@ int ishap_unet_forward(ishap_unet* u, const float* x, const float* timesteps, in
 int ishap_unet_tap_shape(const ishap_unet* u, int feat_layer, int* channels, int* size);
 /* device pointer of the resident tap of the last forward: NHWC fp16 [N][S_tap*S_tap][C_tap] */
 const void* ishap_unet_tap_ptr(const ishap_unet* u);
-/* keep_for_backward is a bit set: bit 0 = keep what a following backward re-reads; bit 1 (with feat_layer >= 0) = enqueue
- * everything AFTER the tapped output block (the remaining output blocks and the fp32 head) on a stream owned by the
- * context, forked from `stream` at the tap.  The drag step needs only the tap for its loss and backward pass
+/* keep_for_backward is a bit set: bit 0 = keep what a following backward re-reads; bit 1 (with feat_layer >= 0) = the part of the
+ * network AFTER the tapped output block (the remaining output blocks and the fp32 head) is only PLANNED by the forward and later
+ * enqueued on a stream owned by the context.  The drag step needs only the tap for its loss and backward pass
  * (drag_utils.py:355-384), the model output only for the DDPM update after them (:385-393): the two then run side by side.
  * `out` is complete on a stream only after ishap_unet_join_tail(u, that stream); the next ishap_unet_forward, a
- * full-depth backward and ishap_unet_block_output join by themselves. */
+ * full-depth backward and ishap_unet_block_output join by themselves.
+ * LIFETIME: with bit 1 the library keeps the raw `out` pointer and writes through it when the tail runs -- `out` must stay allocated until ishap_unet_join_tail has been called for this forward (or the next
+ * forward / full-depth backward has joined it); freeing it earlier lets the tail write into memory that may have a new owner. */
 int ishap_unet_join_tail(ishap_unet* u, void* stream);
-/* Deferred form of the overlapped tail (the default; ISHAP_TAIL_DEFER=0: enqueued by the forward itself): the forward only plans the blocks after the tap;
- * this call enqueues them on the context's stream of its own, behind the point the backward pass marked after its first
- * output blocks (or behind the tap when no backward ran).  No-op when nothing is planned; ishap_unet_join_tail runs a plan that
- * was never enqueued. */
+/* Enqueues the planned tail on the context's own stream, behind the point the backward pass marked after its first output
+ * blocks (or behind the tap when no backward ran).  No-op when nothing is planned; ishap_unet_join_tail runs a plan that was
+ * never enqueued.  On failure the launches already enqueued stay ordered before the next join (the context remains usable). */
 int ishap_unet_run_tail(ishap_unet* u);
 /* Diagnostics (contexts created with ISHAP_BWD_MARKS=1 in the environment; otherwise returns 0): elapsed milliseconds from the start of
  * the last backward pass to the timing event recorded after each of its blocks -- tags: 0 start, 100 + i after output block i, 200

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libishap_hip.so")
-SOURCES = ["igemm.hip", "igemm2.hip", "igemm4.hip", "igemm_skinny.hip", "igemm_small3.hip", "norm.hip", "norm_bwd.hip", "norm_local.hip", "norm_api.hip", "attention.hip", "misc.hip", "ddpm.hip", "decode.hip", "decode_bwd.hip", "drag.hip", "surface.hip", "unet.hip", "backward.hip", "api.hip"]
+SOURCES = ["igemm.hip", "igemm2.hip", "igemm4.hip", "igemm_skinny.hip", "norm.hip", "norm_bwd.hip", "norm_local.hip", "norm_api.hip", "attention.hip", "misc.hip", "ddpm.hip", "decode.hip", "decode_bwd.hip", "drag.hip", "surface.hip", "unet.hip", "backward.hip", "api.hip"]
 # -amdgpu-kernarg-preload-count: the first 14 dwords of a kernel's SCALAR leading parameters arrive in SGPRs at dispatch
 # (gfx940+; csrc/common.h IgemmHot) instead of behind an s_load round trip at kernel entry
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-kernarg-preload-count=14"]

@@ -11,18 +11,7 @@ struct AttnArgs {
   int N = 1, T = 0, C = 0, heads = 0, d = 0;
   float alpha = 1.f;             // 1/sqrt(d)  (= s*s with s = d^-1/4, unet.py:348-351)
   int xcd_map = 1;               // XCD-aware workgroup -> (tile, head) mapping (attention.hip: attn_xcd_item); set by the launchers
-  // forward only, proj_parts > 0 (round 5): proj_out (unet.py:304) leaves the attention launch as per-head fp32 K slices
-  // slices[h][n * T + q][c] = sum_d a[q][h*d + d'] Wproj[c][h*d + d'] -- the consuming GroupNorm pass adds the heads up with proj's
-  // bias and the residual (common.h SlabSrc).  Every query tile is then computed by `proj_parts` workgroups that differ only in
-  // the C / proj_parts output columns of the slice they produce (the attention itself is recomputed: T <= 256, it is latency).
-  const half_t* wproj = nullptr; // [C rows (c_out, padded)][ldp]
-  int ldp = 0;
-  float* slices = nullptr;       // [heads][N * T][C]
-  int proj_parts = 0;
 };
-// proj_parts with which attn_forward_launch emits proj_out as per-head slices for this shape, 0 = it cannot
-// (ISHAP_ATTN_PROJ: 0 = never, the default -- measured, no gain; 1 = wherever built; 256 = only up to 256 tokens)
-int attn_proj_parts(int N, int T, int C, int d);
 int attn_forward_launch(const AttnArgs& a, hipStream_t s);
 int attn_backward_launch(const AttnArgs& a, hipStream_t s);
 
@@ -41,28 +30,12 @@ struct Attn8Args {
   unsigned* flags = nullptr;      // [N][heads][16], zero before the launch
   unsigned* status = nullptr;     // device status word (common.h)
   int spin_limit = 1 << 22;
+  int phases = 3;                 // set by the launcher: 3 = the whole block in one launch (flags); 1 = qkv only; 2 = attention + proj_out only
   int N = 1, C = 0, heads = 0;
   float alpha = 1.f;              // 1 / sqrt(64)
 };
 bool attn8_applicable(int N, int T, int C, int d);
-int attn8_fused_launch(const Attn8Args& a, hipStream_t s);
+// one_launch: the sequence holds the device's rendezvous tenancy (workgroups may wait for each other); false: two launches of the
+// same kernel, bitwise the same results
+int attn8_fused_launch(const Attn8Args& a, hipStream_t s, bool one_launch);
 
-// The backward twin (round 5): d proj_out -> attention backward (both roles) -> d qkv of an 8x8-map AttentionBlock in one launch.
-// No workgroup waits for another: every one of a head's 12 workgroups recomputes the head's dA (a 64 x 64 x C product) and its
-// attention backward (T = 64: one tile) itself and differs only in the columns of the input-gradient slice it produces.
-struct Attn8BwdArgs {
-  const half_t* dy = nullptr;      // [N][64][C] gradient arriving at proj_out's output
-  const half_t* wprojT = nullptr;  // proj_out's input-gradient operand [C rows (c_in)][ldp] (ConvW::wT)
-  const half_t* wqkvT = nullptr;   // qkv's input-gradient operand [C rows (c_in)][ldq]
-  int ldp = 0, ldq = 0;
-  const half_t* qkv = nullptr;     // forward tensors (AttnSaved)
-  const half_t* aout = nullptr;
-  const float* lse = nullptr;
-  half_t* dA = nullptr;            // [N][64][C] scratch: every part of a head writes the same values
-  half_t* dqkv = nullptr;          // [N][64][3C] scratch, likewise
-  float* slices = nullptr;         // [heads][N * 64][C] fp32: slice h = dqkv_h Wqkv[h*192 .. +191][:]  (the gradient at the GroupNorm output)
-  int N = 1, C = 0, heads = 0;
-  float alpha = 1.f;
-};
-bool attn8_bwd_applicable(int N, int T, int C, int d);
-int attn8_bwd_fused_launch(const Attn8BwdArgs& a, hipStream_t s);

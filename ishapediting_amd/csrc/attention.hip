@@ -79,11 +79,7 @@ __device__ __forceinline__ int attn_xcd_item(int lin, int total, int on) {
 // four-wave workgroup per CU (T = 1024, 8 heads: 128 workgroups) every global -> LDS -> MFMA round trip of a tile was
 // exposed; two waves per SIMD on interleaved tiles hide them (T = 1024: 19.9 -> ~11 us).
 // TEAMS = 2 or 4 (round 3: four teams = 1024 threads when the sequence has >= 8 key tiles, so that a team walks T / 256 of them)
-// NT > 0 (round 5, T <= 256): proj_out as per-head fp32 slices from the same launch (attention.h, AttnArgs::proj_parts).  The query
-// tile's a (64 x D, fp16 like the tensor the backward reads) goes through LDS to all 4 * TEAMS waves; wave w multiplies the 16 queries
-// of block w & 3 with NT 16-row panels of Wproj[:, h D .. h D + D) -- A fragments straight from global memory, requested before the
-// team merge -- and stores slice^T accumulators, whose 4 rows per lane are 4 consecutive output channels of one query (16-byte stores).
-template <int D, int TEAMS, int NT = 0>
+template <int D, int TEAMS>
 __global__ __launch_bounds__(256 * TEAMS) void attn_fwd_kernel(const void* h_qkv, void* h_out, float* h_lse, int h_T, int h_C, AttnArgs a0) {
   // leading scalar parameters are preloaded into SGPRs at dispatch (common.h, IgemmHot); the block `a0` arrives by s_load
   AttnArgs a = a0;
@@ -102,10 +98,7 @@ __global__ __launch_bounds__(256 * TEAMS) void attn_fwd_kernel(const void* h_qkv
   half_t* const sV = sV2 + team * 64 * VS;
   // item = tile + ntile * (head + heads * image)
   const int item = attn_xcd_item(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z, a0.xcd_map);
-  constexpr bool PROJ = NT > 0;
-  // PROJ: gridDim.x = tiles * parts, the parts of a tile adjacent (they read the same q, K and V)
-  const int xi = item % (int)gridDim.x, part = PROJ ? xi % a0.proj_parts : 0;
-  const int q0 = (PROJ ? xi / a0.proj_parts : xi) * 64, h = (item / (int)gridDim.x) % (int)gridDim.y, n = item / (int)(gridDim.x * gridDim.y);
+  const int q0 = (item % (int)gridDim.x) * 64, h = (item / (int)gridDim.x) % (int)gridDim.y, n = item / (int)(gridDim.x * gridDim.y);
   const int ld = 3 * a.C;
   const int g = lane >> 4, col = lane & 15;
   const half_t* base = a.qkv + (long long)n * a.T * ld + h * 3 * D;
@@ -181,17 +174,6 @@ __global__ __launch_bounds__(256 * TEAMS) void attn_fwd_kernel(const void* h_qkv
       }
     }
   }
-  // PROJ: this wave's Wproj fragments, in flight across the merge
-  const int pw = threadIdx.x >> 6, qb = pw & 3;
-  const int c_base = PROJ ? (part * 4 * TEAMS + (pw >> 2) * 4) * NT * 4 : 0;      // (part, wave >> 2) -> NT * 16 consecutive output channels
-  half8 wf[PROJ ? NT : 1][KK];
-  if constexpr (PROJ) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-        wf[t][kk] = *reinterpret_cast<const half8*>(a0.wproj + (long long)(c_base + t * 16 + col) * a0.ldp + h * D + kk * 32 + 8 * g);
-  }
   // merge the teams' states (teams 1 .. -> LDS -> team 0, in team order): m' = max, sums rescaled by exp(m - m')
   __syncthreads();                           // every team is done with its tiles: the states go where the tiles were
   if (team > 0) {
@@ -204,48 +186,28 @@ __global__ __launch_bounds__(256 * TEAMS) void attn_fwd_kernel(const void* h_qkv
       for (int r = 0; r < 4; ++r) dst[2 + i * 4 + r] = ot[i][r];
   }
   __syncthreads();
-  if (!PROJ && team > 0) return;
-  // PROJ: the tile's a for every wave, behind the merge states (which team 0 is still reading)
-  half_t* const sO = reinterpret_cast<half_t*>(attn_smem + (TEAMS - 1) * 256 * MRG * 4);
-  static_assert(!PROJ || (TEAMS - 1) * 256 * MRG * 4 + 64 * RS * 2 <= TEAMS * 64 * (RS + VS) * 2, "the output tile fits behind the merge states");
-  if (team == 0) {
+  if (team > 0) return;
 #pragma unroll
-    for (int t = 1; t < TEAMS; ++t) {
-      const float* src = mrg + ((t - 1) * 256 + tid) * MRG;
-      const float m1 = src[0], l1 = src[1];
-      const float mn = fmaxf(m, m1);
-      const float c0 = __expf(m - mn), c1 = __expf(m1 - mn);
-      lsum = lsum * c0 + l1 * c1;
+  for (int t = 1; t < TEAMS; ++t) {
+    const float* src = mrg + ((t - 1) * 256 + tid) * MRG;
+    const float m1 = src[0], l1 = src[1];
+    const float mn = fmaxf(m, m1);
+    const float c0 = __expf(m - mn), c1 = __expf(m1 - mn);
+    lsum = lsum * c0 + l1 * c1;
 #pragma unroll
-      for (int i = 0; i < DS; ++i)
+    for (int i = 0; i < DS; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ot[i][r] = ot[i][r] * c0 + src[2 + i * 4 + r] * c1;
-      m = mn;
-    }
-    const int q = q0 + wave * 16 + col;
-    const float inv = 1.f / lsum;
-#pragma unroll
-    for (int i = 0; i < DS; ++i) {
-      const half4 o4 = {(half_t)(ot[i][0] * inv), (half_t)(ot[i][1] * inv), (half_t)(ot[i][2] * inv), (half_t)(ot[i][3] * inv)};
-      if (part == 0) *reinterpret_cast<half4*>(a.out + ((long long)n * a.T + q) * a.C + h * D + i * 16 + 4 * g) = o4;
-      if constexpr (PROJ) *reinterpret_cast<half4*>(sO + (wave * 16 + col) * RS + i * 16 + 4 * g) = o4;
-    }
-    if (g == 0 && part == 0) a.lse[((long long)n * a.heads + h) * a.T + q] = m + __logf(lsum);
+      for (int r = 0; r < 4; ++r) ot[i][r] = ot[i][r] * c0 + src[2 + i * 4 + r] * c1;
+    m = mn;
   }
-  if constexpr (PROJ) {
-    __syncthreads();
-    half8 of[KK];
+  const int q = q0 + wave * 16 + col;
+  const float inv = 1.f / lsum;
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) of[kk] = ld_frag(sO, RS, qb * 16, kk * 32, lane);
-    float* dst = a0.slices + (((long long)h * a.N + n) * a.T + q0 + qb * 16 + col) * a.C + c_base + 4 * g;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][kk], of[kk], acc, 0, 0, 0);
-      *reinterpret_cast<f32x4*>(dst + t * 16) = acc;          // rows 4g .. 4g+3 of slice^T = 4 consecutive channels of query `col`
-    }
+  for (int i = 0; i < DS; ++i) {
+    const half4 o4 = {(half_t)(ot[i][0] * inv), (half_t)(ot[i][1] * inv), (half_t)(ot[i][2] * inv), (half_t)(ot[i][3] * inv)};
+    *reinterpret_cast<half4*>(a.out + ((long long)n * a.T + q) * a.C + h * D + i * 16 + 4 * g) = o4;
   }
+  if (g == 0) a.lse[((long long)n * a.heads + h) * a.T + q] = m + __logf(lsum);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -253,25 +215,15 @@ __global__ __launch_bounds__(256 * TEAMS) void attn_fwd_kernel(const void* h_qkv
 // Same transposed arrangement as the forward: S^T = K Q^T and dP^T = V dA^T put one query in a lane (lse and D_q are
 // per-lane scalars), dS^T is packed in registers as the B operand of dQ^T = K^T dS^T, and K^T comes from the row-major
 // K tile through the transposed LDS read.  Nothing is staged transposed and nothing round-trips through LDS.
-// team merge of the backward bodies: NA accumulator quads per thread, TEAMS = 2: team 1 -> team 0; TEAMS = 4: teams 2, 3 ->
-// teams 0, 1, then team 1 -> team 0 (fixed order (t0 + t2) + (t1 + t3): bitwise reproducible).  mrg: (TEAMS / 2) * NA * 256 quads.
-// Returns false for the teams that are done (they have passed every barrier of the merge).
+// team merge of the backward bodies: NA accumulator quads per thread, team 1 -> team 0 (fixed order: bitwise reproducible).
+// mrg: NA * 256 quads.  Returns false for the team that is done (it has passed every barrier of the merge).
+// (A four-team form -- 1 024 threads, the kernel held to 128 registers -- was built in round 4, measured slower in situ,
+// 0.1772 -> 0.1779-0.1782 s/shape, and removed in round 6.)
 template <int NA, int TEAMS>
 __device__ __forceinline__ bool attn_bwd_merge(f32x4 (&acc)[NA], int team, int tid, float* mrg) {
+  static_assert(TEAMS == 1 || TEAMS == 2, "one or two teams");
   if (blockDim.x == 256 || TEAMS == 1) return true;          // a single tile is launched with one team
-  f32x4* m4 = reinterpret_cast<f32x4*>(mrg);   // [slot][NA][256] 16-byte entries
-  if (TEAMS == 4) {
-    if (team >= 2) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) m4[((team - 2) * NA + i) * 256 + tid] = acc[i];
-    }
-    __syncthreads();
-    if (team < 2) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) acc[i] += m4[(team * NA + i) * 256 + tid];
-    }
-    __syncthreads();
-  }
+  f32x4* m4 = reinterpret_cast<f32x4*>(mrg);   // [NA][256] 16-byte entries
   if (team == 1) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) m4[i * 256 + tid] = acc[i];
@@ -482,8 +434,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int n, int 
 }
 
 // role 0 = dQ of 64 queries, role 1 = dK/dV of 64 keys (independent of each other, see above); grid (tiles, heads, 2 * images)
-// Each workgroup is TEAMS (2 or 4) teams of four waves on alternating tiles (own staging buffers, shared barriers), merged at the
-// end.  Two teams by default; the four-team form is a measured loss (attn_backward_launch).
+// Each workgroup is two teams of four waves on alternating tiles (own staging buffers, shared barriers), merged at the end.
 // dynamic LDS: [TEAMS] tile A, [TEAMS] tile B, [TEAMS][64 D_q | 64 lse], merge area (TEAMS / 2) * 2 * DS * 4 * 256 floats
 template <int D, int TEAMS>
 __global__ __launch_bounds__(256 * TEAMS) void attn_bwd_kernel(const void* h_qkv, const void* h_out, const void* h_dout, void* h_dqkv, float* h_lse,
@@ -513,28 +464,8 @@ static int check_attn(const AttnArgs& a) {
   return 0;
 }
 
-// teams of the forward launch: four once a team of two would walk >= 4 key tiles (ISHAP_ATTN_TEAMS=2 keeps two; =4: four from 4 tiles on)
-static int attn_fwd_teams(int ntile) {
-  static const int teams_env = [] { const char* e = getenv("ISHAP_ATTN_TEAMS"); return e ? atoi(e) : 0; }();
-  const bool four = teams_env == 2 ? false : (teams_env == 4 ? ntile >= 4 : ntile >= 8);
-  return four ? 4 : 2;
-}
-static bool attn_proj_nt_built(int teams, int nt) { return teams == 2 ? (nt >= 1 && nt <= 4) || nt == 6 || nt == 8 : nt >= 1 && nt <= 4; }
-
-int attn_proj_parts(int N, int T, int C, int d) {
-  static const int on = [] { const char* e = getenv("ISHAP_ATTN_PROJ"); return e ? atoi(e) : 0; }();
-  // NOT the default (ISHAP_ATTN_PROJ=1 | 256 = only up to 256 tokens): measured in situ (profiles/round5_ab_attn_proj.txt) the launch
-  // it removes (6.7 us + a boundary) is paid back by the slices -- heads x the tensor in fp32: 9.4 MB at 16 x 16, 16.8 MB at 32 x 32 --
-  // which the attention launch writes (6.1 -> 11.4 us, 12.3 -> 18.8 us) and the consuming GroupNorm pass reads (+1.2 ... 4 us).
-  // Shapes: batch 1-2 on maps up to 16 x 16 in four parts (48 -> 192 workgroups at 12 heads), batch 1 on the 32 x 32 maps in two
-  // (128 -> 256 workgroups).  The 8 x 8 maps take attn8_fused_kernel when it applies and come here otherwise.
-  if (!on || d != 64 || T % 64 != 0) return 0;
-  const int parts = T <= 256 ? 4 : 2;
-  if (T <= 256 ? N * T > 512 : (T != 1024 || N != 1 || on == 256)) return 0;
-  const int per_wave = parts * attn_fwd_teams(T / 64) * 16;
-  if (C % per_wave != 0 || !attn_proj_nt_built(attn_fwd_teams(T / 64), C / per_wave)) return 0;
-  return parts;
-}
+// teams of the forward launch: four once a team of two would walk >= 4 key tiles (T = 1024: 13.5 -> 12.5 us, round 3)
+static int attn_fwd_teams(int ntile) { return ntile >= 8 ? 4 : 2; }
 
 static int attn_xcd_on() {
   static const int on = [] { const char* e = getenv("ISHAP_ATTN_XCD"); return e ? atoi(e) : 1; }();
@@ -555,28 +486,7 @@ int attn_forward_launch(const AttnArgs& a_in, hipStream_t s) {
     ISHAP_TRY(ishap_set_max_lds((const void*)kern, smem));                                                        \
     hipLaunchKernelGGL(kern, g, dim3(256 * TM), smem, s, (const void*)a.qkv, (void*)a.out, a.lse, a.T, a.C, a);    \
   } while (0)
-  if (a.proj_parts > 0) {
-    // proj_out as per-head slices: every wave NT = C / (parts * teams * 16) panels of 16 output channels
-    const int teams = four ? 4 : 2;
-    ISHAP_REQUIRE(a.d == 64 && a.wproj && a.slices && a.ldp >= a.C && a.C % (a.proj_parts * teams * 16) == 0, "attention + proj_out: shape");
-    g.x = ntile * a.proj_parts;
-    const int nt = a.C / (a.proj_parts * teams * 16);
-    ISHAP_REQUIRE(attn_proj_nt_built(teams, nt), "attention + proj_out: channel count");
-#define ATTN_FWD_PROJ(TM, NTv)                                                                                    \
-  do {                                                                                                            \
-    auto kern = attn_fwd_kernel<64, TM, NTv>;                                                                     \
-    const int smem = TM * 64 * ((64 + 8) + (64 + 16)) * (int)sizeof(half_t);                                      \
-    ISHAP_TRY(ishap_set_max_lds((const void*)kern, smem));                                                        \
-    hipLaunchKernelGGL(kern, g, dim3(256 * TM), smem, s, (const void*)a.qkv, (void*)a.out, a.lse, a.T, a.C, a);    \
-  } while (0)
-    if (four) {
-      if (nt == 1) ATTN_FWD_PROJ(4, 1); else if (nt == 2) ATTN_FWD_PROJ(4, 2); else if (nt == 3) ATTN_FWD_PROJ(4, 3); else ATTN_FWD_PROJ(4, 4);
-    } else {
-      if (nt == 1) ATTN_FWD_PROJ(2, 1); else if (nt == 2) ATTN_FWD_PROJ(2, 2); else if (nt == 3) ATTN_FWD_PROJ(2, 3);
-      else if (nt == 4) ATTN_FWD_PROJ(2, 4); else if (nt == 6) ATTN_FWD_PROJ(2, 6); else ATTN_FWD_PROJ(2, 8);
-    }
-#undef ATTN_FWD_PROJ
-  } else if (a.d == 64) { if (four) ATTN_FWD(64, 4); else ATTN_FWD(64, 2); }
+  if (a.d == 64) { if (four) ATTN_FWD(64, 4); else ATTN_FWD(64, 2); }
   else { if (four) ATTN_FWD(32, 4); else ATTN_FWD(32, 2); }
 #undef ATTN_FWD
   ISHAP_CHECK_HIP(hipGetLastError());
@@ -588,12 +498,7 @@ int attn_backward_launch(const AttnArgs& a_in, hipStream_t s) {
   a.xcd_map = attn_xcd_on();
   ISHAP_TRY(check_attn(a));
   dim3 g(a.T / 64, a.heads, a.N * 2);
-  // one tile: a second team would have nothing to do.  Four teams (ISHAP_ATTN_BWD_TEAMS=4: from 4 tiles on) are built and tested
-  // but NOT the default: at 1024 threads the kernel is held to 128 registers (20 bytes of spills) and in situ the step is slower
-  // than with two teams (0.1772 vs 0.1779-0.1782 s/shape, profiles/round4_env_ab_attention_bwd_teams.txt)
-  static const int teams_env = [] { const char* e = getenv("ISHAP_ATTN_BWD_TEAMS"); return e ? atoi(e) : 0; }();
-  const int ntile = a.T / 64;
-  const bool four = teams_env == 4 && ntile >= 4;
+  // one tile: a second team would have nothing to do
 #define ATTN_BWD(Dv, TM, THREADS)                                                                                              \
   do {                                                                                                                         \
     auto kern = attn_bwd_kernel<Dv, TM>;                                                                                       \
@@ -602,8 +507,8 @@ int attn_backward_launch(const AttnArgs& a_in, hipStream_t s) {
     hipLaunchKernelGGL(kern, g, dim3(THREADS), smem, s, (const void*)a.qkv, (const void*)a.out, (const void*)a.dout,           \
                        (void*)a.dqkv, a.lse, a.Dbuf, a.T, a.C, a);                                                             \
   } while (0)
-  if (a.d == 64) { if (four) ATTN_BWD(64, 4, 1024); else ATTN_BWD(64, 2, a.T > 64 ? 512 : 256); }
-  else { if (four) ATTN_BWD(32, 4, 1024); else ATTN_BWD(32, 2, a.T > 64 ? 512 : 256); }
+  if (a.d == 64) ATTN_BWD(64, 2, a.T > 64 ? 512 : 256);
+  else ATTN_BWD(32, 2, a.T > 64 ? 512 : 256);
 #undef ATTN_BWD
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
@@ -624,7 +529,9 @@ int attn_backward_launch(const AttnArgs& a_in, hipStream_t s) {
 //   3. its share of proj_out's K slice of this head: out_h[64][n] = a_h[64][64] Wproj[n][h*64 ..]^T for its 16-channel tiles
 //      (64 tiles of C = 1024 dealt over the 12 parts), fp32, into slices[h]: the consumer adds the 16 slices up.
 // Part 0 also writes a_h and lse for the backward pass.  All parts of all heads must be resident together: <= 256 workgroups
-// (the launcher), on a sequence that holds the device's rendezvous tenancy (the caller).
+// (the launcher), on a sequence that holds the device's rendezvous tenancy (the caller).  A sequence WITHOUT the tenancy runs the
+// same kernel as two launches (Attn8Args::phases = 1, then 2): step 1 alone, then steps 2-3 without the wait -- no workgroup
+// waits for another, and the values are bitwise those of the one-launch form (round 6).
 constexpr int A8_PARTS = 12;
 
 __device__ __forceinline__ half4 ld8_agent(const half_t* p) {
@@ -662,16 +569,17 @@ __global__ __launch_bounds__(A8_WAVES * 64) void attn8_fused_kernel(Attn8Args a)
   const int t0 = part * tper + (part < trem ? part : trem), tcnt = tper + (part < trem ? 1 : 0);
   constexpr int TMAX = 6;                                                 // C <= 1152 (launcher)
   half8 wp[TMAX][KK];
+  const bool do1 = (a.phases & 1) != 0, do23 = (a.phases & 2) != 0;        // block-uniform (Attn8Args::phases)
 #pragma unroll
   for (int t = 0; t < TMAX; ++t)
-    if (t < tcnt) {
+    if (t < tcnt && do23) {
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
         wp[t][kk] = *reinterpret_cast<const half8*>(a.wproj + (long long)((t0 + t) * 16 + col) * C + h * D + kk * 32 + 8 * g);
     }
   // ---- phase 1: 64 tokens x 16 qkv channels, K = C split over the four waves ----
   const int n0 = h * 3 * D + part * 16;
-  {
+  if (do1) {
     const int ks = C / 64, per = (ks + A8_WAVES - 1) / A8_WAVES, s0 = wave * per, s1 = min(ks, s0 + per);
     const half_t* wrow = a.wqkv + (long long)(n0 + col) * C + 8 * g;
     f32x4 acc[4];
@@ -690,11 +598,7 @@ __global__ __launch_bounds__(A8_WAVES * 64) void attn8_fused_kernel(Attn8Args a)
     // every fragment load of a batch of up to four K-steps is issued before the first MFMA (a wave has at most four steps at
     // C = 1024 with four waves: one round trip instead of a chain of them -- the two-deep ring took 6.5 us here)
     Frag ring[4];
-#ifdef A8_ABL_NO_PHASE1            // timing probe: wrong results
-    const int s1x = s0;
-#else
     const int s1x = s1;
-#endif
     for (int sb = s0; sb < s1x; sb += 4) {
 #pragma unroll
       for (int dd = 0; dd < 4; ++dd)
@@ -726,13 +630,11 @@ __global__ __launch_bounds__(A8_WAVES * 64) void attn8_fused_kernel(Attn8Args a)
   if (tid == 0) s_ok = 1;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's stores are acknowledged ...
   __syncthreads();                                                        // ... and so are every wave's (and red[] has been read)
+  if (!do23) return;                                                      // two-launch form, first launch: the kernel boundary is the hand-off
   unsigned* const flags = a.flags + ((long long)n * a.heads + h) * 16;
-  if (tid == 0) __hip_atomic_store(flags + part, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef A8_ABL_PHASE1_ONLY          // timing probe: wrong results
-  return;
-#endif
+  if (do1 && tid == 0) __hip_atomic_store(flags + part, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---- phase 2: the head's q | k | v ----
-  if (tid < A8_PARTS) {
+  if (do1 && tid < A8_PARTS) {                                            // one-launch form only: wait for the head's other parts
     int spins = 0;
     unsigned f;
     do {
@@ -855,7 +757,7 @@ bool attn8_applicable(int N, int T, int C, int d) {
   return on && T == 64 && d == 64 && C % 64 == 0 && C / 16 <= 6 * A8_PARTS && N * (C / 64) * A8_PARTS <= ishap_cu_count();
 }
 
-int attn8_fused_launch(const Attn8Args& a, hipStream_t s) {
+int attn8_fused_launch(const Attn8Args& a, hipStream_t s, bool one_launch) {
   ISHAP_REQUIRE(a.xn && a.wqkv && a.bqkv && a.wproj && a.qkv && a.aout && a.lse && a.slices && a.flags && a.status, "attn8: null argument");
   ISHAP_REQUIRE(a.heads * 64 == a.C && a.C / 16 <= 6 * A8_PARTS && a.N * a.heads * A8_PARTS <= ishap_cu_count(), "attn8: shape / co-residency");
   ISHAP_TRY(ishap_set_max_lds((const void*)attn8_fused_kernel, A8_SMEM));
@@ -863,136 +765,18 @@ int attn8_fused_launch(const Attn8Args& a, hipStream_t s) {
   // polls before the wait for the head's other parts gives up (ISHAP_GN_SPIN_LIMIT: the test hook of the GroupNorm rendezvous)
   static const int spin = [] { const char* e = getenv("ISHAP_GN_SPIN_LIMIT"); const int n = e ? atoi(e) : 0; return n > 0 ? n : (1 << 22); }();
   b.spin_limit = spin;
-  hipLaunchKernelGGL(attn8_fused_kernel, dim3(a.heads * A8_PARTS, a.N), dim3(A8_WAVES * 64), A8_SMEM, s, b);
-  ISHAP_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Round 5: backward of an 8x8-map AttentionBlock after its proj_out gradient arrives, one launch (Attn8BwdArgs, attention.h).
-// Workgroup (head h, part j), 512 threads:
-//   A. dA_h[token][c] = sum_n dY[token][n] WprojT[h*64 + c][n]: wave w owns channel tile w & 3 and K half w >> 2, fragments straight
-//      from global memory in batches of four K-steps, the two halves meet in LDS; fp16 (the stored gradient map of the three-launch
-//      form) to the dA scratch -- all 12 parts of a head write the same 8 KB;
-//   B. waves 0-3: attention backward of the head's single tile, both roles one after the other, by the SAME device functions the
-//      stand-alone kernel runs (attn_bwd_dq_body / attn_bwd_dkv_body with one team): they read q, k, v, a, lse and this workgroup's
-//      own dA, and write dq | dk | dv to the dqkv scratch (again the same bytes from every part);
-//   C. this part's 16-column tiles of the head's K slice of d(GroupNorm output): out_h[token][c] = sum_{n in head} dqkv[token][n]
-//      WqkvT[c][n] (K = 192), fp32, left as a pending slice for the group-local GroupNorm-backward kernel.
-// Nothing is handed between workgroups, so the kernel needs no tenancy and no bounded wait.
-constexpr int A8B_PARTS = 12;
-__global__ __launch_bounds__(512) void attn8_bwd_fused_kernel(Attn8BwdArgs a) {
-  constexpr int D = 64, RS = D + 8;
-  extern __shared__ __attribute__((aligned(16))) char a8b_smem[];          // 32 KB: phase A partials, then the bodies' tiles
-  f32x4 (*red)[4][64] = reinterpret_cast<f32x4 (*)[4][64]>(a8b_smem);     // [4 channel tiles][4 token sub-tiles][64 lanes]: K half 1's partials
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, col = lane & 15;
-  const int h = blockIdx.x / A8B_PARTS, part = blockIdx.x - h * A8B_PARTS, n = blockIdx.y;
-  const int C = a.C, ld3 = 3 * C;
-  // ---- phase A ----
-  {
-    const int ct = wave & 3, kh = wave >> 2;
-    const int ks = C / 64, half_steps = (ks + 1) / 2, s0 = kh * half_steps, s1 = min(ks, s0 + half_steps);
-    const half_t* wrow = a.wprojT + (long long)(h * D + ct * 16 + col) * a.ldp + 8 * g;
-    const half_t* yrow = a.dy + (long long)n * 64 * C + (long long)col * C + 8 * g;
-    f32x4 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    struct Frag { half8 w[2]; half8 x[4][2]; };
-    Frag ring[4];
-    for (int sb = s0; sb < s1; sb += 4) {
-#pragma unroll
-      for (int dd = 0; dd < 4; ++dd)
-        if (sb + dd < s1) {
-          const int s = sb + dd;
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) ring[dd].w[kk] = *reinterpret_cast<const half8*>(wrow + s * 64 + kk * 32);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-              ring[dd].x[j][kk] = *reinterpret_cast<const half8*>(yrow + (long long)(j * 16) * C + s * 64 + kk * 32);
-        }
-#pragma unroll
-      for (int dd = 0; dd < 4; ++dd)
-        if (sb + dd < s1) {
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[dd].w[kk], ring[dd].x[j][kk], acc[j], 0, 0, 0);
-        }
-    }
-    if (kh == 1) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) red[ct][j][lane] = acc[j];
-    }
-    __syncthreads();
-    if (kh == 0) {
-      half_t* drow = a.dA + (long long)n * 64 * C + h * D + ct * 16 + 4 * g;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 v = acc[j] + red[ct][j][lane];                       // K half 0 + K half 1 (fixed order)
-        const half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        *reinterpret_cast<half4*>(drow + (long long)(j * 16 + col) * C) = o;
-      }
-    }
+  if (one_launch) {
+    b.phases = 3;
+    hipLaunchKernelGGL(attn8_fused_kernel, dim3(a.heads * A8_PARTS, a.N), dim3(A8_WAVES * 64), A8_SMEM, s, b);
+  } else {
+    // a sequence without the device's rendezvous tenancy: the SAME kernel twice -- qkv, then attention + proj_out slices -- with the
+    // kernel boundary as the hand-off instead of the flags; same instructions on the same operands, so the same bits (round 6)
+    b.phases = 1;
+    hipLaunchKernelGGL(attn8_fused_kernel, dim3(a.heads * A8_PARTS, a.N), dim3(A8_WAVES * 64), A8_SMEM, s, b);
+    b.phases = 2;
+    hipLaunchKernelGGL(attn8_fused_kernel, dim3(a.heads * A8_PARTS, a.N), dim3(A8_WAVES * 64), A8_SMEM, s, b);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this workgroup's dA is in memory before anyone reads it back
-  __syncthreads();
-  // ---- phase C operands: requested now, used after phase B.  Waves 0-3 take the even tiles of the part, waves 4-7 the odd ones ----
-  const int role = wave >> 2, ms = wave & 3;
-  const int ntile = C / 16;
-  const int tper = ntile / A8B_PARTS, trem = ntile - tper * A8B_PARTS;
-  const int t0 = part * tper + (part < trem ? part : trem), tcnt = tper + (part < trem ? 1 : 0);
-  constexpr int TMAX = 3, KC = 3 * D / 32;                                // <= 6 tiles per part, every other one per wave group; six 32-deep K pieces
-  half8 wq[TMAX][KC];
-#pragma unroll
-  for (int t = 0; t < TMAX; ++t)
-    if (2 * t + role < tcnt) {
-#pragma unroll
-      for (int kk = 0; kk < KC; ++kk)
-        wq[t][kk] = *reinterpret_cast<const half8*>(a.wqkvT + (long long)((t0 + 2 * t + role) * 16 + col) * a.ldq + h * 3 * D + kk * 32 + 8 * g);
-    }
-  // ---- phase B: the stand-alone kernel's two roles side by side, one team each (both bodies pass exactly two barriers) ----
-  AttnArgs aa;
-  aa.qkv = a.qkv; aa.out = const_cast<half_t*>(a.aout); aa.dout = a.dA; aa.dqkv = a.dqkv; aa.lse = const_cast<float*>(a.lse);
-  aa.N = a.N; aa.T = 64; aa.C = C; aa.heads = a.heads; aa.d = D; aa.alpha = a.alpha;
-  half_t* const s0p = reinterpret_cast<half_t*>(a8b_smem) + role * (2 * 64 * RS + 256);      // + 256 halfs = the dK/dV role's 128 floats
-  half_t* const s1p = s0p + 64 * RS;
-  float* const sD = reinterpret_cast<float*>(s1p + 64 * RS);
-  float* const mrg = reinterpret_cast<float*>(a8b_smem);                  // unused with one team
-  if (role == 0) attn_bwd_dq_body<D, 1>(aa, n, 0, h, 0, s0p, s1p, mrg);
-  else attn_bwd_dkv_body<D, 1>(aa, n, 0, h, 0, s0p, s1p, sD, mrg);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  // ---- phase C: wave = (token sub-tile, tile parity) ----
-  half8 df[KC];
-  const half_t* drow = a.dqkv + ((long long)n * 64 + ms * 16 + col) * ld3 + h * 3 * D + 8 * g;
-#pragma unroll
-  for (int kk = 0; kk < KC; ++kk) df[kk] = *reinterpret_cast<const half8*>(drow + kk * 32);
-  float* const slice = a.slices + ((long long)h * a.N + n) * 64 * C;
-#pragma unroll
-  for (int t = 0; t < TMAX; ++t)
-    if (2 * t + role < tcnt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < KC; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[t][kk], df[kk], acc, 0, 0, 0);
-      *reinterpret_cast<f32x4*>(slice + (long long)(ms * 16 + col) * C + (t0 + 2 * t + role) * 16 + 4 * g) = acc;
-    }
-}
-
-bool attn8_bwd_applicable(int N, int T, int C, int d) {
-  static const int on = [] { const char* e = getenv("ISHAP_ATTN8_BWD"); return e ? atoi(e) : 0; }();
-  return on && T == 64 && d == 64 && C % 64 == 0 && C / 16 <= 6 * A8B_PARTS;
-}
-
-int attn8_bwd_fused_launch(const Attn8BwdArgs& a, hipStream_t s) {
-  ISHAP_REQUIRE(a.dy && a.wprojT && a.wqkvT && a.qkv && a.aout && a.lse && a.dA && a.dqkv && a.slices, "attn8 backward: null argument");
-  ISHAP_REQUIRE(a.heads * 64 == a.C && a.C / 16 <= 6 * A8B_PARTS && a.ldp >= a.C && a.ldq >= 3 * a.C, "attn8 backward: shape");
-  constexpr int smem = 40 * 1024;            // phase A's partial tiles (16 KB), then two roles x (two 64 x 72 fp16 tiles + 128 floats)
-  ISHAP_TRY(ishap_set_max_lds((const void*)attn8_bwd_fused_kernel, smem));
-  hipLaunchKernelGGL(attn8_bwd_fused_kernel, dim3(a.heads * A8B_PARTS, a.N), dim3(512), smem, s, a);
   ISHAP_CHECK_HIP(hipGetLastError());
   return 0;
 }
+

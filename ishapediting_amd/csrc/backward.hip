@@ -43,7 +43,6 @@ static int gn_bwd_local_op(Exec& e, const GnBwdArgs& g, Tensor& up) {
   a.g = up.p; a.slab = up.pend; a.x = g.x; a.add = g.add; a.add2 = g.add2; a.dx = g.dx; a.dx2 = g.dx2; a.csplit = g.csplit;
   a.stats = g.stats; a.gamma = g.gamma; a.beta = g.beta; a.emb = g.emb; a.emb_ld = g.emb_ld;
   a.N = g.N; a.H = g.H; a.W = g.W; a.C = g.C; a.film = g.film; a.act = g.act; a.gmode = g.gmode;
-  a.pf = g.pf;
   long long* rec = nullptr;
   ISHAP_SALLOC(rec, e, (size_t)g.N * 32 * GN_REC_STRIDE);       // zeroed with the rest of the statistics arena
   a.rec = exec_is_solo(e) ? reinterpret_cast<unsigned long long*>(rec) : nullptr;     // see gn_local_op
@@ -56,9 +55,8 @@ static bool local_gn_bwd(int HW, int C, int gmode) { return small_map(HW) && gn_
 // `split` > 0: the block input was a skip concatenation [h | skip]; its gradient is written as two dense tensors
 // (dx = first `split` channels, *dx2 = the rest) so no slicing pass is needed afterwards.
 // `add2`: a gradient map of the block input's shape (the skip-connection gradient of an input block) added to the result.
-// `next`: weights of the first convolution the backward pass runs after this block (prefetched by this block's last kernel)
 static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int split = 0, Tensor* dx2 = nullptr,
-                        const half_t* add2 = nullptr, PrefetchHint next = PrefetchHint{}) {
+                        const half_t* add2 = nullptr) {
   ishap_unet* u = e.u;
   const ResSaved& sv = L.sv;
   const Tensor& x = sv.x;
@@ -76,7 +74,6 @@ static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int spli
     ISHAP_TRY(dgrad_op(e, L.c2, dy, dc, L.cout, loc ? nullptr : &g, loc));
     ISHAP_ALLOC(dh1.p, e, h1.numel());
     g.g = dc.p; g.dx = dh1.p;
-    g.pf = pf_bwd(L.c1);
     if (loc) ISHAP_TRY(gn_bwd_local_op(e, g, dc));
     else ISHAP_TRY(gn_bwd_op(e, g));
   }
@@ -108,46 +105,17 @@ static int res_backward(Exec& e, ResL& L, const Tensor& dy, Tensor& dx, int spli
   }
   dx.sums = nullptr;
   g1.g = da.p; g1.add = add; g1.dx = dx.p; g1.add2 = add2;
-  g1.pf = next;
   if (loc1) ISHAP_TRY(gn_bwd_local_op(e, g1, da));
   else ISHAP_TRY(gn_bwd_op(e, g1));
   return 0;
 }
 
-static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx, PrefetchHint next = PrefetchHint{}) {
+static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx) {
   ishap_unet* u = e.u;
   const AttnSaved& sv = L.sv;
   const Tensor& x = sv.x;
   const int N = x.N, T = x.H * x.W, C = L.C, heads = L.heads, d = C / heads;
   const float alpha = 1.f / sqrtf((float)d);
-  if (attn8_bwd_applicable(N, T, C, d) && local_gn_bwd(T, C, GB_SAME) && L.proj.cout_pad >= C && L.qkv.cout_pad >= 3 * C) {
-    // 8x8 map: d proj_out + attention backward + d qkv in ONE launch (attention.hip, attn8_bwd_fused_kernel); the gradient at the
-    // GroupNorm output leaves as per-head K slices that the group-local GroupNorm-backward kernel adds up (ISHAP_ATTN8_BWD)
-    Tensor dA{nullptr, N, x.H, x.W, C};
-    ISHAP_ALLOC(dA.p, e, dA.numel());
-    Tensor dqkv{nullptr, N, x.H, x.W, 3 * C};
-    ISHAP_ALLOC(dqkv.p, e, dqkv.numel());
-    float* slices = nullptr;
-    ISHAP_ALLOC(slices, e, (size_t)heads * N * T * C);
-    Tensor dn{nullptr, N, x.H, x.W, C};
-    ISHAP_ALLOC(dn.p, e, dn.numel());
-    dn.pend.ws = slices; dn.pend.nslab = heads; dn.pend.zstride = (long long)N * T * C;
-    if (!e.dry) {
-      Attn8BwdArgs g;
-      g.dy = dy.p; g.wprojT = L.proj.wT; g.ldp = L.proj.cout_pad; g.wqkvT = L.qkv.wT; g.ldq = L.qkv.cout_pad;
-      g.qkv = sv.qkv.p; g.aout = sv.a.p; g.lse = sv.lse; g.dA = dA.p; g.dqkv = dqkv.p; g.slices = slices;
-      g.N = N; g.C = C; g.heads = heads; g.alpha = alpha;
-      ISHAP_TRY(attn8_bwd_fused_launch(g, e.s));
-    }
-    dx = x;
-    GnBwdArgs g;
-    g.x = x.p; g.stats = sv.stats; g.gamma = L.n.gamma; g.beta = L.n.beta;
-    g.N = N; g.H = x.H; g.W = x.W; g.C = C; g.film = 0; g.act = 0; g.gmode = GB_SAME;
-    ISHAP_ALLOC(dx.p, e, x.numel());
-    g.g = dn.p; g.add = dy.p; g.dx = dx.p;
-    g.pf = next;
-    return gn_bwd_local_op(e, g, dn);
-  }
   Tensor dA;
   ISHAP_TRY(dgrad_op(e, L.proj, dy, dA, C));
   Tensor dqkv{nullptr, N, x.H, x.W, 3 * C};
@@ -171,18 +139,10 @@ static int attn_backward(Exec& e, AttnL& L, const Tensor& dy, Tensor& dx, Prefet
     ISHAP_TRY(dgrad_op(e, L.qkv, dqkv, dn, C, loc ? nullptr : &g, loc));
     ISHAP_ALLOC(dx.p, e, x.numel());
     g.g = dn.p; g.add = dy.p; g.dx = dx.p;
-    g.pf = next;
     if (loc) ISHAP_TRY(gn_bwd_local_op(e, g, dn));
     else ISHAP_TRY(gn_bwd_op(e, g));
   }
   return 0;
-}
-
-// the first convolution a layer's backward runs: its weights are what the kernel before it should prefetch
-static PrefetchHint first_bwd_weights(ishap_unet* u, const LayerRef& l) {
-  if (l.kind == 0) return pf_bwd(u->stem);
-  if (l.kind == 1) return pf_bwd(u->res[l.idx].c2);
-  return pf_bwd(u->attn[l.idx].proj);
 }
 
 static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out, int split = 0, Tensor* out2 = nullptr,
@@ -190,16 +150,15 @@ static int block_backward(Exec& e, BlockL& b, Tensor g, Tensor& out, int split =
   ishap_unet* u = e.u;
   for (int i = (int)b.layers.size() - 1; i >= 0; --i) {
     const LayerRef& l = b.layers[i];
-    const PrefetchHint next = i > 0 ? first_bwd_weights(u, b.layers[i - 1]) : e.next_block_pf;
     Tensor dx;
     if (l.kind == 0) {
       ISHAP_TRY(dgrad_op(e, u->stem, g, dx, u->in_pad));
     } else if (l.kind == 1) {
-      if (i == 0 && split > 0) ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, split, out2, nullptr, next));
-      else if (i == 0 && add2) { ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, 0, nullptr, add2, next)); *add2_done = true; }
-      else ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, 0, nullptr, nullptr, next));
+      if (i == 0 && split > 0) ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, split, out2, nullptr));
+      else if (i == 0 && add2) { ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, 0, nullptr, add2)); *add2_done = true; }
+      else ISHAP_TRY(res_backward(e, u->res[l.idx], g, dx, 0, nullptr, nullptr));
     } else {
-      ISHAP_TRY(attn_backward(e, u->attn[l.idx], g, dx, next));
+      ISHAP_TRY(attn_backward(e, u->attn[l.idx], g, dx));
     }
     g = dx;
   }
@@ -275,7 +234,6 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
     const int Cs = b.skip_ch, Ch = b.cin - Cs;
     ISHAP_REQUIRE(b.layers[0].kind == 1 && Ch % 8 == 0, "an output block starts with a ResBlock on the concatenation");
     Tensor gh, gs;
-    e.next_block_pf = first_bwd_weights(u, (i > 0 ? u->out_blocks[i - 1] : u->mid).layers.back());
     ISHAP_TRY(block_backward(e, b, g, gh, Ch, &gs));       // the first ResBlock writes d/d[h | skip] as two tensors
     skipgrad[n_in - 1 - i] = gs;     // hs.pop() order (unet.py:663)
     g = gh;
@@ -303,11 +261,9 @@ int unet_backward_impl(ishap_unet* u, const half_t* cot_tap, const void* cot_out
     return 0;
   };
   const half_t* pending = nullptr;
-  e.next_block_pf = n_in > 0 ? first_bwd_weights(u, u->in_blocks[n_in - 1].layers.back()) : PrefetchHint{};
   ISHAP_TRY(run(u->mid, n_in > 0 ? skipgrad[n_in - 1].p : nullptr, pending));
   ISHAP_TRY(bwd_mark(u, s, 200, dry));
   for (int i = n_in - 1; i >= 0; --i) {
-    e.next_block_pf = i > 0 ? first_bwd_weights(u, u->in_blocks[i - 1].layers.back()) : PrefetchHint{};
     if (pending) {                       // fall-back: a separate add
       Tensor sum = g;
       ISHAP_ALLOC(sum.p, e, g.numel());

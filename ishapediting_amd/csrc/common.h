@@ -177,48 +177,6 @@ __device__ __forceinline__ float row16_max(float v) {
   return v;
 }
 
-// Weight prefetch hint -- an OPT-IN experiment (ISHAP_PREFETCH=1), measured and rejected in round 3.  Idea: the kernel that
-// runs before a convolution (a GroupNorm pass: latency-bound, the memory system mostly idle) carries a few extra workgroups
-// that touch one dword of every 128-byte line of the convolution's weights, pulling them into the Infinity Cache while the
-// GroupNorm runs (the UNet streams 1.5 GB of once-read weights per guided step through ~270 dependent launches).
-// Result (bench.py, same box, two rounds each): 0.2045 s/edit without, 0.2175 / 0.2335 / 0.2323 with the first 256 KB / 1 MB /
-// 4 MB of each operand prefetched, 0.231 with whole operands.  The convolutions gain only 1-4 % from warm weights (their
-// rings hide an HBM miss almost as well as an L2 hit), while every carrying kernel now ends one HBM round trip after its
-// last prefetch workgroup was dispatched: +2.4 us on each of ~140 GroupNorm launches per step.  A kernel boundary waits for
-// the prefetch, so it cannot run ahead of the consumer the way a persistent loader ring does.
-struct PrefetchHint {
-  const void* p = nullptr;
-  unsigned lines = 0;            // 128-byte lines starting at p
-  __host__ __device__ bool any() const { return lines != 0; }
-};
-static inline PrefetchHint prefetch_hint(const void* p, size_t bytes) {
-  // a prefetch keeps the carrying kernel alive until its loads are back, so it must stay shorter than that kernel:
-  // only the first ISHAP_PREFETCH_KB of an operand are touched (what the consumer's pipeline fill waits for)
-  static const size_t cap = [] { const char* e = getenv("ISHAP_PREFETCH_KB"); return (size_t)(e ? atoi(e) : 1024) * 1024; }();
-  PrefetchHint h;
-  if (bytes > cap) bytes = cap;
-  if (p && bytes >= 128) { h.p = p; h.lines = (unsigned)(bytes / 128); }
-  return h;
-}
-// workgroups of `threads` threads that cover the hint with ~8 loads per thread, at most `cap`
-static inline int prefetch_blocks(const PrefetchHint& h, int threads, int cap = 64) {
-  if (!h.any()) return 0;
-  const long long per = (long long)threads * 8;
-  const long long n = (h.lines + per - 1) / per;
-  return (int)(n < 1 ? 1 : (n > cap ? cap : n));
-}
-#if defined(__HIPCC__)
-__device__ __forceinline__ void prefetch_block(const PrefetchHint& h, int blk, int nblk) {
-  const char* base = reinterpret_cast<const char*>(h.p);
-  const unsigned stride = (unsigned)nblk * blockDim.x;
-  unsigned acc = 0;
-#pragma unroll 8
-  for (unsigned i = (unsigned)blk * blockDim.x + threadIdx.x; i < h.lines; i += stride)
-    acc ^= *reinterpret_cast<const unsigned*>(base + (size_t)i * 128);
-  asm volatile("" ::"v"(acc));          // keeps the loads; the wave ends when they have returned
-}
-#endif
-
 // A convolution result that has not been materialised yet: the split-K slices of an implicit-GEMM launch left as fp32
 // partial sums [nslab][rows][ld].  The next kernel on the tensor (a GroupNorm pass, forward or backward -- it has to read
 // the whole tensor anyway) adds the slices in slice order, applies bias / residual, rounds to fp16 and goes on from
@@ -277,11 +235,6 @@ struct IgemmArgs {
   int ups = 0;                   // conv3 source map is (H/2, W/2): nearest-neighbour upsample on the fly
   int res_ups = 0;               // residual map is (H/2, W/2)
   int ksplit = 1;
-  int lite = 0;                  // 1 (experiment, the overlapped forward tail): kernels sized to SHARE a compute unit with another stream's workgroup --
-                                 // 128x128 tiles on a 3 + 2 slot ring (83 KB of LDS instead of 132) with the fragment-layout epilogue (no 119 KB staging),
-                                 // one-team 64x64 tiles (76 KB instead of 150)
-  int force_small = 0;           // 1: 64x64 tiles whatever the tile policy says (experiment: the overlapped tail on tiles that leave room for a second workgroup per CU)
-  int chunk_tiles_big = 0;       // the same for the 128x128-tile launches (0: chunk_tiles)
   int chunk_tiles = 0;           // > 0 (a multiple of 8): igemm4 runs the layer as several launches of at most that many tiles (igemm4.hip, launch4)
   int defer_reduce = 0;          // ksplit > 1: leave the fp32 slices in `ws` (no reduce launch); the caller hands a SlabSrc to the consumer
   float alpha = 1.f;
@@ -300,29 +253,12 @@ struct IgemmArgs {
   int gb_emb_ld = 0;
   int gb_film = 0, gb_act = 0;
   long long* gb_csums = nullptr;
-  // Fused GroupNorm(32) (+FiLM) + SiLU of THIS launch's output (round 4; forward launches with stat_out, staged epilogue):
-  // once its tile's channel sums are out, a workgroup announces itself on a per-(image, n-tile) counter, waits until every
-  // m-tile of that image has done so (the launcher only allows it when the whole grid is co-resident), reads the group
-  // totals, and writes act(film(GN(out))) of its own tile -- still in LDS -- to gn_out; the raw output goes to `out` as
-  // always (the backward pass re-reads it).  Replaces a gn_apply launch (a ResBlock's out_layers norm, gd/unet.py:245-252).
-  half_t* gn_out = nullptr;          // [M][N] dense
-  const float* gn_gamma = nullptr;
-  const float* gn_beta = nullptr;
-  const float* gn_emb = nullptr;     // FiLM rows (scale at c, shift at N + c), per image stride gn_emb_ld
-  int gn_emb_ld = 0, gn_film = 0;
-  float* gn_stats_out = nullptr;     // [N_img][32][2] (mean, rstd) for the backward pass
-  unsigned* gn_counter = nullptr;    // [N_img][n-tiles], zeroed before the launch
-  unsigned* gn_status = nullptr;     // device status word (common.h): a wait that gives up raises ISHAP_DEV_GN_RENDEZVOUS
-  int gn_spin_limit = 0;
 };
 // set (non-null) by igemm.hip around a launch while ishap_profile_begin/end is active: the kernel launchers then attach
 // these events to the dispatch itself (hipExtLaunchKernelGGL), so their elapsed time is the kernel's own duration
 extern hipEvent_t g_igemm_prof_start, g_igemm_prof_stop;
 int igemm_launch(const IgemmArgs& a, hipStream_t s);
 int igemm_reduce_launch(const IgemmArgs& a, hipStream_t s);
-bool igemm_small3_wanted(const IgemmArgs& a);
-int igemm_small3_slices(const IgemmArgs& a);      // K slices that fill the chip (consumer must be able to add them up)    // the one-launch small-map 3x3 kernel takes this shape (then no split-K)
 int igemm4_small_map_slices(const IgemmArgs& a);  // igemm4.hip: K slices of its sliced launch on an 8x8 map (consumer adds them up), 0 = not taken
 // picks a split so the grid fills the chip; returns workspace floats needed
 int igemm_pick_ksplit(int M, int N, int K, int nbatch, bool pending = false);   // pending: the consumer adds the slices up (no reduce launch)
-int igemm_stat_launch_workgroups(const IgemmArgs& a);

@@ -285,14 +285,14 @@ int drag_setup_launch(const DragArgs& a, hipStream_t s) {
 // every workgroup of these passes ends with same-address atomics (loss sum, max|g|) that serialise at ~10 ns each:
 // few, fat workgroups (the loops are grid-stride).  Measured: tools/experiments/drag_probe.sh.
 static int drag_terms_launch(const DragArgs& a, unsigned* bits, hipStream_t s) {
-  static const int cap = [] { const char* e = getenv("ISHAP_DRAG_BLOCKS"); return e ? atoi(e) : 1024; }();
+  constexpr int cap = 1024;          // swept in round 2 (tools/experiments/drag_probe.sh)
   const int side = 2 * a.r + 1;
   const int nrows = 3 * a.B * side * ((a.Cc + 63) / 64) * ((side + DSEG - 1) / DSEG);
   hipLaunchKernelGGL(drag_terms_kernel, dim3(min(ceil_div(nrows * 64, 256), cap)), dim3(256), 0, s, a, bits);
   return 0;
 }
 static unsigned gather_blocks(long long n) {
-  static const int cap = [] { const char* e = getenv("ISHAP_DRAG_OUT_BLOCKS"); return e ? atoi(e) : 512; }();
+  constexpr int cap = 512;
   return (unsigned)std::min<long long>((n / 8 + 255) / 256, cap);
 }
 

@@ -276,8 +276,9 @@ extern "C" int ishap_profile_begin(void) {
 }
 // out[v*3 + {0,1,2}] = {launches, total milliseconds, algorithmic FLOPs} for variant v:
 //   0 conv3x3 128x128 tile, 1 conv3x3 64x64 tile, 2 GEMM 128x128 tile, 3 GEMM 64x64 tile, 4 conv3x3 64x64 two-team,
-//   5 small-map kernel, 6 register-staged (BK = 32) kernel, 7 small-map 3x3 kernel, 8 / 9 / 10 the dx-reuse conv kernel
-//   (igemm4.hip): 128x128 tile / 64x64 tile / 64x64 two-team, 11 its sliced launches on the 8x8 maps, 12 its 128x64 tiles
+//   5 small-map (skinny) GEMM kernel, 6 register-staged (BK = 32) kernel, 7 unused (was conv3_small, removed in round 6),
+//   8 / 9 / 10 the dx-reuse conv kernel (igemm4.hip): 128x128 tile / 64x64 tile / 64x64 two-team, 11 its sliced launches on
+//   the 8x8 maps, 12 its 128x64 tiles
 extern "C" int ishap_profile_end(double* out, int nvar) {
   g_prof_on = false;
   for (int i = 0; i < nvar * 3; ++i) out[i] = 0.0;
@@ -332,17 +333,21 @@ static bool igemm4_wanted(const IgemmArgs& a, bool big) {
 
 template <int BM, int BN, int BK, int WM, int WN, bool CONV3>
 static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
-  constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(half_t);
-  auto kern = igemm_kernel<BM, BN, BK, WM, WN, CONV3>;
-  ISHAP_TRY(ishap_set_max_lds((const void*)kern, (int)smem));
-  dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
   int prof_slot = -1;
   auto fire = [&]() -> int {
-    if (BK == 64 && CONV3 && igemm4_wanted(a, BM == 128)) return igemm4_launch_main(a, BM == 128, s);
-    if (BK == 64) return igemm2_launch_main(a, BM == 128, s);
-    if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(256), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a);
-    else hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
-    return 0;
+    if constexpr (BK == 64) {
+      if (CONV3 && igemm4_wanted(a, BM == 128)) return igemm4_launch_main(a, BM == 128, s);
+      return igemm2_launch_main(a, BM == 128, s);
+    } else {
+      // K not a multiple of 64 (tiny configurations; the full model's stem is padded to 128 channels): the register-staged kernel
+      constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(half_t);
+      auto kern = igemm_kernel<BM, BN, BK, WM, WN, CONV3>;
+      ISHAP_TRY(ishap_set_max_lds((const void*)kern, (int)smem));
+      const dim3 grid(a.M / BM, ceil_div(a.N, BN), a.nbatch * a.ksplit);
+      if (g_igemm_prof_start) hipExtLaunchKernelGGL(kern, grid, dim3(256), smem, s, g_igemm_prof_start, g_igemm_prof_stop, 0, a);
+      else hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+      return 0;
+    }
   };
   if (g_prof_on) {
     ProfRec r;
@@ -386,29 +391,18 @@ static bool igemm_use_big(int M, int N, int nbatch) {
   static const int big_min = [] { const char* e = getenv("ISHAP_BIG_MIN"); return e ? atoi(e) : 192; }();
   return blocks >= big_min;
 }
-// workgroups of the main launch of a statistics-carrying conv / GEMM (the tile the dispatcher below will pick), or 0 when the
-// shape does not take the LDS-DMA kernels with the staged epilogue (the fused GroupNorm of IgemmArgs::gn_out needs them)
-int igemm_stat_launch_workgroups(const IgemmArgs& a) {
-  const bool k64 = a.conv3 ? (a.Cin % 64 == 0) : (a.K % 64 == 0);
-  const int hw = a.H * a.W;
-  if (!k64 || hw <= 0 || hw % 64 != 0 || a.M % 64 != 0 || a.nbatch != 1) return 0;
-  bool big = igemm_use_big(a.M, a.N, a.nbatch);
-  if (hw % 128 != 0) big = false;
-  const int bm = big ? 128 : 64;
-  return (a.M / bm) * ceil_div(a.N, bm) * a.ksplit;
-}
 int igemm_pick_ksplit(int M, int N, int K, int nbatch, bool pending) {
   const bool big = igemm_use_big(M, N, nbatch);
   const int bm = big ? 128 : 64, bn = big ? 128 : 64;
   long long blocks = (long long)(M / bm) * ceil_div(N, bn) * nbatch;
   int ks = K / 64;
-  static const int nosplit = [] { const char* e = getenv("ISHAP_NOSPLIT_STEPS"); return e ? atoi(e) : 36; }();   // in situ: 36 beats 24 / 48 by ~0.5 %
-  static const int fill = [] { const char* e = getenv("ISHAP_SPLIT_FILL"); return e ? atoi(e) : 224; }();   // in-situ sweep (tools/experiments/sweep_split_policy.sh): plateau 208..256, 1 % better than 160
-  static const int minsteps = [] { const char* e = getenv("ISHAP_SPLIT_MINSTEPS"); return e ? atoi(e) : 6; }();
-  // slices whose consumer adds them up cost no reduce launch: thresholds of their own (ISHAP_PEND_NOSPLIT / ISHAP_PEND_MINSTEPS)
-  // in situ 12 / 3 against 36 / 6: 0.1783 -> 0.1777 s/shape (profiles/round4_env_ab_pending_split.txt)
-  static const int p_nosplit = [] { const char* e = getenv("ISHAP_PEND_NOSPLIT"); return e ? atoi(e) : 12; }();
-  static const int p_minsteps = [] { const char* e = getenv("ISHAP_PEND_MINSTEPS"); return e ? atoi(e) : 3; }();
+  // policy constants, each swept in situ (tools/experiments/sweep_split_policy.sh, profiles/round4_env_ab_pending_split.txt,
+  // profiles/round5_ab_policy_resweep.txt: all flat within +-0.5 % around these values)
+  constexpr int nosplit = 36;       // K-steps below which a launch followed by a reduce launch is not split (24 / 48: +0.5 %)
+  constexpr int fill = 224;         // split while the grid stays below this many workgroups (plateau 208 .. 256)
+  constexpr int minsteps = 6;       // K-steps left per slice at least
+  // slices whose consumer adds them up cost no reduce launch: thresholds of their own (12 / 3 against 36 / 6: 0.1783 -> 0.1777 s/shape)
+  constexpr int p_nosplit = 12, p_minsteps = 3;
   if (ks < (pending ? p_nosplit : nosplit)) return 1;        // below ~36 K-steps the extra reduce launch (~5.5 us) costs more than the split saves (harness sweep: ~48; in situ: 36)
   int split = 1;
   while (blocks * split < fill && ks / (split * 2) >= (pending ? p_minsteps : minsteps) && split < 32) split *= 2;
@@ -424,31 +418,15 @@ int igemm_reduce_launch(const IgemmArgs& a, hipStream_t s) {
   return 0;
 }
 
-bool igemm_small3_applicable(const IgemmArgs& a);                      // igemm_small3.hip (3x3 on small maps, one launch, weights read once)
-int igemm_small3_launch(const IgemmArgs& a, int nt, hipStream_t s);
-// 3x3 layers on maps of at most 32 x 32 pixels per image: no split-K, no reduce launch (ISHAP_SMALL3=0 restores the tiled route)
-int igemm_small3_slices(const IgemmArgs& a);
-bool igemm_small3_wanted(const IgemmArgs& a) {
-  // 1: the 8x8 maps only (measured: on 16x16 / 32x32 maps every 16-channel tile re-stages its pixels and the tiled kernel
-  // wins, tools/experiments/s3_probe.sh), 2: every map up to 32x32, 0: off
-  static const int mode = [] { const char* e = getenv("ISHAP_SMALL3"); return e ? atoi(e) : 1; }();
-  if (!mode || !a.conv3 || a.H * a.W > (mode == 2 ? 1024 : 64)) return false;
-  if (a.defer_reduce && a.ksplit > 1 && igemm4_small_map_slices(a) == a.ksplit && igemm4_wanted(a, false)) return false;   // conv_op chose igemm4's sliced launch
-  IgemmArgs t = a;
-  t.ksplit = 1;
-  return igemm_small3_applicable(t);
-}
-
 bool igemm_skinny_applicable(const IgemmArgs& a);                      // igemm_skinny.hip (small maps, one launch)
 int igemm_skinny_launch(const IgemmArgs& a, int mt, hipStream_t s);
 
 // 1x1 GEMMs on the 8x8 maps: the one-launch skinny kernel beats the tiled one there (measured in situ: 7.8 vs 11.4 us
 // at 64 x 1024 x 1024); for 3x3 layers it re-reads the im2col fragments once per 16-channel tile and loses.
 static bool use_skinny(const IgemmArgs& a) {
-  static const int mode = [] { const char* e = getenv("ISHAP_SKINNY"); return e ? atoi(e) : 1; }();   // 0 off, 1 1x1 only, 2 all
-  if (!mode || !igemm_skinny_applicable(a)) return false;
-  if (mode == 1 && (a.conv3 || a.M > 64)) return false;      // in situ it wins at M = 64 (-3..5 us per launch) and loses at M = 256
-  return true;
+  static const int on = [] { const char* e = getenv("ISHAP_SKINNY"); return e ? atoi(e) : 1; }();   // 0: the tiled kernel + reduce instead
+  // in situ it wins at M = 64 (-3..5 us per launch) and loses at M = 256; 3x3 layers never (L2-bound fragment re-reads)
+  return on && !a.conv3 && a.M <= 64 && igemm_skinny_applicable(a);
 }
 
 int igemm_launch(const IgemmArgs& a, hipStream_t s) {
@@ -463,20 +441,6 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
                             a.gb_stats && a.gb_gamma && a.gb_beta && (!a.gb_film || a.gb_emb)),
                 "fused GroupNorm-backward sums: fp16 dense output, N % 32 == 0, no forward statistics");
   ISHAP_REQUIRE(a.ldx % 8 == 0 && a.ldw % 8 == 0, "row strides must keep 16-byte alignment");
-  if (igemm_small3_wanted(a)) {
-    ISHAP_REQUIRE(a.ksplit == 1 || a.defer_reduce, "the sliced small-map kernel leaves its slices to the consumer");
-    if (!g_prof_on) return igemm_small3_launch(a, 0, s);
-    ProfRec r;
-    r.a = prof_event(); r.b = prof_event(); r.c = nullptr;
-    r.flops = 2.0 * a.M * a.N * a.K * a.flops_scale;
-    r.variant = 7;
-    r.M = a.M; r.N = a.N; r.K = a.K; r.conv3 = 1; r.big = false; r.ksplit = -a.ksplit;      // negative: the small-map 3x3 kernel with that many K slices
-    g_igemm_prof_start = r.a; g_igemm_prof_stop = r.b;
-    const int rc = igemm_small3_launch(a, 0, s);
-    g_igemm_prof_start = nullptr; g_igemm_prof_stop = nullptr;
-    g_prof.push_back(r);
-    return rc;
-  }
   if (use_skinny(a)) {
     if (!g_prof_on) return igemm_skinny_launch(a, 0, s);
     ProfRec r;
@@ -491,7 +455,7 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
     return rc;
   }
   const bool k64 = a.conv3 ? (a.Cin % 64 == 0) : (a.K % 64 == 0);
-  bool big = igemm_use_big(a.M, a.N, a.nbatch) && !a.force_small;
+  bool big = igemm_use_big(a.M, a.N, a.nbatch) && k64;      // the register-staged BK = 32 kernel (tiny configurations only) is built with 64x64 tiles
   if (a.stat_out || a.gb_x) {
     // the statistics epilogues file a whole tile under image m0 / HW: a tile must not straddle two images
     const int hw = a.H * a.W;
@@ -508,7 +472,10 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
       return launch_cfg<BM, BN, 32, WM_, WN_, false>(a, s);                                    \
     }                                                                                          \
   } while (0)
-  if (big) IG_DISPATCH(128, 128, 2, 2);
+  if (big) {
+    if (a.conv3) return launch_cfg<128, 128, 64, 2, 2, true>(a, s);
+    return launch_cfg<128, 128, 64, 2, 2, false>(a, s);
+  }
   IG_DISPATCH(64, 64, 2, 2);
 #undef IG_DISPATCH
 }

@@ -416,12 +416,10 @@ static int launch2(const IgemmArgs& a, hipStream_t s) {
 // (measured: +4..16 % there, a loss on short slices and 1x1)
 bool igemm2_two_teams(const IgemmArgs& a, bool big) {
   static const int halves = [] { const char* e = getenv("ISHAP_HALVES"); return e ? atoi(e) : 2; }();
-  if (big || halves != 2 || !a.conv3 || a.lite == 1) return false;
+  if (big || halves != 2 || !a.conv3) return false;
   const long long tiles = (long long)(a.M / 64) * ((a.N + 63) / 64) * a.nbatch * a.ksplit;
   const int steps = (a.K / 64 + a.ksplit - 1) / a.ksplit;
-  static const int max_tiles = [] { const char* e = getenv("ISHAP_TEAM_TILES"); return e ? atoi(e) : 256; }();
-  static const int min_steps = [] { const char* e = getenv("ISHAP_TEAM_STEPS"); return e ? atoi(e) : 16; }();
-  return tiles <= max_tiles && steps >= min_steps;
+  return tiles <= 256 && steps >= 16;
 }
 
 // main kernel only (the caller adds the split-K reduce); big = 128x128 tile, else 64x64

@@ -20,7 +20,7 @@
 // Tile shapes (igemm4_launch_main): 128x128 on maps 16 ... 128 wide (several image rows per tile below 128; fragment reads
 // interleaved into the MFMA blocks), 64x64 one- and two-team on maps 16 ... 64 wide, 128 pixels x 64 channels on the 64-wide
 // maps, and on the 8x8 maps 64x64 tiles (= one image) with K cut into ~16 slices whose fp32 partial tiles are left for the
-// consuming GroupNorm kernel to add up (igemm4_small_map_slices; took the level over from conv3_small late in round 4).
+// consuming GroupNorm kernel to add up (igemm4_small_map_slices; took the level over from a one-launch small-map kernel late in round 4, removed in round 6).
 // Reference arithmetic: conv2d 3x3, padding 1 (gd/unet.py ResBlock in_layers / out_layers, :236-256) and its input
 // gradient (flipped, transposed weights).  Same products as igemm2, another order of the K sum inside the fp32
 // accumulators: the two kernels agree to summation order (tests/test_gpu_fullsize.py: <= 2e-3 relative over the full model).
@@ -505,8 +505,7 @@ static int launch4(const IgemmArgs& a, hipStream_t s) {
   constexpr size_t ring = (size_t)HALVES * (NSTW * BN * 64 + NSTX * (BM + 8) * 64) * sizeof(half_t);
   constexpr size_t epi = (size_t)HALVES * BM * (BN + 4) * 4 + (size_t)BM * (BN + 8) * 2 + 16384;      // staged epilogue: fp32 tile(s) + fp16 tile + partial sums
   static_assert((ring > epi ? ring : epi) <= 163840, "LDS");
-  // lite launches take the fragment-layout epilogue (igemm_epilogue_is_staged), which needs 3 KB: the ring alone sets the request
-  const size_t smem = a.lite ? ring : (ring > epi ? ring : epi);
+  const size_t smem = ring > epi ? ring : epi;
   auto kern = igemm4_kernel<BM, BN, WD, NSTW, NSTX, HALVES>;
   ISHAP_TRY(ishap_set_max_lds((const void*)kern, (int)smem));
   const dim3 grid(a.M / BM, ceil_div(a.N, BN), a.ksplit);
@@ -546,7 +545,7 @@ static int launch4(const IgemmArgs& a, hipStream_t s) {
   }
   const int order_bit = n_outer ? (1 << 30) : 0;
   const int tiles = h.nwg;
-  const int chunk = (BM == 128 && BN == 128 && a.chunk_tiles_big > 0) ? a.chunk_tiles_big : a.chunk_tiles;
+  const int chunk = a.chunk_tiles;
   const bool chunked = chunk > 0 && chunk % 8 == 0 && tiles > chunk && b.nx_shift >= 0 && !g_igemm_prof_start;
   if (chunked) {
     for (int base = 0; base < tiles; base += chunk) {
@@ -570,10 +569,9 @@ bool igemm4_applicable(const IgemmArgs& a, bool big) {
   if (a.K2 && (a.K2 % 64 != 0 || a.K2 / 64 > 127 || !a.X2)) return false;
   // the folded second source runs with a short lookahead (one slab per step, NSTX - 1 ahead): worth it on the 128-tiles
   // (-11 %), a loss on the 64-tiles (+4..18 %, profiles/round4_igemm4_probe_v4.txt) -- those stay with igemm2
-  // (the sliced launches on the 8x8 maps excepted: there the alternative is conv3_small, at 26 us for K = 9216 + 2048)
+  // (the sliced launches on the 8x8 maps excepted: 9.5 us against 23.9 for the one-launch kernel they replaced, round 4)
   const bool w8 = !big && a.W == 8 && a.H == 8 && a.ksplit > 1;
-  static const int k2_small = [] { const char* e = getenv("ISHAP_IG4_K2_SMALL"); return e ? atoi(e) : 0; }();
-  if (a.K2 && !big && !w8 && !k2_small) return false;
+  if (a.K2 && !big && !w8) return false;
   // (128-pixel tiles on maps narrower than 128: several image rows per tile -- the batched generate path, where M = batch * H * W
   // fills the chip with 128x128 tiles on the 64^2 ... 16^2 maps)
   if (big ? (a.W != 128 && a.W != 64 && a.W != 32 && a.W != 16) : (a.W != 16 && a.W != 32 && a.W != 64 && !w8)) return false;
@@ -581,20 +579,15 @@ bool igemm4_applicable(const IgemmArgs& a, bool big) {
   return true;
 }
 
-// The 8x8 maps (one tile = one image): K slices for a sliced launch whose consumer adds the slices up, 0 = leave the shape to
-// conv3_small (igemm_small3.hip).  Enough slices for ~one workgroup per CU: the harness has 16 x 16 workgroups at 8.1 us against
-// conv3_small's 9.1 (1024 -> 1024), 11.3 against 15.1 (2048 -> 1024), 11.1 against 16.4 (1024 -> 2048)
-// (profiles/round4_igemm4_w8_probe.txt).  ISHAP_IG4_W8=0 switches it off, ISHAP_IG4_W8_WGS sets the workgroup target.
+// The 8x8 maps (one tile = one image): K slices for a sliced launch whose consumer adds the slices up, 0 = not taken (the shape
+// then goes through the generic tile + split policy).  Enough slices for ~one workgroup per CU: the harness has 16 x 16 workgroups at
+// 8.1 us against 9.1 for the one-launch small-map kernel this replaced (1024 -> 1024), 11.3 against 15.1 (2048 -> 1024), 11.1
+// against 16.4 (1024 -> 2048), 9.5 against 23.9 with the folded skip (profiles/round4_igemm4_w8_probe.txt, _w8_k2_probe.txt)
 int igemm4_small_map_slices(const IgemmArgs& a) {
-  static const int on = [] {
-    const char* e = getenv("ISHAP_IG4_W8");
-    const char* all = getenv("ISHAP_IGEMM4");      // igemm.hip: 2 (default) = every shape igemm4 takes
-    return (e ? atoi(e) : 1) && (all ? atoi(all) : 2) > 1;
-  }();
-  static const int target = [] { const char* e = getenv("ISHAP_IG4_W8_WGS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 256; }();
-  static const int k2on = [] { const char* e = getenv("ISHAP_IG4_W8_K2"); return e ? atoi(e) : 1; }();
+  static const int on = [] { const char* all = getenv("ISHAP_IGEMM4"); return (all ? atoi(all) : 2) > 1; }();      // igemm.hip: 2 (default) = every shape igemm4 takes
+  constexpr int target = 256;        // workgroups (in-situ sweep 256 .. 640: flat)
   if (!on || !a.conv3 || a.W != 8 || a.H != 8 || a.nbatch != 1 || a.Cin % 64 != 0 || a.M % 64 != 0 || a.K != 9 * a.Cin + a.K2) return 0;
-  if (a.K2 && (!k2on || a.K2 % 64 != 0 || a.K2 / 64 > 127 || !a.X2)) return 0;
+  if (a.K2 && (a.K2 % 64 != 0 || a.K2 / 64 > 127 || !a.X2)) return 0;
   const int tiles = (a.M / 64) * ((a.N + 63) / 64), G = 3 * (a.Cin / 64);
   int ks = (target + tiles / 2) / tiles;
   if (ks > 16) ks = 16;
@@ -623,28 +616,22 @@ int igemm4_small_map_slices(const IgemmArgs& a) {
 // two teams: one workgroup per CU at most (<= 256 tiles) and a K slice long enough to halve (measured break-even: ~40 steps)
 bool igemm4_two_teams(const IgemmArgs& a, bool big) {
   static const int on = [] { const char* e = getenv("ISHAP_IG4_TEAMS"); return e ? atoi(e) : 2; }();
-  if (big || on != 2 || a.lite == 1) return false;
+  if (big || on != 2) return false;
   const long long tiles = (long long)(a.M / 64) * ((a.N + 63) / 64) * a.ksplit;
   const int groups = (3 * (a.Cin / 64) + a.ksplit - 1) / a.ksplit;
-  static const int min_steps = [] { const char* e = getenv("ISHAP_IG4_TEAM_STEPS"); return e ? atoi(e) : 48; }();
-  return tiles <= 256 && 3 * groups + a.K2 / 64 >= min_steps;
+  return tiles <= 256 && 3 * groups + a.K2 / 64 >= 48;
 }
 // 128-pixel x 64-channel tiles (two image rows of a 64-wide map): for the 64^2 layers with >= 512 output channels the grid still
-// fills the chip (32 x 8 = 256 workgroups) and a K-step stages 13.3 KB for twice the FLOPs of a 64x64 tile's 10.7 KB
+// fills the chip (32 x 8 = 256 workgroups) and a K-step stages 13.3 KB for twice the FLOPs of a 64x64 tile's 10.7 KB; with only 128
+// such tiles (the 64^2 256->256 layers) it loses (0.1804 -> 0.182 s/shape): at least 224 tiles
 bool igemm4_tall_tiles(const IgemmArgs& a, bool big) {
-  static const int on = [] { const char* e = getenv("ISHAP_IG4_TALL"); return e ? atoi(e) : 1; }();
-  if (big || !on || a.lite == 1 || a.W != 64 || a.K2 != 0 || a.ksplit != 1 || a.M % 128 != 0 || (a.H * a.W) % 128 != 0) return false;
+  static const int on = [] { const char* e = getenv("ISHAP_IG4_TEAMS"); return e ? atoi(e) : 2; }();      // 0: plain one-team 64x64 tiles everywhere
+  if (big || !on || a.W != 64 || a.K2 != 0 || a.ksplit != 1 || a.M % 128 != 0 || (a.H * a.W) % 128 != 0) return false;
   const long long tiles = (long long)(a.M / 128) * ((a.N + 63) / 64);
-  static const int tmin = [] { const char* e = getenv("ISHAP_IG4_TALL_MIN"); return e ? atoi(e) : 224; }();
-  return tiles >= tmin && tiles <= 512;
+  return tiles >= 224 && tiles <= 512;
 }
 int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
   if (big) {
-    if (a.lite) {                                    // 83 KB of LDS: two workgroups per CU
-      if (a.W == 128) return launch4<128, 128, 128, 3, 2>(a, s);
-      if (a.W == 64) return launch4<128, 128, 64, 3, 2>(a, s);
-      if (a.W == 32) return launch4<128, 128, 32, 3, 2>(a, s);
-    }
     if (a.W == 128) return launch4<128, 128, 128, IG4_BIG_W, IG4_BIG_X>(a, s);
     if (a.W == 64) return launch4<128, 128, 64, IG4_BIG_W, IG4_BIG_X>(a, s);
     if (a.W == 32) return launch4<128, 128, 32, IG4_BIG_W, IG4_BIG_X>(a, s);
@@ -661,9 +648,8 @@ int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
   // slices of 9-12 K-steps: too short for the 6-slot ring's compile-time loader path (13 steps), long enough for the 4-slot
   // ring's (9) -- -13 % per launch there (16^2 512->512 in 8 slices 7.7 -> 6.7 us, 32^2 256->512 in 4 slices 9.9 -> 8.6;
   // profiles/round4_igemm4_ring_by_slice_length_probe.txt); longer slices keep the deeper ring (+5 % at 36 steps with 4 slots)
-  static const int short_on = [] { const char* e = getenv("ISHAP_IG4_SHORT_RING"); return e ? atoi(e) : 1; }();
   const int steps = 3 * ((3 * (a.Cin / 64) + a.ksplit - 1) / a.ksplit);
-  if (short_on && a.K2 == 0 && steps >= 9 && steps <= 12) {
+  if (a.K2 == 0 && steps >= 9 && steps <= 12) {
     if (a.W == 64) return launch4<64, 64, 64, IG4_W8_W, IG4_W8_X>(a, s);
     if (a.W == 32) return launch4<64, 64, 32, IG4_W8_W, IG4_W8_X>(a, s);
     return launch4<64, 64, 16, IG4_W8_W, IG4_W8_X>(a, s);

@@ -47,7 +47,7 @@ extern __device__ unsigned long long* g_ig_stamps;      // [workgroup][16]
 __device__ __forceinline__ bool igemm_epilogue_is_staged(const IgemmArgs& a, int batch) {
   const half_t* out16 = (const half_t*)a.out + (long long)batch * a.bso;
   const bool aligned16 = ((reinterpret_cast<unsigned long long>(out16) | reinterpret_cast<unsigned long long>(a.res)) & 15) == 0;
-  return !a.lite && a.out_mode == IG_OUT_F16 && a.ksplit == 1 && (a.N & 7) == 0 && (a.ldo & 7) == 0 && (!a.res || (a.ldr & 7) == 0) && aligned16 &&
+  return a.out_mode == IG_OUT_F16 && a.ksplit == 1 && (a.N & 7) == 0 && (a.ldo & 7) == 0 && (!a.res || (a.ldr & 7) == 0) && aligned16 &&
          (!a.gb_x || (a.N & 31) == 0);
 }
 
@@ -219,92 +219,6 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
         atomicAdd(reinterpret_cast<unsigned long long*>(a.stat_out + ((long long)n_img * a.N + n0 + nl) * 2 + k),
 #endif
                   (unsigned long long)__double2ll_rn(v * (double)(k ? STAT_SCALE_SQ : STAT_SCALE_SUM)));
-      }
-    }
-    if (a.gn_out) {
-      // ---- fused GroupNorm (+FiLM) + SiLU of this tile (common.h, IgemmArgs::gn_out) ----
-      // this thread's affine / FiLM operands: fetched now, their latency hides under the rendezvous
-      float gn_g[8], gn_b[8];
-      half_t gn_sc[8], gn_sh[8];
-      if (has) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          gn_g[c] = a.gn_gamma[n + c];
-          gn_b[c] = a.gn_beta[n + c];
-          gn_sc[c] = a.gn_film ? (half_t)(1.f + (float)(half_t)a.gn_emb[(long long)n_img * a.gn_emb_ld + n + c]) : (half_t)1.f;
-          gn_sh[c] = a.gn_film ? (half_t)a.gn_emb[(long long)n_img * a.gn_emb_ld + a.N + n + c] : (half_t)0.f;
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's atomics have been acknowledged by the memory side
-      __syncthreads();
-      const int tiles_m = HW / BM_T;                         // m-tiles per image: all of them add to this n-tile's channels
-      unsigned* ctr = a.gn_counter + n_img * (int)gridDim.y + n0 / BN;
-      if (t == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        unsigned seen;
-        do {
-          seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (seen < (unsigned)tiles_m) __builtin_amdgcn_s_sleep(8);      // ~0.25 us between polls: the late tiles' atomics share that memory channel
-        } while (seen < (unsigned)tiles_m && ++spins < a.gn_spin_limit);
-        if (seen < (unsigned)tiles_m)                        // the grid was not co-resident: an error, never a silent wrong result
-          __hip_atomic_store(a.gn_status, (unsigned)ISHAP_DEV_GN_RENDEZVOUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        slots[0] = seen < (unsigned)tiles_m ? 1.f : 0.f;
-      }
-      __syncthreads();
-      const bool failed = slots[0] != 0.f;
-      __syncthreads();
-      // group totals of this n-tile's channels, straight from the table the atomics went to; mean / rstd as gn_apply forms them
-      long long* const tot = reinterpret_cast<long long*>(slots);          // [BN][2]
-      if (t < BN * 2) {
-        const int nl = t >> 1, k = t & 1;
-        long long v = 0;
-        // agent-scope loads (round 5): the totals were formed by atomics of workgroups on other XCDs; every add was
-        // acknowledged before its tile announced itself on the counter this workgroup polled with agent-scope loads, and these
-        // loads bypass this CU's L1 as well -- no reliance on "the line cannot be cached yet".  (Plain loads measured faster; the
-        // whole path is an opt-in that lost to the separate launches anyway, profiles/round4_ab_fused_groupnorm.txt.)
-        if (n0 + nl < a.N)
-          v = (long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.stat_out + ((long long)n_img * a.N + n0 + nl) * 2 + k),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tot[nl * 2 + k] = v;
-      }
-      __syncthreads();
-      const int cpg = a.N / 32;
-      float* const mr = reinterpret_cast<float*>(tot + BN * 2);            // [BN / cpg][2] (mean, rstd)
-      if (t < BN / cpg && n0 + t * cpg < a.N) {
-        long long si = 0, qi = 0;
-        for (int c = 0; c < cpg; ++c) { si += tot[(t * cpg + c) * 2]; qi += tot[(t * cpg + c) * 2 + 1]; }
-        const double cnt = (double)HW * (double)cpg;
-        const double md = (double)si * (1.0 / (double)STAT_SCALE_SUM) / cnt;
-        double vd = (double)qi * (1.0 / (double)STAT_SCALE_SQ) / cnt - md * md;
-        vd = vd < 0.0 ? 0.0 : vd;
-        float mean = (float)md, rstd = (float)(1.0 / sqrt(vd + 1e-5));
-        if (failed) { mean = __builtin_nanf(""); rstd = mean; }
-        mr[t * 2] = mean;
-        mr[t * 2 + 1] = rstd;
-        const int g = (n0 + t * cpg) / cpg;
-        if (m0 == n_img * HW && a.gn_stats_out) {            // the image's first m-tile records them for the backward pass
-          a.gn_stats_out[(n_img * 32 + g) * 2] = mean;
-          a.gn_stats_out[(n_img * 32 + g) * 2 + 1] = rstd;
-        }
-      }
-      __syncthreads();
-      if (has) {
-        const int gl = (chunk * 8) / cpg;                    // cpg % 8 == 0 (launcher): a chunk lies inside one group
-        const float mean = mr[gl * 2], rstd = mr[gl * 2 + 1];
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-          const int row = row_first + k * RSTEP;
-          const half8 x = *reinterpret_cast<const half8*>(tileH + row * LDH + chunk * 8);
-          half8 o;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            half_t yh = gn_affine((float)x[c], mean, rstd, gn_g[c], gn_b[c]);
-            if (a.gn_film) yh = gn_film(yh, gn_sc[c], gn_sh[c]);
-            o[c] = (half_t)gn_silu((float)yh);
-          }
-          *reinterpret_cast<half8*>(a.gn_out + (long long)(m0 + row) * a.N + n) = o;
-        }
       }
     }
   } else {

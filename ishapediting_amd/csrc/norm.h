@@ -33,8 +33,7 @@ struct GnApplyArgs {
   const long long* sums2 = nullptr;
   half_t* xcopy = nullptr;
   int csplit = 0;
-  PrefetchHint pf;               // weights of the convolution that runs next (extra workgroups touch them, common.h)
-  int main_blocks = 0;           // set by the launcher: workgroups [0, main_blocks) do the GroupNorm, the rest prefetch
+  int main_blocks = 0;           // set by the launcher: the grid size (a preloaded scalar in the kernel)
 };
 int gn_apply_launch(const GnApplyArgs& a, hipStream_t s);
 
@@ -59,7 +58,6 @@ struct GnBwdArgs {
   int N = 1, H = 0, W = 0, C = 0;
   int film = 0, act = 1, gmode = GB_SAME;
   int sums_ready = 0;             // csums were already accumulated by the producing implicit-GEMM epilogue: apply pass only
-  PrefetchHint pf;                // as in GnApplyArgs (apply pass)
   int main_blocks = 0;
 };
 int gn_backward_launch(const GnBwdArgs& a, hipStream_t s);
@@ -98,7 +96,6 @@ struct GnLocalArgs {
   int parts = 1;
   unsigned* status = nullptr;    // device status word (set by the launcher)
   int spin_limit = GN_SPIN_LIMIT;
-  PrefetchHint pf;               // weights of the convolution that runs next: workgroups beyond 32 * parts touch them
 };
 bool gn_local_fits(int HW, int C);              // LDS budget of the forward / backward staging
 int gn_local_parts(int N, int HW, int C);       // workgroups per (image, group) the launcher picks when a rendezvous record is given
@@ -124,7 +121,6 @@ struct GnBwdLocalArgs {
   int parts = 1;
   unsigned* status = nullptr;
   int spin_limit = GN_SPIN_LIMIT;
-  PrefetchHint pf;
 };
 bool gn_bwd_local_fits(int HW, int C, int gmode);
 int gn_bwd_local_launch(const GnBwdLocalArgs& a, hipStream_t s);

@@ -117,10 +117,6 @@ template <bool FILM, bool ACT, bool POOL, bool SPLIT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(int h_main_blocks, int h_C, int h_H, int h_W, int h_N, GnApplyArgs a) {
   // h_*: copies of h_main_blocks, h_C, h_H, h_W, h_N as leading scalar parameters, preloaded into SGPRs at dispatch
   // (common.h, IgemmHot): the index arithmetic runs under the s_load of `a`
-  if ((int)blockIdx.x >= h_main_blocks) {          // prefetch workgroups: the next convolution's weights (common.h)
-    prefetch_block(a.pf, blockIdx.x - h_main_blocks, gridDim.x - h_main_blocks);
-    return;
-  }
   const int CV = h_C >> 3;
   const int HWo = POOL ? (h_H >> 1) * (h_W >> 1) : h_H * h_W;
   const long long total = (long long)h_N * HWo * CV;
@@ -289,7 +285,7 @@ int gn_apply_launch(const GnApplyArgs& a, hipStream_t s) {
   const int HWo = a.pool ? (a.H / 2) * (a.W / 2) : a.H * a.W;
   long long total = (long long)a.N * HWo * (a.C / 8);
   int blocks = (int)((total + 255) / 256);
-  static const int cap_sums = [] { const char* e = getenv("ISHAP_GN_APPLY_BLOCKS"); return e ? atoi(e) : 1024; }();
+  constexpr int cap_sums = 1024;          // in-situ sweep (tools/experiments/gn_apply_probe.sh): flat 512 .. 2048
   if (blocks > (a.sums ? cap_sums : 4096)) blocks = a.sums ? cap_sums : 4096;   // fewer, fatter blocks amortise the finalise prologue
   // thread count = multiple of CV (a thread owns one 8-channel vector): blocks = multiple of CV / gcd(CV, 256)
   const int CV = a.C / 8;
@@ -297,10 +293,9 @@ int gn_apply_launch(const GnApplyArgs& a, hipStream_t s) {
   while (r256) { const int t = gcd % r256; gcd = r256; r256 = t; }
   const int unit = CV / gcd;
   blocks = blocks < unit ? unit : blocks / unit * unit;
-  static const int pf_on = [] { const char* e = getenv("ISHAP_PREFETCH"); return e ? atoi(e) : 0; }();
   GnApplyArgs a2 = a;
   a2.main_blocks = blocks;
-  dim3 g(blocks + (pf_on ? prefetch_blocks(a.pf, 256) : 0)), b(256);
+  dim3 g(blocks), b(256);
   if (a.split) hipLaunchKernelGGL((gn_apply_kernel<false, true, false, true>), g, b, 0, s, a2.main_blocks, a2.C, a2.H, a2.W, a2.N, a2);
   else if (a.pool) hipLaunchKernelGGL((gn_apply_kernel<false, true, true, false>), g, b, 0, s, a2.main_blocks, a2.C, a2.H, a2.W, a2.N, a2);
   else if (a.film) hipLaunchKernelGGL((gn_apply_kernel<true, true, false, false>), g, b, 0, s, a2.main_blocks, a2.C, a2.H, a2.W, a2.N, a2);

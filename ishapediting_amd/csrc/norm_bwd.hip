@@ -89,10 +89,6 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnBwdArgs a, int ro
 template <bool FILM, bool ACT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const long long* h_csums, int h_main_blocks, int h_C, int h_H, int h_W, int h_N, GnBwdArgs a) {
   // h_*: preloaded copies of h_csums, h_main_blocks, h_C, h_H, h_W, h_N (see gn_apply_kernel)
-  if ((int)blockIdx.x >= h_main_blocks) {          // prefetch workgroups: the next convolution's weights (common.h)
-    prefetch_block(a.pf, blockIdx.x - h_main_blocks, gridDim.x - h_main_blocks);
-    return;
-  }
   const int CV = h_C >> 3, HW = h_H * h_W, cpg = h_C / 32;
   const long long total = (long long)h_N * HW * CV;
   // group means of dyh and dyh*xh from the per-channel sums (8 lanes per (image, group))
@@ -195,10 +191,9 @@ int gn_backward_launch(const GnBwdArgs& a, hipStream_t s) {
   while (r256) { const int t = gcd % r256; gcd = r256; r256 = t; }
   const int unit = CV / gcd;
   blocks = blocks < unit ? unit : blocks / unit * unit;
-  static const int pf_on = [] { const char* e = getenv("ISHAP_PREFETCH"); return e ? atoi(e) : 0; }();
   GnBwdArgs a2 = a;
   a2.main_blocks = blocks;
-  const int grid_apply = blocks + (pf_on ? prefetch_blocks(a.pf, 256) : 0);
+  const int grid_apply = blocks;
 #define GB_LAUNCH(F, A)                                                                                             \
   do {                                                                                                              \
     if (!a.sums_ready)                                                                                              \

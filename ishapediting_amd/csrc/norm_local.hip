@@ -218,7 +218,8 @@ __device__ __forceinline__ void group_rendezvous(double& a, double& b, unsigned 
 }
 
 // workgroup -> (group, part).  xcd_local: the parts of a group get linear ids 8 apart (equal `id & 7` = one XCD under round-robin
-// placement; the image index blockIdx.y adds a multiple of 32 * parts, itself a multiple of 8); else parts are consecutive ids
+// placement; gridDim.x is exactly 32 * parts, so the image index blockIdx.y adds a multiple of 8 to the linear id -- round 6: the
+// prefetch workgroups that used to ride at the end of the grid and broke this for batches > 1 are gone); else parts are consecutive ids
 __device__ __forceinline__ void group_of_block(int parts, bool xcd_local, int& g, int& part) {
   if (xcd_local) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -236,11 +237,6 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(int h_parts, int h_C, in
   // h_*: copies of a.parts, a.C, a.H * a.W, a.Ca as leading scalar parameters -- preloaded into SGPRs at dispatch (common.h,
   // IgemmHot), so that the index arithmetic (three integer divisions) runs UNDER the s_load of the argument block, not after it
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if ((int)blockIdx.x >= 32 * (h_parts < 0 ? (-h_parts & 63) : h_parts)) {           // prefetch workgroups (last in the grid: the GroupNorm ones are dispatched first)
-    const int nmain = 32 * (h_parts < 0 ? (-h_parts & 63) : h_parts), npf = gridDim.x - nmain;
-    prefetch_block(a.pf, (blockIdx.x - nmain) + npf * blockIdx.y, npf * gridDim.y);
-    return;
-  }
   double* scratch = reinterpret_cast<double*>(smem_raw);                 // 32 doubles (block_sum2: 2 x 16; rendezvous: 4 x parts)
   half_t* st = reinterpret_cast<half_t*>(smem_raw + 256);                // [HW][cpg]
   const bool xcd_local = h_parts < 0;                                    // the launcher passes -(parts [+ 64]) for the XCD-local dealing
@@ -440,11 +436,6 @@ template <int VEC, bool FILM, bool ACT, bool STAGE32>
 __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(int h_parts, int h_C, int h_HW, GnBwdLocalArgs a) {
   // h_*: preloaded copies of a.parts, a.C, a.H * a.W (see gn_local_kernel)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if ((int)blockIdx.x >= 32 * (h_parts < 0 ? (-h_parts & 63) : h_parts)) {
-    const int nmain = 32 * (h_parts < 0 ? (-h_parts & 63) : h_parts), npf = gridDim.x - nmain;
-    prefetch_block(a.pf, (blockIdx.x - nmain) + npf * blockIdx.y, npf * gridDim.y);
-    return;
-  }
   double* scratch = reinterpret_cast<double*>(smem_raw);
   half_t* st16 = reinterpret_cast<half_t*>(smem_raw + 256);
   float* st32 = reinterpret_cast<float*>(smem_raw + 256);
@@ -563,7 +554,7 @@ int pick_threads(int nunits) { return nunits >= 1024 ? 1024 : (nunits <= 256 ? 2
 // at least `min_pixels` pixels made of whole units of `unit` pixels (a row pair when the kernel pools)
 int pick_parts(int N, int HW, int cpg, int unit, bool have_rec) {
   static const int maxp = [] { const char* e = getenv("ISHAP_GN_PARTS"); return e ? atoi(e) : 8; }();
-  static const int min_el = [] { const char* e = getenv("ISHAP_GN_PART_ELEMS"); return e ? atoi(e) : 128; }();
+  constexpr int min_el = 128;       // elements per part at least (in-situ sweeps below)
   if (!have_rec) return 1;
   // the rendezvous costs ~3 atomic round trips (3-4 us), yet more, smaller parts still win down to a few hundred elements
   // per workgroup (in-situ sweep: 0.2445 / 0.2464 / 0.2500 / 0.2574 s per edit at >= 256 / 1024 / 2048 / 4096 elements;
@@ -572,23 +563,14 @@ int pick_parts(int N, int HW, int cpg, int unit, bool have_rec) {
   int p = 1;
   // co-residency: a workgroup of these kernels (<= 1024 threads, <= 160 KB of LDS) always fits a compute unit by itself, so
   // a grid of at most one workgroup per CU OF THIS DEVICE (a partitioned MI355X exposes fewer than 256) becomes resident
-  // whatever else is draining; ISHAP_GN_MAX_WGS can only lower that bound
-  static const int env_wgs = [] { const char* e = getenv("ISHAP_GN_MAX_WGS"); return e ? atoi(e) : 0; }();
-  int max_wgs = ishap_cu_count();
-  if (env_wgs > 0 && env_wgs < max_wgs) max_wgs = env_wgs;
+  // whatever else is draining
+  const int max_wgs = ishap_cu_count();
   while (p * 2 <= maxp && p * 2 <= GN_REC_HALF / GN_REC_PER_PART && 32 * N * (p * 2) <= max_wgs && HW % (p * 2) == 0 &&
          (HW / (p * 2)) % unit == 0 && (long long)(HW / (p * 2)) * cpg >= min_el)
     p *= 2;
   return p;
 }
 constexpr size_t LOCAL_LDS_CAP = 160 * 1024 - 256;
-// prefetch workgroups per image row of the grid (they inherit the launch's LDS request: none when that would cost a CU each)
-int pf_blocks_for(const PrefetchHint& h, int threads, int N, size_t smem) {
-  static const int on = [] { const char* e = getenv("ISHAP_PREFETCH"); return e ? atoi(e) : 0; }();
-  if (!on || !h.any() || smem > 16 * 1024) return 0;
-  const int total = prefetch_blocks(h, threads);
-  return (total + N - 1) / N;
-}
 // polls before a rendezvous gives up; ISHAP_GN_SPIN_LIMIT exists so that a test can force the give-up path (1 poll)
 int spin_limit() {
   static const int v = [] { const char* e = getenv("ISHAP_GN_SPIN_LIMIT"); const int n = e ? atoi(e) : 0; return n > 0 ? n : GN_SPIN_LIMIT; }();
@@ -633,7 +615,7 @@ int gn_local_launch(const GnLocalArgs& a, hipStream_t s) {
   const int VEC = pick_vec(cpg, PP, a.slab.pending());
   const int T = pick_threads(PP * (cpg / VEC));
   const size_t smem = 256 + (size_t)PP * cpg * sizeof(half_t);
-  dim3 grid(32 * b.parts + pf_blocks_for(a.pf, T, a.N, smem), a.N), blk(T);
+  dim3 grid(32 * b.parts, a.N), blk(T);
 #define GL_LAUNCH(V, F, A, P)                                                            \
   do {                                                                                   \
     auto kern = gn_local_kernel<V, F, A, P>;                                             \
@@ -678,7 +660,7 @@ int gn_bwd_local_launch(const GnBwdLocalArgs& a, hipStream_t s) {
   ISHAP_REQUIRE(smem <= LOCAL_LDS_CAP + 256, "group does not fit in LDS");
   const int VEC = pick_vec(cpg, PP, a.slab.pending());
   const int T = pick_threads(PP * (cpg / VEC));
-  dim3 grid(32 * b.parts + pf_blocks_for(a.pf, T, a.N, smem), a.N), blk(T);
+  dim3 grid(32 * b.parts, a.N), blk(T);
 #define GB_LAUNCH(V, F, A, S32)                                                          \
   do {                                                                                   \
     auto kern = gn_bwd_local_kernel<V, F, A, S32>;                                       \

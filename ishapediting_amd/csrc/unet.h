@@ -181,28 +181,13 @@ struct ishap_unet {
   size_t attn_D_floats = 0;
 };
 
-// weights a convolution is about to stream, as a prefetch hint for the kernel that runs before it (common.h)
-static inline PrefetchHint pf_fwd(const ConvW& c) {          // forward operand; the [c2 | skip] concatenation when there is one
-  const size_t rows = ((size_t)c.cout + 127) / 128 * 128;
-  if (c.cat && c.cat_off == 0) return prefetch_hint(c.cat, rows * c.cat_ld * sizeof(half_t));
-  return prefetch_hint(c.w, rows * c.taps * c.kpad * sizeof(half_t));
-}
-static inline PrefetchHint pf_bwd(const ConvW& c) {          // input-gradient operand
-  const size_t rows = ((size_t)((c.cin + 31) / 32 * 32) + 127) / 128 * 128;
-  return prefetch_hint(c.wT, rows * c.taps * c.cout_pad * sizeof(half_t));
-}
-
 struct Exec {
   ishap_unet* u;
   hipStream_t s;
   bool dry;
-  PrefetchHint next_block_pf;   // backward: first weights of the block processed after the current one
   bool keep = false;   // the forward keeps what a following backward re-reads
   float* ws = nullptr;          // split-K / GroupNorm-statistics scratch of this launch sequence (null: the context's)
   float* gn_partial = nullptr;
-  int lite = 0;                 // 1: this sequence's convolutions use the LDS-light kernel forms (IgemmArgs::lite)
-  int force_small = 0;          // 1: this sequence's convolutions take 64x64 tiles only
-  int chunk_tiles_big = 0;
   int chunk_tiles = 0;          // > 0: the dx-reuse convolutions of this sequence run as launches of at most that many tiles (the overlapped forward tail)
   bool tenant = true;           // this sequence holds the device's rendezvous tenancy (common.h ishap_rendezvous_begin)
 };
@@ -230,24 +215,13 @@ static inline int aalloc_checked(Exec& e, size_t count, T** out) {
     (ptr) = salloc((e), (size_t)(count));                                                             \
     ISHAP_REQUIRE((ptr) != nullptr, "GroupNorm statistics arena exhausted");                          \
   } while (0)
-// GroupNorm (+FiLM) + SiLU of a convolution's output applied in that convolution's own epilogue (IgemmArgs::gn_out): what the
-// caller would otherwise run as a gn_apply launch on the result.  conv_op sets *fused when the launch could take it.
-struct GnFuse {
-  half_t* out = nullptr;           // act(film(GN(conv output))), dense [N*H*W][cout]
-  const float* gamma = nullptr;
-  const float* beta = nullptr;
-  const float* emb = nullptr;      // FiLM rows or null
-  int emb_ld = 0;
-  float* stats_out = nullptr;      // (mean, rstd) [N][32][2] for the backward pass
-  bool* fused = nullptr;
-};
 // X [N,H,W,ldx] (*) Wt -> out; taps 9 (3x3, pad 1) or 1; picks split-K and uses the context workspace
 // pend_out: the caller's consumer can read split-K slices (a group-local GroupNorm pass): when the launch splits K, the
 // slices stay in an arena buffer described by *pend_out and no reduce kernel runs (fp16 dense outputs only)
 int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps, int cout,
             const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups, int res_ups,
             long long* stat_out = nullptr, const struct GnBwdArgs* gb = nullptr, const half_t* X2 = nullptr, int ldx2 = 0,
-            int K2 = 0, const float* bias2 = nullptr, int ldw = 0, SlabSrc* pend_out = nullptr, const GnFuse* gf = nullptr);
+            int K2 = 0, const float* bias2 = nullptr, int ldw = 0, SlabSrc* pend_out = nullptr);
 // small maps (<= 32 x 32): GroupNorm passes run group-local (norm_local.hip), producers gather no statistics
 int unet_join_tail(ishap_unet* u, hipStream_t s);
 bool small_map(int HW);

@@ -264,23 +264,21 @@ long long* salloc(Exec& e, size_t count) {
 // the tail never launches rendezvous grids (exec_is_solo is false for it), and kernels that wait for nobody cannot starve a
 // grid that does -- they finish and free their compute units (the same argument as for tenants, common.h).
 bool exec_is_solo(const Exec& e) {
-  static const int strict = [] { const char* v = getenv("ISHAP_SOLO_STRICT"); return v ? atoi(v) : 0; }();
-  return e.dry || (e.tenant && (!strict || !e.u->tail_pending) && (e.u->side == nullptr || e.s != e.u->side));
+  return e.dry || (e.tenant && (e.u->side == nullptr || e.s != e.u->side));
 }
 
 bool small_map(int HW) {
+  // ISHAP_LOCAL_GN=0: the two-pass GroupNorm route everywhere (A/B); the 64x64 maps group-local as well measured slower (round 5)
   static const int on = [] { const char* v = getenv("ISHAP_LOCAL_GN"); return v ? atoi(v) : 1; }();
-  static const int max_hw = [] { const char* v = getenv("ISHAP_LOCAL_GN_HW"); return v ? atoi(v) : 1024; }();   // experiment: 4096 = the 64x64 maps too
-  return on && HW <= (on == 2 ? 64 : max_hw);      // 2: only the 8x8 maps
+  return on && HW <= 1024;
 }
 bool local_gn(int HW, int C) { return small_map(HW) && gn_local_fits(HW, C); }
 
 int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t* Wt, int kpad, int taps,
                    int cout, const float* bias, const half_t* res, int ldr, void* out, int ldo, int out_mode, int ups,
                    int res_ups, long long* stat_out, const GnBwdArgs* gb, const half_t* X2, int ldx2, int K2,
-                   const float* bias2, int ldw, SlabSrc* pend_out, const GnFuse* gf) {
+                   const float* bias2, int ldw, SlabSrc* pend_out) {
   IgemmArgs a;
-  if (gf && gf->fused) *gf->fused = false;
   a.stat_out = stat_out;
   if (gb) {       // this launch produces the gradient arriving at act(film(GN(x))): accumulate the GN-backward sums in its epilogue
     a.gb_x = gb->x; a.gb_stats = gb->stats; a.gb_gamma = gb->gamma; a.gb_beta = gb->beta; a.gb_emb = gb->emb;
@@ -294,13 +292,6 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
   a.H = H; a.W = W; a.ups = ups; a.res_ups = res_ups;
   a.out_mode = out_mode;
   a.chunk_tiles = e.chunk_tiles;
-  a.chunk_tiles_big = e.chunk_tiles_big;
-  a.force_small = e.force_small;
-  a.lite = e.lite;
-  // experiment (ISHAP_LITE_BATCH=n): from batch n on, the 128x128-tile launches of EVERY sequence take the LDS-light form, two
-  // workgroups per CU -- with 4+ tiles per CU (the batched generate path) one tile's epilogue then runs under another's K loop
-  static const int lite_batch = [] { const char* v = getenv("ISHAP_LITE_BATCH"); return v ? atoi(v) : 0; }();
-  if (lite_batch > 0 && N >= lite_batch && taps == 9 && H * W >= 1024) a.lite = 2;
   a.flops_scale = (Wt == e.u->head.w) ? 1.f / 3.f : 1.f;
   a.ksplit = igemm_pick_ksplit(a.M, a.N, a.K, 1, pend_out != nullptr);
   if (!a.conv3 && a.M <= 64 && a.K % 64 == 0) {
@@ -310,11 +301,10 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
     static const int sliced = [] { const char* v = getenv("ISHAP_G1_SLICES"); return v ? atoi(v) : 1; }();
     a.ksplit = (sliced && pend_out && a.K >= 2048) ? (a.K >= 3072 ? 16 : 8) : 1;
   }
-  if (igemm_small3_wanted(a)) {
-    // 3x3 on the 8x8 maps: K sliced over workgroups only when the consumer adds the slices up -- then igemm4's 64x64 tiles with
-    // ~16 slices (igemm4_small_map_slices), else conv3_small (igemm_small3.hip) in one launch
-    const int s4 = pend_out ? igemm4_small_map_slices(a) : 0;
-    a.ksplit = s4 > 1 ? s4 : pend_out ? igemm_small3_slices(a) : 1;
+  if (a.conv3 && H * W == 64 && pend_out) {
+    // 3x3 on the 8x8 maps whose consumer adds K slices up: igemm4's 64x64 tiles (= one image) with ~16 slices
+    const int s4 = igemm4_small_map_slices(a);
+    if (s4 > 1) a.ksplit = s4;
   }
   if (pend_out) *pend_out = SlabSrc{};
   if (pend_out && a.ksplit > 1) {
@@ -330,37 +320,9 @@ int conv_op(Exec& e, const half_t* X, int N, int H, int W, int ldx, const half_t
     return igemm_launch(a, e.s);
   }
   size_t need = a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N : 0;
-  // Fused GroupNorm of the output (IgemmArgs::gn_out): an unsplit launch with the staged epilogue whose whole grid is resident at
-  // once (at most one workgroup per CU of this device), on the context's only launch sequence (the in-launch wait: exec_is_solo)
-  // OFF by default: measured a LOSS (profiles/round4_ab_fused_groupnorm.txt: 0.1845 -> 0.1879 s/shape; a fused 128-tile launch
-  // takes +16.7 us -- every workgroup waits for the slowest tile of the grid, then the acknowledged atomics, the counter and the
-  // totals each cost a memory round trip -- against the 6.7-9.2 us gn_apply launch + 1.5 us boundary it removes).  ISHAP_FUSE_GN=1
-  // switches it on; tests/test_gpu_fullsize.py holds it bitwise against the separate launches.
-  static const int fuse_on = [] { const char* v = getenv("ISHAP_FUSE_GN"); return v ? atoi(v) : 0; }();
-  unsigned* gn_counter = nullptr;
-  bool fuse = false;
-  if (gf && fuse_on && stat_out && !gb && a.ksplit == 1 && out_mode == IG_OUT_F16 && ldo == cout && cout % 32 == 0 && (cout / 32) % 8 == 0 &&
-      (res == nullptr || ldr % 8 == 0) && H * W >= 4096 && exec_is_solo(e)) {
-    const int wgs = igemm_stat_launch_workgroups(a);
-    if (wgs > 0 && wgs <= ishap_cu_count()) {
-      long long* c64 = salloc(e, 128);              // [N_img][n-tiles] arrival counters, zeroed with the statistics arena
-      ISHAP_REQUIRE(c64 != nullptr, "GroupNorm statistics arena exhausted");
-      gn_counter = reinterpret_cast<unsigned*>(c64);
-      fuse = N * ceil_div(cout, 64) <= 256;
-    }
-  }
   if (e.dry) {
     if (need > e.u->ws_floats) e.u->ws_floats = need;
-    if (gf && gf->fused) *gf->fused = fuse;
     return 0;
-  }
-  if (fuse) {
-    a.gn_out = gf->out; a.gn_gamma = gf->gamma; a.gn_beta = gf->beta; a.gn_emb = gf->emb; a.gn_emb_ld = gf->emb_ld; a.gn_film = gf->emb != nullptr;
-    a.gn_stats_out = gf->stats_out; a.gn_counter = gn_counter; a.gn_status = ishap_status_word();
-    ISHAP_REQUIRE(a.gn_status != nullptr, "device status word");
-    static const int spin = [] { const char* v = getenv("ISHAP_GN_SPIN_LIMIT"); const int n = v ? atoi(v) : 0; return n > 0 ? n : (1 << 22); }();
-    a.gn_spin_limit = spin;
-    if (gf->fused) *gf->fused = true;
   }
   ISHAP_REQUIRE(need <= e.u->ws_floats, "split-K workspace too small");
   a.ws = e.ws ? e.ws : e.u->ws;
@@ -393,9 +355,8 @@ int gn_stats_op(Exec& e, const Tensor& x, float* stats) {
 // GroupNorm (+FiLM) (+SiLU) (+2x2 pool) of `x` into `out` on a small map: one group-local launch that also adds up `x`
 // when it is still pending (and its first half when x is a lazy skip concatenation), see norm_local.hip
 static int gn_local_op(Exec& e, Tensor& x, const NormW& nw, half_t* out, half_t* xpool, float* stats_out, const float* emb,
-                       int emb_ld, int film, int act, int pool, PrefetchHint pf = PrefetchHint{}) {
+                       int emb_ld, int film, int act, int pool) {
   GnLocalArgs g;
-  g.pf = pf;
   if (x.cat_a) {
     g.xa = x.cat_a; g.slab = x.cat_pend; g.ya = x.cat_pend.pending() ? const_cast<half_t*>(x.cat_a) : nullptr;
     g.Ca = x.cat_ca; g.xb = x.cat_b; g.xcopy = x.p;
@@ -432,7 +393,7 @@ static int res_forward(Exec& e, ResL& L, Tensor x, Tensor& y) {
   xs.pend = SlabSrc{}; xs.cat_pend = SlabSrc{};
   if (L.down) { xs = a; ISHAP_ALLOC(xs.p, e, a.numel()); }
   if (loc_in) {
-    ISHAP_TRY(gn_local_op(e, x, L.n1, a.p, L.down ? xs.p : nullptr, st1, nullptr, 0, 0, 1, L.down, pf_fwd(L.c1)));
+    ISHAP_TRY(gn_local_op(e, x, L.n1, a.p, L.down ? xs.p : nullptr, st1, nullptr, 0, 0, 1, L.down));
   } else {
     ISHAP_REQUIRE(!lazy_cat || (x.cat_sa && x.cat_sb), "a lazy concatenation on a large map carries the producers' sums");
     ISHAP_TRY(slab_materialize(e, x));
@@ -442,7 +403,6 @@ static int res_forward(Exec& e, ResL& L, Tensor x, Tensor& y) {
       g.x = x.p; g.out = a.p; g.xpool = L.down ? xs.p : nullptr;
       g.stats = st1; g.sums = x.sums; g.stats_out = x.sums ? st1 : nullptr; g.gamma = L.n1.gamma; g.beta = L.n1.beta;
       g.N = N; g.H = H; g.W = W; g.C = L.cin; g.act = 1; g.pool = L.down;
-      g.pf = pf_fwd(L.c1);
       if (lazy_cat) {
         g.x = x.cat_a; g.x2 = x.cat_b; g.sums = x.cat_sa; g.sums2 = x.cat_sb; g.csplit = x.cat_ca; g.xcopy = x.p;
         g.stats_out = st1;
@@ -456,18 +416,10 @@ static int res_forward(Exec& e, ResL& L, Tensor x, Tensor& y) {
   Tensor c = h1;
   c.pend = SlabSrc{};
   ISHAP_ALLOC(c.p, e, h1.numel());
-  // on the big maps the second norm (+FiLM +SiLU) runs in conv1's own epilogue when the launch can take it (conv_op, GnFuse)
-  bool fused2 = false;
-  GnFuse gf;
-  gf.out = c.p; gf.gamma = L.n2.gamma; gf.beta = L.n2.beta; gf.emb = u->film_cur + L.emb_off; gf.emb_ld = u->film_cur_ld;
-  gf.stats_out = st2; gf.fused = &fused2;
   ISHAP_TRY(conv_op(e, a.p, N, Ho, Wo, L.cin, L.c1.w, L.c1.kpad, 9, L.cout, L.c1.bias, nullptr, 0, h1.p, L.cout, IG_OUT_F16,
-                    L.up, 0, h1.sums, nullptr, nullptr, 0, 0, nullptr, 0, loc_out ? &h1.pend : nullptr,
-                    (!loc_out && h1.sums) ? &gf : nullptr));
-  if (fused2) {
-    // nothing to launch
-  } else if (loc_out) {
-    ISHAP_TRY(gn_local_op(e, h1, L.n2, c.p, nullptr, st2, u->film_cur + L.emb_off, u->film_cur_ld, 1, 1, 0, pf_fwd(L.c2)));
+                    L.up, 0, h1.sums, nullptr, nullptr, 0, 0, nullptr, 0, loc_out ? &h1.pend : nullptr));
+  if (loc_out) {
+    ISHAP_TRY(gn_local_op(e, h1, L.n2, c.p, nullptr, st2, u->film_cur + L.emb_off, u->film_cur_ld, 1, 1, 0));
   } else {
     if (!h1.sums) ISHAP_TRY(gn_stats_op(e, h1, st2));
     if (!e.dry) {
@@ -475,7 +427,6 @@ static int res_forward(Exec& e, ResL& L, Tensor x, Tensor& y) {
       g.x = h1.p; g.out = c.p; g.stats = st2; g.sums = h1.sums; g.stats_out = h1.sums ? st2 : nullptr; g.gamma = L.n2.gamma; g.beta = L.n2.beta;
       g.emb = u->film_cur + L.emb_off; g.emb_ld = u->film_cur_ld;
       g.N = N; g.H = Ho; g.W = Wo; g.C = L.cout; g.film = 1; g.act = 1;
-      g.pf = pf_fwd(L.c2);
       ISHAP_TRY(gn_apply_launch(g, e.s));
     }
   }
@@ -518,7 +469,7 @@ static int attn_forward(Exec& e, AttnL& L, Tensor x, Tensor& y) {
   nrm.pend = SlabSrc{};
   ISHAP_ALLOC(nrm.p, e, x.numel());
   if (local_gn(T, C)) {
-    ISHAP_TRY(gn_local_op(e, x, L.n, nrm.p, nullptr, st, nullptr, 0, 0, 0, 0, pf_fwd(L.qkv)));
+    ISHAP_TRY(gn_local_op(e, x, L.n, nrm.p, nullptr, st, nullptr, 0, 0, 0, 0));
   } else {
     ISHAP_TRY(slab_materialize(e, x));
     if (!x.sums) ISHAP_TRY(gn_stats_op(e, x, st));
@@ -526,15 +477,16 @@ static int attn_forward(Exec& e, AttnL& L, Tensor x, Tensor& y) {
       GnApplyArgs g;
       g.x = x.p; g.out = nrm.p; g.stats = st; g.sums = x.sums; g.stats_out = x.sums ? st : nullptr; g.gamma = L.n.gamma; g.beta = L.n.beta;
       g.N = N; g.H = x.H; g.W = x.W; g.C = C; g.act = 0;
-      g.pf = pf_fwd(L.qkv);
       ISHAP_TRY(gn_apply_launch(g, e.s));
     }
   }
   Tensor qkv{nullptr, N, x.H, x.W, 3 * C};
   ISHAP_ALLOC(qkv.p, e, qkv.numel());
-  if (attn8_applicable(N, T, C, d) && L.qkv.kpad == C && L.proj.kpad == C && small_map(T) && exec_is_solo(e)) {
+  if (attn8_applicable(N, T, C, d) && L.qkv.kpad == C && L.proj.kpad == C && small_map(T)) {
     // 8x8 map: qkv GEMM + attention + proj_out in ONE launch (attention.hip, attn8_fused_kernel); proj_out leaves as per-head
-    // K slices that the next GroupNorm pass adds up with its bias and the residual x (ISHAP_ATTN8=1)
+    // K slices that the next GroupNorm pass adds up with its bias and the residual x (ISHAP_ATTN8=1).  The route depends on the
+    // shape only: a sequence without the rendezvous tenancy (a second context, the deferred forward tail's replay) makes the same
+    // allocations and runs the same kernel as two launches -- the same bits (round 6)
     Tensor a = x;
     ISHAP_ALLOC(a.p, e, x.numel());
     float* slices = nullptr;
@@ -553,7 +505,7 @@ static int attn_forward(Exec& e, AttnL& L, Tensor x, Tensor& y) {
       g.slices = slices; g.flags = reinterpret_cast<unsigned*>(fl); g.status = ishap_status_word();
       ISHAP_REQUIRE(g.status != nullptr, "device status word");
       g.N = N; g.C = C; g.heads = heads; g.alpha = 1.f / sqrtf((float)d);
-      ISHAP_TRY(attn8_fused_launch(g, e.s));
+      ISHAP_TRY(attn8_fused_launch(g, e.s, exec_is_solo(e)));
     }
     L.sv.x = x; L.sv.qkv = qkv; L.sv.a = a; L.sv.stats = st; L.sv.lse = lse; L.sv.P = nullptr;
     return 0;
@@ -562,30 +514,17 @@ static int attn_forward(Exec& e, AttnL& L, Tensor x, Tensor& y) {
                     IG_OUT_F16, 0, 0));
   Tensor a = x;
   ISHAP_ALLOC(a.p, e, x.numel());
-  // proj_out from the attention launch as per-head slices (attention.hip, attn_fwd_kernel<.., NT>): small maps only -- the
-  // consumer must be a GroupNorm pass that adds pending slices up (opt-in: ISHAP_ATTN_PROJ=1)
-  const int proj_parts = L.proj.kpad >= C && small_map(T) ? attn_proj_parts(N, T, C, d) : 0;
-  const bool proj_slices = proj_parts > 0;
-  float* slices = nullptr;
-  if (proj_slices) ISHAP_ALLOC(slices, e, (size_t)heads * N * T * C);
   if (!e.dry) {
     // fused flash-style attention: w = softmax((q*s)^T (k*s)), a = w v   (unet.py:347-353)
     AttnArgs g;
     g.qkv = qkv.p; g.out = a.p; g.lse = lse; g.N = N; g.T = T; g.C = C; g.heads = heads; g.d = d;
     g.alpha = 1.f / sqrtf((float)d);
-    if (proj_slices) { g.wproj = L.proj.w; g.ldp = L.proj.kpad; g.slices = slices; g.proj_parts = proj_parts; }
     ISHAP_TRY(attn_forward_launch(g, e.s));
   }
   y = x;
   y.pend = SlabSrc{};
   ISHAP_ALLOC(y.p, e, x.numel());
   y.sums = nullptr;
-  if (proj_slices) {
-    y.pend.ws = slices; y.pend.nslab = heads; y.pend.zstride = (long long)N * T * C;
-    y.pend.bias = L.proj.bias; y.pend.res = x.p; y.pend.ldr = C;
-    L.sv.x = x; L.sv.qkv = qkv; L.sv.a = a; L.sv.stats = st; L.sv.lse = lse; L.sv.P = nullptr;
-    return 0;
-  }
   const bool nosum = small_map(T);
   if (!nosum) ISHAP_SALLOC(y.sums, e, (size_t)N * C * 2);
   ISHAP_TRY(conv_op(e, a.p, N, x.H, x.W, C, L.proj.w, L.proj.kpad, 1, C, L.proj.bias, x.p, C, y.p, C, IG_OUT_F16, 0, 0,
@@ -632,19 +571,11 @@ static void tail_exec(Exec& e, ishap_unet* u) {
   e.s = u->side;
   e.ws = u->ws_side;
   e.gn_partial = u->gn_partial_side;
-  // the tail's 3x3 convolutions as launches of at most P tiles: it then holds the LDS of at most P compute units at a time
-  // and the backward chain on the caller's stream keeps the rest (ISHAP_TAIL_WGS, 0 = whole-layer grids)
-  // in-situ sweep (profiles/round5_overlap_tail_ab.txt): 64 tiles per launch is the optimum (32: the tail becomes the critical
-  // path; 96 ... 192 and whole layers: the backward's convolutions wait for compute units)
-  static const int tail_wgs = [] { const char* v = getenv("ISHAP_TAIL_WGS"); return v ? atoi(v) : 64; }();
-  e.chunk_tiles = tail_wgs;
-  static const int tail_wgs_big = [] { const char* v = getenv("ISHAP_TAIL_WGS_BIG"); return v ? atoi(v) : 0; }();
-  e.chunk_tiles_big = tail_wgs_big;
-  static const int tail_small = [] { const char* v = getenv("ISHAP_TAIL_SMALL"); return v ? atoi(v) : 0; }();
-  e.force_small = tail_small;
-  static const int tail_lite = [] { const char* v = getenv("ISHAP_TAIL_LITE"); return v ? atoi(v) : 0; }();
-  e.lite = tail_lite;
-  if (tail_lite) e.chunk_tiles = 0;              // whole-layer grids: the point is to share every CU, not to leave some free
+  // the tail's 3x3 convolutions as launches of at most P tiles: it then holds the LDS of at most P compute units at a time and
+  // the backward chain on the caller's stream keeps the rest.  In-situ sweep with the start point (profiles/round5_overlap_tail_ab.txt):
+  // 96 / 112 / 128 / 144 / 160 / 192 / 256 tiles -> 0.1706 / 0.1707 / 0.1682 / 0.1707 / 0.1714 / 0.1727 / 0.1785 s per edit
+  static const int wgs = [] { const char* v = getenv("ISHAP_TAIL_DEFER_WGS"); return v ? atoi(v) : 128; }();
+  e.chunk_tiles = wgs;
 }
 
 // output blocks [i0, i1): skip concatenation + block (gd/unet.py:661-664); records the tap after block `feat_layer`
@@ -696,7 +627,6 @@ static int forward_head(Exec& e, ishap_unet* u, Tensor h, int N, float* out) {
     g.x = h.p; g.out = hsplit; g.stats = u->head_stats; g.sums = h.sums; g.stats_out = h.sums ? u->head_stats : nullptr;
     g.gamma = u->head_norm.gamma; g.beta = u->head_norm.beta;
     g.N = N; g.H = S; g.W = S; g.C = h.C; g.act = 1; g.split = 1;
-    g.pf = pf_fwd(u->head);
     ISHAP_TRY(gn_apply_launch(g, e.s));
   }
   ISHAP_TRY(conv_op(e, hsplit, N, S, S, 3 * h.C, u->head.w, u->head.kpad, 9, cfg.out_channels, u->head.bias, nullptr, 0, out,
@@ -706,12 +636,7 @@ static int forward_head(Exec& e, ishap_unet* u, Tensor h, int N, float* out) {
 
 // the deferred forward tail (ISHAP_TAIL_DEFER): the launches unet_forward_impl only planned, on the side stream, behind the event
 // the backward recorded after its first blocks (or behind the fork when it recorded none)
-int unet_run_tail(ishap_unet* u) {
-  if (!u->tail_deferred) return 0;
-  u->tail_deferred = false;
-  const size_t keep_arena = u->arena.off, keep_stat = u->stat_off;
-  u->arena.off = u->tail.arena_off;
-  u->stat_off = u->tail.stat_off;
+static int unet_run_tail_body(ishap_unet* u) {
   ISHAP_CHECK_HIP(hipStreamWaitEvent(u->side, u->mid_recorded ? u->ev_mid : u->ev_fork, 0));
   if (u->marks_on && u->marks_n > 0) {           // diagnostic marks (unet.h): the tail's span on the side stream
     if (!u->mark_tail_begin) { ISHAP_CHECK_HIP(hipEventCreate(&u->mark_tail_begin)); ISHAP_CHECK_HIP(hipEventCreate(&u->mark_tail_end)); }
@@ -721,34 +646,33 @@ int unet_run_tail(ishap_unet* u) {
   e.tenant = false;
   e.keep = u->tail.keep;
   tail_exec(e, u);
-  // tiles per launch: 128 = half a layer at a time (in-situ sweep with the start point: 96 / 112 / 128 / 144 / 160 / 192 / 256 ->
-  // 0.1706 / 0.1707 / 0.1682 / 0.1707 / 0.1714 / 0.1727 / 0.1785 s per edit, default before 0.1720-0.1731)
-  static const int wgs = [] { const char* v = getenv("ISHAP_TAIL_DEFER_WGS"); return v ? atoi(v) : 128; }();
-  e.chunk_tiles = wgs;
   Tensor h = u->tail.h;
   std::vector<Tensor> hs = u->tail.hs;
-  // ISHAP_TAIL_LATE=k / ISHAP_TAIL_LATE_WGS=n: the last k blocks and the head with n tiles per launch (they run when the backward
-  // is back on its chip-filling input blocks)
-  static const int late = [] { const char* v = getenv("ISHAP_TAIL_LATE"); return v ? atoi(v) : 0; }();
-  static const int late_wgs = [] { const char* v = getenv("ISHAP_TAIL_LATE_WGS"); return v ? atoi(v) : 64; }();
-  const size_t n_out = u->out_blocks.size();
-  const size_t cut = late > 0 && n_out - u->tail.split > (size_t)late ? n_out - (size_t)late : n_out;
-  ISHAP_TRY(out_blocks_range(e, u, u->tail.split, cut, h, hs, u->last_feat));
-  if (cut < n_out) {
-    e.chunk_tiles = late_wgs;
-    ISHAP_TRY(out_blocks_range(e, u, cut, n_out, h, hs, u->last_feat));
-  }
+  ISHAP_TRY(out_blocks_range(e, u, u->tail.split, u->out_blocks.size(), h, hs, u->last_feat));
   ISHAP_TRY(forward_head(e, u, h, u->tail.N, u->tail.out));
   if (u->marks_on && u->marks_n > 0 && u->mark_tail_begin) {
     ISHAP_CHECK_HIP(hipEventRecord(u->mark_tail_end, u->side));
     u->mark_tail_set = true;
   }
-  ISHAP_CHECK_HIP(hipEventRecord(u->ev_tail, u->side));
-  u->tail_pending = true;
   ISHAP_REQUIRE(u->arena.off == u->fwd_mark && u->stat_off == u->stat_fwd_mark, "the deferred tail allocated differently from its plan");
+  return 0;
+}
+
+int unet_run_tail(ishap_unet* u) {
+  if (!u->tail_deferred) return 0;
+  u->tail_deferred = false;
+  const size_t keep_arena = u->arena.off, keep_stat = u->stat_off;
+  u->arena.off = u->tail.arena_off;
+  u->stat_off = u->tail.stat_off;
+  const int r = unet_run_tail_body(u);
+  // on EVERY exit path: the caller's arena offsets come back, and whatever was enqueued on the side stream before a failure is
+  // closed by ev_tail, so that the next join (forward, full-depth backward, read-out) still orders behind it before the arena
+  // or `out` is reused
   u->arena.off = keep_arena;
   u->stat_off = keep_stat;
-  return 0;
+  if (hipEventRecord(u->ev_tail, u->side) == hipSuccess) u->tail_pending = true;
+  else if (r == 0) { ishap_set_error("hipEventRecord(ev_tail) failed after the deferred forward tail"); return -1; }
+  return r;
 }
 
 int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int feat_layer, float* out,
@@ -772,15 +696,7 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     // leaves idle, not compete with it for compute units
     int prio_least = 0, prio_greatest = 0;
     ISHAP_CHECK_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    static const int prio_env = [] { const char* e = getenv("ISHAP_TAIL_PRIORITY"); return e ? atoi(e) : 1; }();
-    static const unsigned cu_mask_env = [] { const char* e = getenv("ISHAP_TAIL_CU_MASK"); return e ? (unsigned)strtoul(e, nullptr, 16) : 0u; }();
-    if (cu_mask_env) {                 // experiment: confine the tail to a subset of the compute units
-      unsigned mask[8];
-      for (int i = 0; i < 8; ++i) mask[i] = cu_mask_env;
-      ISHAP_CHECK_HIP(hipExtStreamCreateWithCUMask(&u->side, 8, mask));
-    } else {
-      ISHAP_CHECK_HIP(hipStreamCreateWithPriority(&u->side, hipStreamNonBlocking, prio_env ? prio_least : prio_greatest));
-    }
+    ISHAP_CHECK_HIP(hipStreamCreateWithPriority(&u->side, hipStreamNonBlocking, prio_least));
     ISHAP_CHECK_HIP(hipEventCreateWithFlags(&u->ev_fork, ishap_event_flags()));
     ISHAP_CHECK_HIP(hipEventCreateWithFlags(&u->ev_tail, ishap_event_flags()));
     ISHAP_CHECK_HIP(hipEventCreateWithFlags(&u->ev_mid, ishap_event_flags()));
@@ -789,9 +705,8 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
   }
   u->arena.reset();
   u->stat_off = 0;
-  // the statistics arena is zeroed by the layout conversion below (its first use comes after it); ISHAP_STAT_MEMSET=1: by a memset launch
-  static const bool stat_memset = [] { const char* e = getenv("ISHAP_STAT_MEMSET"); return e && atoi(e) != 0; }();
-  const bool zero_in_convert = !stat_memset && (u->stat_cap % 2 == 0) && (reinterpret_cast<uintptr_t>(u->stat_base) & 15) == 0;
+  // the statistics arena is zeroed by the layout conversion below (its first use comes after it)
+  const bool zero_in_convert = (u->stat_cap % 2 == 0) && (reinterpret_cast<uintptr_t>(u->stat_base) & 15) == 0;
   if (!dry && u->stat_cap && !zero_in_convert) ISHAP_CHECK_HIP(hipMemsetAsync(u->stat_base, 0, u->stat_cap * sizeof(long long), s));
   u->have_saved = false;
   const int S = cfg.image_size, HW = S * S;
@@ -847,47 +762,26 @@ int unet_forward_impl(ishap_unet* u, const float* x, const float* ts, int N, int
     ISHAP_TRY(slab_materialize(e, h));             // the tap is complete on the caller's stream
     u->tap = h;
     ISHAP_CHECK_HIP(hipEventRecord(u->ev_fork, s));
-    static const int defer = [] { const char* v = getenv("ISHAP_TAIL_DEFER"); return v ? atoi(v) : 1; }();
-    if (defer) {
-      // DEFERRED tail (default since late round 5: -2.2 % against the tail forked at the tap): only PLAN the rest here -- allocate what it will allocate, launch nothing -- so that the
-      // caller's backward gets its scratch above the whole forward; ishap_unet_run_tail enqueues the launches later, behind an
-      // event the backward records after its first blocks (the tail then runs beside the backward's latency-bound middle,
-      // not beside its chip-filling first and last launches)
-      // ISHAP_TAIL_EARLY=n: the first n blocks after the tap are enqueued right away (at the fork, ISHAP_TAIL_WGS tiles per
-      // launch), only the rest is deferred
-      static const int early = [] { const char* v = getenv("ISHAP_TAIL_EARLY"); return v ? atoi(v) : 0; }();
-      size_t split2 = split;
-      if (early > 0) {
-        split2 = std::min(n_out, split + (size_t)early);
-        ISHAP_CHECK_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
-        Exec ea = e;
-        tail_exec(ea, u);
-        ISHAP_TRY(out_blocks_range(ea, u, split, split2, h, hs, feat_layer));
-      }
-      u->tail = ishap_unet::TailState{split2, h, hs, N, out, u->arena.off, u->stat_off, (keep & 1) != 0};
-      Exec plan = e;
-      plan.dry = true;
-      Tensor hp = h;
-      std::vector<Tensor> hsp = hs;
-      ISHAP_TRY(out_blocks_range(plan, u, split2, n_out, hp, hsp, feat_layer));
-      ISHAP_TRY(forward_head(plan, u, hp, N, out));
-      u->tail_deferred = true;
-      u->mid_recorded = false;
-    } else {
-      ISHAP_CHECK_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
-      tail_exec(e, u);
-      ISHAP_TRY(out_blocks_range(e, u, split, n_out, h, hs, feat_layer));
-      ISHAP_TRY(forward_head(e, u, h, N, out));
-    }
+    // DEFERRED tail (round 5: -2.2 % against a tail enqueued here, at the tap; that form was removed in round 6): only PLAN the
+    // rest -- allocate what it will allocate, launch nothing -- so that the caller's backward gets its scratch above the whole
+    // forward; ishap_unet_run_tail enqueues the launches later, behind an event the backward records after its first blocks
+    // (the tail then runs beside the backward's latency-bound middle, not beside its chip-filling first and last launches).
+    // The plan and the replay make the same allocations by construction: no route below depends on the tenancy, only launch
+    // forms do (gn_local_op's parts, attn8_fused_launch's one- or two-launch form)
+    u->tail = ishap_unet::TailState{split, h, hs, N, out, u->arena.off, u->stat_off, (keep & 1) != 0};
+    Exec plan = e;
+    plan.dry = true;
+    Tensor hp = h;
+    std::vector<Tensor> hsp = hs;
+    ISHAP_TRY(out_blocks_range(plan, u, split, n_out, hp, hsp, feat_layer));
+    ISHAP_TRY(forward_head(plan, u, hp, N, out));
+    u->tail_deferred = true;
+    u->mid_recorded = false;
   } else {
     ISHAP_TRY(forward_head(e, u, h, N, out));
   }
   if (feat_layer >= 0 && inter_feat && !dry)
     ISHAP_TRY(nhwc_f16_to_nchw(u->tap.p, inter_feat, 0, N, u->tap.C, u->tap.H * u->tap.W, u->tap.C, s));
-  if (e.s != s) {                                      // the tail ran on the side stream
-    ISHAP_CHECK_HIP(hipEventRecord(u->ev_tail, u->side));
-    u->tail_pending = true;
-  }
   u->last_N = N;
   u->last_feat = feat_layer;
   u->have_saved = (keep & 1) != 0 && !dry;

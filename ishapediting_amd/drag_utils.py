@@ -210,6 +210,7 @@ class DragStuff:
     """drag_utils.py:174-583."""
 
     args = get_args()
+    overlap_tail = None       # None: the module default (_OVERLAP_TAIL, i.e. ISHAP_OVERLAP_TAIL); True / False: this object only
 
     def __init__(self, device=None, args=None):
         if args is not None:
@@ -370,7 +371,8 @@ class DragStuff:
             # backward run between the model call and the step arithmetic either way, beside the forward tail when overlapping
             outs = self.diffusion.p_sample_guidance(self.model, img, i, feat_layer=self.args.feat_layer,
                                                     keep_for_backward=True, want_inter_feat=False,
-                                                    noise=self._noise(i, img), between=loss_and_backward, overlap=_OVERLAP_TAIL,
+                                                    noise=self._noise(i, img), between=loss_and_backward,
+                                                    overlap=_OVERLAP_TAIL if self.overlap_tail is None else self.overlap_tail,
                                                     guided_scale=float(scale) if _FUSED_UPDATE else None, want_noise=False)
             if _FUSED_UPDATE:
                 img = outs["guided"]

@@ -224,11 +224,15 @@ class SpacedDiffusion:
         mo, inter = self._model(model, x, ti, feat_layer, **kw)
         grad = None
         if between is not None:
-            grad = between()
-            if kw.get("overlap_tail"):
-                if hasattr(model, "run_tail"):
-                    model.run_tail()          # a tail the forward only planned (deferred form); no-op otherwise
-                model.join_tail()
+            try:
+                grad = between()
+            finally:
+                # also when `between` raises: the planned tail writes `model_output` through the pointer the forward was given --
+                # it must be enqueued and joined while that tensor is still alive (include/ishap.h, ishap_unet_forward)
+                if kw.get("overlap_tail"):
+                    if hasattr(model, "run_tail"):
+                        model.run_tail()      # the tail the forward only planned
+                    model.join_tail()
         if guided_scale is not None and grad is not None and variance_noise is None:
             rng = None
             if noise is None:

@@ -98,3 +98,28 @@ def handles(b: int = 3, seed: int = 7, step: float = 0.15):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     tgt = (src + step * d).astype(np.float32)
     return src, tgt
+
+
+# BASELINE configs[3] at FULL length (drag_utils.py:401-471, :552-566): 200 reconstruction steps x 40 000 occupancy samples,
+# DDPM inversion over w_time = 170, 170 guided drag iterations, 256^3 decode
+C4_T, C4_W, C4_RES, C4_POINTS = 200, 170, 256, 40000
+
+
+def c4_inputs(T: int = C4_T, W: int = C4_W, points: int = C4_POINTS, seed: int = 2024):
+    """Seeded inputs of the full-length C4 chain, identical for the device run, the oracle run and the committed fixture
+    (tools/make_c4_fixture.py).  The 'real shape' is the union of four ellipsoids bench.py's C4 leg uses as its synthetic
+    airplane, sampled analytically (occupancy = inside any ellipsoid).  Returns (img0, batch(k), noise(tag, k))."""
+    gen = torch.Generator().manual_seed(seed)
+    img0 = torch.randn(1, 96, 128, 128, generator=gen)
+    centres = torch.tensor([[0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [-0.55, 0.0, 0.12], [0.1, 0.0, 0.0]])
+    radii = torch.tensor([[0.75, 0.10, 0.10], [0.12, 0.62, 0.03], [0.10, 0.22, 0.03], [0.10, 0.03, 0.20]])
+
+    def batch(k):                       # a fresh batch per step from its own seed (DataLoader(shuffle=True), drag_utils.py:453)
+        g = torch.Generator().manual_seed(seed * 1000 + k)
+        c = torch.rand(points, 3, generator=g) * 2 - 1
+        inside = (((c[:, None, :] - centres[None]) / radii[None]).pow(2).sum(-1) < 1).any(dim=1)
+        return c, inside.float()
+
+    def noise(tag, k):                  # one 6.3 MB tensor at a time (three chains x 170-200 steps would be 3.4 GB resident)
+        return torch.randn(1, 96, 128, 128, generator=torch.Generator().manual_seed(seed * 7919 + tag * 1000 + k))
+    return img0, batch, noise

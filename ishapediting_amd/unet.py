@@ -117,8 +117,10 @@ class UNetModel:
     # ------------------------------------------------------------------ forward / backward
     def forward(self, x: torch.Tensor, timesteps, y=None, feat_layer: int = -1, keep_for_backward: bool = False,
                 want_inter_feat: bool = True, overlap_tail: bool = False):
-        """`overlap_tail` (with a tap): the blocks after the tap and the head run on the context's own stream beside
-        whatever the caller enqueues next (loss, backward); the returned model output is valid only after `join_tail()`."""
+        """`overlap_tail` (with a tap): the blocks after the tap and the head are only PLANNED; `run_tail()` enqueues them on the
+        context's own stream beside whatever the caller has enqueued meanwhile (loss, backward) -- a join, the next forward or a
+        full-depth backward does so by itself.  The returned model output is valid only after `join_tail()`; the model keeps a
+        reference to it until then (the library writes it through the raw pointer)."""
         assert y is None, "class conditioning is not on the path"
         assert x.dim() == 4 and x.shape[1] == self.in_channels and x.shape[2] == x.shape[3] == self.image_size
         N = x.shape[0]
@@ -136,6 +138,7 @@ class UNetModel:
                                                   _lib.ptr(inter), int(bool(keep_for_backward)) | (2 if overlap_tail else 0),
                                                   _lib.stream_ptr(self.device)))
         self._last_shape = tuple(x.shape)
+        self._tail_out = out if overlap_tail else None       # alive until the tail that writes it has been joined
         if feat_layer < 0:
             return out
         return out, inter
@@ -143,7 +146,7 @@ class UNetModel:
     __call__ = forward
 
     def run_tail(self):
-        """Enqueue a forward tail that `forward(overlap_tail=True)` only planned (ISHAP_TAIL_DEFER=1); no-op otherwise."""
+        """Enqueue the forward tail that `forward(overlap_tail=True)` only planned; no-op when there is none."""
         with torch.cuda.device(self.device):
             _lib.check(self._L.ishap_unet_run_tail(self._h))
 
@@ -151,6 +154,7 @@ class UNetModel:
         """Order the current stream behind an overlapped forward tail (no-op when there is none)."""
         with torch.cuda.device(self.device):
             _lib.check(self._L.ishap_unet_join_tail(self._h, _lib.stream_ptr(self.device)))
+        self._tail_out = None
 
     def prepare_timesteps(self, timesteps):
         """Compute the timestep-dependent FiLM rows of a sampling loop once (they do not depend on x): forwards at these

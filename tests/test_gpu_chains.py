@@ -151,15 +151,68 @@ def test_smaller_batches_on_a_context_built_for_more():
         own.load_state_dict(sd)
         o_big, _ = big(x[:n], ts[:n], feat_layer=k, keep_for_backward=True)
         g_big = big.backward_input(cot[:n].contiguous())
-        # each context runs ALONE on the device (a context that arrives while another's work is in flight holds no rendezvous
-        # tenancy and takes the wait-free kernel forms: the same values for GroupNorm, the three-launch form -- equal to summation
-        # order only -- for the 8x8 attention block of round 5)
-        torch.cuda.synchronize()
+        # no synchronisation between the two: `own` arrives while `big`'s work is still in flight, holds no rendezvous tenancy
+        # and takes the wait-free launch forms -- one workgroup per GroupNorm group, the 8x8 AttentionBlock kernel as two launches
+        # of the same code (csrc/attention.hip, Attn8Args::phases) -- whose values are BITWISE those of the tenant's forms
         o_own, _ = own(x[:n], ts[:n], feat_layer=k, keep_for_backward=True)
         g_own = own.backward_input(cot[:n].contiguous())
         torch.cuda.synchronize()
         assert torch.equal(o_big, o_own), n
         assert torch.equal(g_big, g_own), n
+
+
+def test_two_contexts_at_once_give_the_bits_of_a_solo_run():
+    """two model contexts driven from two host threads on two streams AT THE SAME TIME.  Whichever arrives second
+    holds no rendezvous tenancy (csrc/common.h) and takes the wait-free launch forms -- one workgroup per GroupNorm group, the 8x8
+    AttentionBlock as two launches of attn8_fused_kernel instead of one -- and which one that is changes from iteration to
+    iteration.  Every result of every iteration must equal, bit for bit, what the same context computes alone on the device
+    (gd/unet.py:337-354: one result per input)."""
+    import threading
+    from ishapediting_amd.unet import UNetModel
+    cfg = UNetConfig(image_size=32, in_channels=6, model_channels=64, out_channels=12, num_res_blocks=1,
+                     attention_resolutions="16,8", channel_mult=(1, 2, 4), num_head_channels=64)
+    k = len(build_spec(cfg).output_blocks) - 2
+    models, xs, cots = [], [], []
+    for j in range(2):
+        m = UNetModel(cfg, dev())
+        m.load_state_dict(synthetic.round_torso_to_fp16(synthetic.unet_state_dict(cfg, 300 + j)))
+        g = torch.Generator().manual_seed(40 + j)
+        ch, sz = m.tap_shape(k)
+        models.append(m)
+        xs.append(torch.randn(1, 6, 32, 32, generator=g).to(dev()))
+        cots.append((torch.randn(1, sz * sz, ch, generator=g) * 0.1).half().to(dev()))
+    solo = []
+    for j in range(2):                                       # alone on the device: the tenant's forms
+        o, t = models[j](xs[j], [333.0], feat_layer=k, keep_for_backward=True)
+        gx = models[j].backward_input(cots[j])
+        torch.cuda.synchronize()
+        solo.append((o.clone(), t.clone(), gx.clone()))
+    ITER = 12
+    got = [[], []]
+    errs = []
+    gate = threading.Barrier(2)
+
+    def worker(j):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=dev())):
+                gate.wait()
+                for _ in range(ITER):
+                    o, t = models[j](xs[j], [333.0], feat_layer=k, keep_for_backward=True)
+                    gx = models[j].backward_input(cots[j])
+                    got[j].append((o, t, gx))
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:                                # noqa: BLE001  (reported by the asserting thread)
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(j,)) for j in range(2)]
+    for t_ in th: t_.start()
+    for t_ in th: t_.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for j in range(2):
+        assert len(got[j]) == ITER
+        for it, (o, t, gx) in enumerate(got[j]):
+            assert torch.equal(o, solo[j][0]) and torch.equal(t, solo[j][1]) and torch.equal(gx, solo[j][2]), (j, it)
 
 
 def test_full_size_context_for_batch_2_serves_batch_1():
@@ -573,12 +626,21 @@ cot = (torch.randn(1, sz * sz, ch, generator=g) * 0.1).half().to(dev)
 out, tap = m(x, [617.0], feat_layer=k, keep_for_backward=True)
 gx = m.backward_input(cot)
 torch.cuda.synchronize()
+# the same step with the part of the forward after the tap planned, then enqueued beside the backward (ISHAP_TAIL_DEFER_WGS /
+# ISHAP_TAIL_MID size and place it): bitwise the plain sequence under every switch
+out2, tap2 = m(x, [617.0], feat_layer=k, keep_for_backward=True, overlap_tail=True)
+gx2 = m.backward_input(cot)
+m.run_tail()
+m.join_tail()
+torch.cuda.synchronize()
+assert torch.equal(out2, out) and torch.equal(tap2, tap) and torch.equal(gx2, gx), "overlapped forward tail changed a bit"
 np.savez({out!r}, out=out.cpu().numpy(), tap=tap.float().cpu().numpy(), gx=gx.cpu().numpy())
 """
 
 
 def test_runtime_switches_keep_the_results(tmp_path):
-    """Every A/B switch DESIGN.md section 3 lists selects another kernel or grid for the same arithmetic: the mid-size
+    """Every A/B switch of the C library that DESIGN.md section 3 lists (17 after round 6's pruning; the three Python-side ones are
+    exercised by the full-size tests) selects another kernel or grid for the same arithmetic: the mid-size
     configuration (forward output, a tap, the input gradient) under each switch, in a process of its own (the switches are
     read once per process), against the default build's results.  Same values up to summation order: relative L2 <= 2e-3
     forward, 5e-3 gradient (fp16 maps; the default-vs-oracle distance of these quantities is 1e-3 / 3e-3); switches that
@@ -588,24 +650,13 @@ def test_runtime_switches_keep_the_results(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = {"default": {}, "ISHAP_HALVES=1": {"ISHAP_HALVES": "1"},
             "ISHAP_LOCAL_GN=0": {"ISHAP_LOCAL_GN": "0"}, "ISHAP_SKINNY=0": {"ISHAP_SKINNY": "0"},
-            "ISHAP_SMALL3=0": {"ISHAP_SMALL3": "0"}, "ISHAP_GN_PARTS=1": {"ISHAP_GN_PARTS": "1"},
-            "ISHAP_PREFETCH=1": {"ISHAP_PREFETCH": "1"}, "ISHAP_IGEMM4=0": {"ISHAP_IGEMM4": "0"},
-            "ISHAP_IG4_TEAMS=0": {"ISHAP_IG4_TEAMS": "0"}, "ISHAP_IG4_TALL=0": {"ISHAP_IG4_TALL": "0"},
-            "ISHAP_IG4_W8=0": {"ISHAP_IG4_W8": "0"}, "ISHAP_G1_SLICES=0": {"ISHAP_G1_SLICES": "0"},
-            "ISHAP_ATTN_BWD_TEAMS=4": {"ISHAP_ATTN_BWD_TEAMS": "4"}, "ISHAP_ATTN_BWD_TEAMS=2": {"ISHAP_ATTN_BWD_TEAMS": "2"},
-            "ISHAP_ATTN_XCD=0": {"ISHAP_ATTN_XCD": "0"}, "ISHAP_IG4_SHORT_RING=0": {"ISHAP_IG4_SHORT_RING": "0"},
-            # round 5: the switches the list had missed
-            "ISHAP_IG4_W8_K2=0": {"ISHAP_IG4_W8_K2": "0"}, "ISHAP_IG4_K2_SMALL=1": {"ISHAP_IG4_K2_SMALL": "1"},
-            "ISHAP_PEND_NOSPLIT=36 ISHAP_PEND_MINSTEPS=6": {"ISHAP_PEND_NOSPLIT": "36", "ISHAP_PEND_MINSTEPS": "6"},
-            "ISHAP_PEND_NOSPLIT=6 ISHAP_PEND_MINSTEPS=2": {"ISHAP_PEND_NOSPLIT": "6", "ISHAP_PEND_MINSTEPS": "2"},
-            "ISHAP_ATTN_TEAMS=2": {"ISHAP_ATTN_TEAMS": "2"}, "ISHAP_ATTN_TEAMS=4": {"ISHAP_ATTN_TEAMS": "4"},
-            "ISHAP_BIG_MIN=1": {"ISHAP_BIG_MIN": "1"},
-            # round 5 switches
+            "ISHAP_GN_PARTS=1": {"ISHAP_GN_PARTS": "1"}, "ISHAP_IGEMM4=0": {"ISHAP_IGEMM4": "0"}, "ISHAP_IGEMM4=1": {"ISHAP_IGEMM4": "1"},
+            "ISHAP_IG4_TEAMS=0": {"ISHAP_IG4_TEAMS": "0"}, "ISHAP_G1_SLICES=0": {"ISHAP_G1_SLICES": "0"},
+            "ISHAP_ATTN_XCD=0": {"ISHAP_ATTN_XCD": "0"}, "ISHAP_BIG_MIN=1": {"ISHAP_BIG_MIN": "1"},
             "ISHAP_GN_XCD=0": {"ISHAP_GN_XCD": "0"}, "ISHAP_GN_XCD=2": {"ISHAP_GN_XCD": "2"},
             "ISHAP_IG4_NOUTER=0": {"ISHAP_IG4_NOUTER": "0"}, "ISHAP_IG4_NOUTER=1": {"ISHAP_IG4_NOUTER": "1"},
             "ISHAP_EVENT_FENCE=1": {"ISHAP_EVENT_FENCE": "1"}, "ISHAP_ATTN8=0": {"ISHAP_ATTN8": "0"},
-            "ISHAP_ATTN8_BWD=1": {"ISHAP_ATTN8_BWD": "1"}, "ISHAP_ATTN_PROJ=1": {"ISHAP_ATTN_PROJ": "1"},
-            "ISHAP_ATTN8=0 ISHAP_ATTN_PROJ=1": {"ISHAP_ATTN8": "0", "ISHAP_ATTN_PROJ": "1"}}
+            "ISHAP_TAIL_DEFER_WGS=64 ISHAP_TAIL_MID=1": {"ISHAP_TAIL_DEFER_WGS": "64", "ISHAP_TAIL_MID": "1"}}
     res = {}
     for name, env in runs.items():
         path = str(tmp_path / (name.replace("=", "_").replace(" ", "_") + ".npz"))
@@ -623,7 +674,8 @@ def test_runtime_switches_keep_the_results(tmp_path):
         print(f"{name:18s} out {r_out:.1e} tap {r_tap:.1e} grad {r_gx:.1e}")
         assert r_out < 2e-3 and r_tap < 2e-3 and r_gx < 5e-3, (name, r_out, r_tap, r_gx)
         # extra workgroups that only touch weights / another placement of the same workgroups / other event flags: bitwise the same
-        if name in ("ISHAP_PREFETCH=1", "ISHAP_GN_XCD=0", "ISHAP_GN_XCD=2", "ISHAP_IG4_NOUTER=0", "ISHAP_IG4_NOUTER=1", "ISHAP_EVENT_FENCE=1"):
+        if name in ("ISHAP_GN_XCD=0", "ISHAP_GN_XCD=2", "ISHAP_IG4_NOUTER=0", "ISHAP_IG4_NOUTER=1", "ISHAP_EVENT_FENCE=1",
+                    "ISHAP_TAIL_DEFER_WGS=64 ISHAP_TAIL_MID=1"):
             assert r_out == 0.0 and r_tap == 0.0 and r_gx == 0.0, name
 
 

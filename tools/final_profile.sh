@@ -18,7 +18,7 @@ timeout -k 10 300 python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --n
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-concurrent --no-c2 --no-c4 > $O/trace_bench.json 2> $O/trace.err || exit 1
 f=$(find $O/trace -name "*kernel_trace.csv")
 python3 $R/tools/trace_by_grid.py $f > $O/kernel_by_grid.txt
-python3 $R/tools/step_timeline.py $f > $O/step_timeline.txt
+python3 $R/tools/step_timeline.py $f --json $O/step_breakdown.json > $O/step_timeline.txt
 rm -f $f
 cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
 python3 $R/tools/shape_table.py $O/shapes.csv > $O/shapes.txt

@@ -125,26 +125,7 @@ def shape_like_report(dec_sd, dev, res, extract_surface, mesh_chamfer, chamfer_d
 # oracle stage by stage FROM THE DEVICE'S STAGE INPUTS (so each tolerance measures one stage, as the shortened chain in
 # tests/test_gpu_fullsize.py does) and writes the report.
 # ------------------------------------------------------------------------------------------------------------------
-C4_T, C4_W, C4_RES, C4_POINTS = 200, 170, 256, 40000
-
-
-def c4_inputs(T=C4_T, W=C4_W, points=C4_POINTS, seed=2024):
-    """Seeded inputs of the full-length C4 chain, identical on both sides.  The 'real shape' is the union of four ellipsoids
-    bench.py's C4 leg uses as its synthetic airplane, sampled analytically (occupancy = inside any ellipsoid)."""
-    gen = torch.Generator().manual_seed(seed)
-    img0 = torch.randn(1, 96, 128, 128, generator=gen)
-    centres = torch.tensor([[0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [-0.55, 0.0, 0.12], [0.1, 0.0, 0.0]])
-    radii = torch.tensor([[0.75, 0.10, 0.10], [0.12, 0.62, 0.03], [0.10, 0.22, 0.03], [0.10, 0.03, 0.20]])
-
-    def batch(k):                       # a fresh batch per step from its own seed (DataLoader(shuffle=True), drag_utils.py:453)
-        g = torch.Generator().manual_seed(seed * 1000 + k)
-        c = torch.rand(points, 3, generator=g) * 2 - 1
-        inside = (((c[:, None, :] - centres[None]) / radii[None]).pow(2).sum(-1) < 1).any(dim=1)
-        return c, inside.float()
-
-    def noise(tag, k):                  # one 6.3 MB tensor at a time (three chains x 170-200 steps would be 3.4 GB resident)
-        return torch.randn(1, 96, 128, 128, generator=torch.Generator().manual_seed(seed * 7919 + tag * 1000 + k))
-    return img0, batch, noise
+from ishapediting_amd.synthetic import C4_POINTS, C4_RES, C4_T, C4_W, c4_inputs  # noqa: E402  (shared with tools/make_c4_fixture.py and the GPU test)
 
 
 def c4_device(out_path):

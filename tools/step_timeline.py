@@ -1,6 +1,8 @@
 """From a rocprofv3 kernel_trace.csv: one guided step = the dispatches between two consecutive drag-loss launches (drag_terms_kernel; drag_motion_kernel in older traces).
 Prints, for the median step: wall span, sum of kernel durations, idle (gaps), launches, and the per-kernel breakdown with
-the gap that precedes each kernel.  Usage: step_timeline.py kernel_trace.csv [--list]"""
+the gap that precedes each kernel.  --json FILE: the same step as ms / launches per kernel CLASS (conv3x3, gemm1x1, groupnorm,
+attention, other) -- profiles/step_breakdown.json, which bench.py quotes as `step_breakdown.trace`.
+Usage: step_timeline.py kernel_trace.csv [--list] [--json out.json]"""
 import csv
 import re
 import statistics
@@ -41,3 +43,27 @@ if "--list" in sys.argv:
     for s, e, name in rows[a:b]:
         print(f"  +{(s-prev_end)/1e3:6.2f} {(e-s)/1e3:8.2f} us  {short(name)}")
         prev_end = e
+
+if "--json" in sys.argv:
+    import json
+
+    def klass(k):
+        if k.startswith("igemm4_kernel") or re.match(r"igemm2?_kernel<.*true", k) or k.startswith("conv3_"):
+            return "conv3x3"
+        if re.match(r"igemm2?_kernel<.*false", k) or k.startswith("igemm_skinny") or k.startswith("igemm_splitk_reduce"):
+            return "gemm1x1"
+        if k.startswith("gn_"):
+            return "groupnorm"
+        if k.startswith("attn"):
+            return "attention"
+        return "other"
+    cls = {}
+    for k, v in agg.items():
+        c = cls.setdefault(klass(k), {"ms": 0.0, "launches": 0})
+        c["ms"] += (v[1] + v[2]) / 1e3
+        c["launches"] += v[0]
+    for c in cls.values():
+        c["ms"] = round(c["ms"], 4)
+    out = {"what": "median guided step of the plain launch sequence (ISHAP_OVERLAP_TAIL=0) under rocprofv3 --kernel-trace: kernel time + the gap in front "
+                   "of each kernel, per class", "step_wall_ms": round(wall / 1e6, 4), "kernel_ms": round(busy / 1e6, 4), "launches": n, "classes": cls}
+    json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
