@@ -235,6 +235,12 @@ struct IgemmArgs {
   int ups = 0;                   // conv3 source map is (H/2, W/2): nearest-neighbour upsample on the fly
   int res_ups = 0;               // residual map is (H/2, W/2)
   int ksplit = 1;
+  // LAYOUT MATTERS HERE (round 6, tools/kernel_meta.py, tests/test_host_cpu.py::test_hot_kernels_use_no_scratch): these three dwords
+  // (once lite / force_small / chunk_tiles_big) keep {alpha, out_mode, stat_out} OFF a 16-byte boundary of the kernarg block.
+  // Without them the compiler fetched those four dwords with one s_load_dwordx4 into a PRIVATE copy of the argument block --
+  // s_load + s_waitcnt + scratch_store at kernel entry, scratch_load in the epilogue, 32 bytes of scratch per lane -- and every
+  // LDS-DMA convolution launch was 0.5-1.1 us slower (+3 % per edit, profiles/round6_ab_prune_scratch.txt)
+  int reserved_[3] = {0, 0, 0};
   int chunk_tiles = 0;           // > 0 (a multiple of 8): igemm4 runs the layer as several launches of at most that many tiles (igemm4.hip, launch4)
   int defer_reduce = 0;          // ksplit > 1: leave the fp32 slices in `ws` (no reduce launch); the caller hands a SlabSrc to the consumer
   float alpha = 1.f;
