@@ -524,8 +524,8 @@ def test_c4_full_length_end_to_end_vs_the_committed_oracle_fixture():
     (tools/make_c4_fixture.py, ~10 min of host time; `ishapediting_amd.synthetic.c4_inputs` defines the inputs for both sides).
     Unlike the stage-wise report of round 5 (profiles/round5_parity_c4_full.json: every oracle stage restarted from the DEVICE's
     stage input: 1.8e-4 / 1.6e-7 / 1.6e-4) nothing is re-synchronised here: the inversion starts from each side's own
-    reconstruction and the drag from each side's own w and guidance cache, so the bounds are END-TO-END bounds and wider than
-    DESIGN 4's per-stage ones by the factor the chain accumulates (stated next to each assert)."""
+    reconstruction and the drag from each side's own w and guidance cache, so the bounds are END-TO-END bounds (they turned out
+    equal to DESIGN 4's per-stage ones, see the asserts)."""
     import os
     from ishapediting_amd.drag_utils import DragStuff, get_args
     from ishapediting_amd.synthetic import c4_inputs
@@ -582,16 +582,21 @@ def test_c4_full_length_end_to_end_vs_the_committed_oracle_fixture():
           f"(drag loss {l_drag:.2e}); sub-grid sign flips {flips_rec} / {flips} of {nvox}, inside voxels {inside_rec} vs {int(g['vol_rec_inside'])} / "
           f"{inside} vs {int(g['vol_inside'])}, logit RMS err / RMS {rms_err:.2e}")
     assert len(loss_rec) == T and len(loss_drag) == W
-    # stage 1 starts from identical inputs on both sides: DESIGN 4's per-stage bound (measured 1.8e-4 / 5e-5 in round 5)
+    # Measured end to end (round 6, gpurun_out/r6/c4_full.txt): reconstruction 1.81e-4 (loss 4.3e-5), w 3.8e-6 (|variance noise|
+    # 2.8e-5), final 1.61e-4 (drag loss 1.5e-4), sub-grid sign flips 28 / 26 of 262 144, logit RMS error 3.5e-4 of the RMS -- i.e.
+    # the chain does NOT accumulate beyond its per-stage figures (round 5, stage-wise: 1.8e-4 / 1.6e-7 / 1.6e-4): the inversion
+    # contracts the reconstruction's difference (w = sqrt(abar_170) rec + noise) and the drag stage starts almost in step.  The
+    # end-to-end bounds therefore EQUAL DESIGN 4's per-stage C4 bounds -- nothing had to widen:
+    # stage 1 starts from identical inputs on both sides
     assert r_rec <= 5e-4 and l_rec <= 5e-4, (r_rec, l_rec)
-    # inversion is w = sqrt(abar) rec + noise: it inherits the reconstruction's difference scaled down
-    assert r_w <= 5e-4 and r_vn <= 5e-4, (r_w, r_vn)
-    # 170 guided steps from each side's own w and cache: per-stage 1.6e-4 (round 5) + what stages 1-2 handed on; bound 1e-3
-    assert r_fin <= 1e-3 and l_drag <= 2e-3, (r_fin, l_drag)
-    # occupancy: sign flips <= 5e-4 of the voxels (the per-stage full-grid figure of round 5 was 7.7e-5), logits to 1 % of their RMS
+    # inversion: inherits the reconstruction's difference scaled down by sqrt(abar)
+    assert r_w <= 5e-5 and r_vn <= 5e-4, (r_w, r_vn)
+    # 170 guided steps from each side's own w and guidance cache
+    assert r_fin <= 5e-4 and l_drag <= 1e-3, (r_fin, l_drag)
+    # occupancy: sign flips <= 5e-4 of the voxels, inside-voxel counts likewise, logits to 0.2 % of their RMS
     assert flips_rec <= 5e-4 * nvox and flips <= 5e-4 * nvox, (flips_rec, flips)
     assert abs(inside - int(g["vol_inside"])) <= 5e-4 * res ** 3 and abs(inside_rec - int(g["vol_rec_inside"])) <= 5e-4 * res ** 3
-    assert rms_err <= 1e-2, rms_err
+    assert rms_err <= 2e-3, rms_err
 
 
 def test_shortened_c2_generate_against_the_oracle():
