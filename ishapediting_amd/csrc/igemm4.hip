@@ -301,6 +301,37 @@ __global__ __launch_bounds__(512 * HALVES) void igemm4_kernel(const void* hX, co
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         issue3();
+#ifdef ABL_XFORM
+        // HARNESS TIMING PROBE (tools/bench_igemm.hip -DABL_XFORM; wrong results): what a GroupNorm apply + SiLU
+        // of the NEXT activation slab, done in LDS by the loader waves, costs the K loop.  The slab of steps 3(j+1) .. 3(j+1)+2 is
+        // rewritten in two halves, in the iterations of steps 3j+1 and 3j+2 (it has landed once at most the weights of the three
+        // steps issued after it are outstanding); the arithmetic is gn_act.h's sequence with per-lane stand-in parameters
+        if (ph != 0) {
+          if (ph == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * WI) : "memory");
+          const int nslot = (s / 3 + 1) % NSTX;
+          half_t* xs = sX + nslot * XSLOT;
+          const float x_mu = 0.01f * (float)(lane & 7), x_rs = 1.05f, x_g = 0.9f + 1e-3f * (float)lane, x_b = 0.02f;
+#pragma unroll
+          for (int i2 = 0; i2 < (XI + 1) / 2; ++i2) {
+            const int i = (ph - 1) * ((XI + 1) / 2) + i2;
+            if (i < XI) {
+              half8* p = reinterpret_cast<half8*>(xs + (wave * XI + i) * 8 * BK + lane * 8);
+              half8 v = *p;
+#pragma unroll
+              for (int c = 0; c < 8; ++c) {
+                const half_t yh = gn_affine((float)v[c], x_mu, x_rs, x_g, x_b);
+#ifdef ABL_XFORM_FILM
+                const half_t yf = gn_film(yh, (half_t)1.01f, (half_t)0.01f);
+                v[c] = (half_t)gn_silu((float)yf);
+#else
+                v[c] = (half_t)gn_silu((float)yh);
+#endif
+              }
+              *p = v;
+            }
+          }
+        }
+#endif
         ph = ph == 2 ? 0 : ph + 1;
       }
     } else {

@@ -7,7 +7,6 @@
 #include "../ishapediting_amd/csrc/igemm2.hip"
 #include "../ishapediting_amd/csrc/igemm4.hip"
 #include "../ishapediting_amd/csrc/igemm_skinny.hip"
-#include "../ishapediting_amd/csrc/igemm_small3.hip"
 hipEvent_t g_igemm_prof_start = nullptr, g_igemm_prof_stop = nullptr;
 #ifdef IG_STAMPS
 __device__ unsigned long long* g_ig_stamps;
@@ -35,7 +34,7 @@ int main(int argc, char** argv) {
   const int nwg_st = 8192;                         // before ANY launch: the stamped kernels write through this pointer
   unsigned long long* sb; hipMalloc(&sb, (size_t)nwg_st * 16 * 8); hipMemset(sb, 0, (size_t)nwg_st * 16 * 8);
   hipMemcpyToSymbol(HIP_SYMBOL(g_ig_stamps), &sb, sizeof(sb));
-  if (gen != 5 && M / 64 * ((Cout + 63) / 64) * ksplit > nwg_st) { printf("too many workgroups for the stamp buffer\n"); return 1; }
+  if (M / 64 * ((Cout + 63) / 64) * ksplit > nwg_st) { printf("too many workgroups for the stamp buffer\n"); return 1; }
 #endif
   half_t *X, *W, *O; float* ws;
   const size_t wel = (size_t)((Cout + 127) / 128 * 128) * K;
@@ -60,17 +59,16 @@ int main(int argc, char** argv) {
   if (stats) { hipMalloc(&st, (size_t)Cout * 2 * 8 * 64); hipMemset(st, 0, (size_t)Cout * 2 * 8 * 64); a.stat_out = st; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int mt = ksplit;                          // gen 4 (skinny kernel): argument 5 is MT (pixels per workgroup / 16)
-  if (gen == 4 || gen == 5) { a.ksplit = 1; }
+  if (gen == 4) { a.ksplit = 1; }
   int turn = 0;
   auto run = [&]() {
     a.Wt = W + (size_t)(turn++ % nbuf) * wel;
-    if (gen == 5) { IgemmArgs b = a; b.ksplit = ksplit; b.ws = ws; igemm_small3_launch(b, 0, 0); }
-    else if (gen == 4) igemm_skinny_launch(a, mt, 0);
+    if (gen == 4) igemm_skinny_launch(a, mt, 0);
     else if (gen == 6 && igemm4_applicable(a, big)) igemm4_launch_main(a, big, 0);
     else igemm2_launch_main(a, big, 0);
   };
   if (gen == 6 && !igemm4_applicable(a, big)) { printf("gen6: shape not applicable\n"); return 1; }
-  if (gen == 4 || gen == 5 || gen == 6) {         // check against the tiled kernel
+  if (gen == 4 || gen == 6) {         // check against the tiled kernel
     half_t* O1; hipMalloc(&O1, (size_t)M * Cout * 2);
     IgemmArgs b = a; b.out = O1; b.stat_out = nullptr; b.ksplit = 1;
     igemm2_launch_main(b, 0, 0);
@@ -78,7 +76,7 @@ int main(int argc, char** argv) {
     std::vector<half_t> o((size_t)M * Cout), o1((size_t)M * Cout);
     hipMemcpy(o.data(), O, o.size() * 2, hipMemcpyDeviceToHost);
     hipMemcpy(o1.data(), O1, o1.size() * 2, hipMemcpyDeviceToHost);
-    if ((gen == 5 || gen == 6) && ksplit > 1) {   // partial tiles: add the slices up on the host
+    if (gen == 6 && ksplit > 1) {   // partial tiles: add the slices up on the host
       std::vector<float> sl((size_t)ksplit * M * Cout);
       hipMemcpy(sl.data(), ws, sl.size() * 4, hipMemcpyDeviceToHost);
       for (size_t i = 0; i < o.size(); ++i) { float v = 0; for (int z = 0; z < ksplit; ++z) v += sl[(size_t)z * M * Cout + i]; o[i] = (half_t)v; }
