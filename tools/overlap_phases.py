@@ -3,7 +3,7 @@ runs: under the tracer the caller's queue stood still for 0.3-1 ms after the for
 torch events on the caller's stream: step start | loss + backward enqueued (between()) | tail joined | guided update done.
 Plain mode:      t1 - t0 = full forward + loss + backward                     t2 - t1 = DDPM step + guided update
 Overlapped mode: t1 - t0 = forward to the tap + loss + backward (contended)    t2 - t1 = what the tail still needs after the backward + step
-Usage: [ISHAP_OVERLAP_TAIL=1 ISHAP_TAIL_WGS=64] python tools/overlap_phases.py"""
+Usage: [ISHAP_OVERLAP_TAIL=1 ISHAP_TAIL_DEFER_WGS=128] python tools/overlap_phases.py"""
 import os
 import statistics
 import sys
@@ -53,7 +53,7 @@ def main():
         torch.cuda.synchronize()
     a = [m[0].elapsed_time(m[1]) for m in marks]
     b = [m[1].elapsed_time(m[2]) for m in marks]
-    what = (f"overlapped (ISHAP_TAIL_WGS={os.environ.get('ISHAP_TAIL_WGS', '64')}, ISHAP_TAIL_LITE={os.environ.get('ISHAP_TAIL_LITE', '0')})"
+    what = (f"overlapped (ISHAP_TAIL_DEFER_WGS={os.environ.get('ISHAP_TAIL_DEFER_WGS', '128')})"
             if ov else "plain sequence")
     print(f"{what}: step start -> loss + backward done {statistics.median(a):.3f} ms; -> tail joined + DDPM step / update "
           f"{statistics.median(b):.3f} ms; sum {statistics.median(a) + statistics.median(b):.3f} ms")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel traces of the plain sequence and of overlapped-tail settings on ONE box, then tools/overlap_timeline.py on each:
-#   tools/overlap_trace.sh "ISHAP_TAIL_WGS=128" "ISHAP_TAIL_WGS=192" ...     (ISHAP_OVERLAP_TAIL=1 is added to every setting)
+#   tools/overlap_trace.sh "ISHAP_TAIL_DEFER_WGS=128" "ISHAP_TAIL_DEFER_WGS=192" ...     (ISHAP_OVERLAP_TAIL=1 is added to every setting)
 # Output: gpurun_out/overlap/{plain,<setting>}.txt
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}

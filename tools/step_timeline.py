@@ -59,11 +59,15 @@ if "--json" in sys.argv:
         return "other"
     cls = {}
     for k, v in agg.items():
-        c = cls.setdefault(klass(k), {"ms": 0.0, "launches": 0})
-        c["ms"] += (v[1] + v[2]) / 1e3
+        c = cls.setdefault(klass(k), {"kernel_ms": 0.0, "gap_before_ms": 0.0, "launches": 0})
+        c["kernel_ms"] += v[1] / 1e3
+        c["gap_before_ms"] += v[2] / 1e3
         c["launches"] += v[0]
     for c in cls.values():
-        c["ms"] = round(c["ms"], 4)
-    out = {"what": "median guided step of the plain launch sequence (ISHAP_OVERLAP_TAIL=0) under rocprofv3 --kernel-trace: kernel time + the gap in front "
-                   "of each kernel, per class", "step_wall_ms": round(wall / 1e6, 4), "kernel_ms": round(busy / 1e6, 4), "launches": n, "classes": cls}
+        c["kernel_ms"] = round(c["kernel_ms"], 4)
+        c["gap_before_ms"] = round(c["gap_before_ms"], 4)
+    out = {"what": "median guided step of the plain launch sequence (ISHAP_OVERLAP_TAIL=0) under rocprofv3 --kernel-trace, per kernel class: kernel "
+                   "durations (a dependent launch's duration includes its boundary) and, separately, the idle gaps in front of the kernels (inflated by "
+                   "the tracer: the un-traced step is shorter than step_wall_ms)",
+           "step_wall_ms": round(wall / 1e6, 4), "kernel_ms": round(busy / 1e6, 4), "launches": n, "classes": cls}
     json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
