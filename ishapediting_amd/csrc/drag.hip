@@ -87,24 +87,41 @@ __device__ __forceinline__ void drag_motion_body(const DragArgs& a, int blk, int
       if (ycur >= 0 && ycur < a.W) fx_add(a.gfx + ((long long)ycur * a.W + x) * a.ld + ch, v0, DRAG_FX_SCALE);
       if (ycur + 1 >= 0 && ycur + 1 < a.W) fx_add(a.gfx + ((long long)(ycur + 1) * a.W + x) * a.ld + ch, v1, DRAG_FX_SCALE);
     };
-    // the segment's DSEG positions: all their texel loads are issued before the first is used
+    // the segment's DSEG positions: all their texel loads are issued before the first is used.  Round 6: really -- written as
+    // `if (in bounds) patch = fma(w, texel[...], patch)` every one of the 40 loads sat in a conditional block of its own, and the
+    // compiler closes such a block with s_waitcnt vmcnt(0): 41 of the kernel's 46 waits stood right behind a load (26 us per step).
+    // Now every load is unconditional at a clamped coordinate and a sample outside the map (zeros padding, drag_utils.py:355)
+    // enters with weight 0: fma(0, texel, acc) = acc, the same sums (the sign of a zero apart, which the fixed-point scatter drops).
     float dseg[DSEG];
+    half_t tp[DSEG][4], te[DSEG][4];
+    float wp[DSEG][4], we[DSEG][4];
 #pragma unroll
     for (int ii = 0; ii < DSEG; ++ii) {
       const int i = seg * DSEG + ii;
       const float oi = a.voxel * (float)(i - a.r);
       const Bilin bs = bilin_setup(su + oi, sv, a.W);
       const Bilin bt = bilin_setup(tu + oi, tv, a.W);
-      float patch = 0.f, shift = 0.f;
-      if (live && i < side) {
+      const bool on = live && i < side;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          int xs = bs.x0 + (q & 1), ys = bs.y0 + (q >> 1);
-          // explicit fused multiply-adds on both sides: identical inputs must give shift == patch exactly
-          if (xs >= 0 && xs < a.W && ys >= 0 && ys < a.W) patch = __fmaf_rn(bs.w[q], (float)a.orig[((long long)ys * a.W + xs) * a.ld + ch], patch);
-          int xt = bt.x0 + (q & 1), yt = bt.y0 + (q >> 1);
-          if (xt >= 0 && xt < a.W && yt >= 0 && yt < a.W) shift = __fmaf_rn(bt.w[q], (float)a.edit[((long long)yt * a.W + xt) * a.ld + ch], shift);
-        }
+      for (int q = 0; q < 4; ++q) {
+        const int xs = bs.x0 + (q & 1), ys = bs.y0 + (q >> 1);
+        const int xt = bt.x0 + (q & 1), yt = bt.y0 + (q >> 1);
+        const int xsc = min(max(xs, 0), a.W - 1), ysc = min(max(ys, 0), a.W - 1);
+        const int xtc = min(max(xt, 0), a.W - 1), ytc = min(max(yt, 0), a.W - 1);
+        tp[ii][q] = a.orig[((long long)ysc * a.W + xsc) * a.ld + ch];
+        te[ii][q] = a.edit[((long long)ytc * a.W + xtc) * a.ld + ch];
+        wp[ii][q] = (on && xs == xsc && ys == ysc) ? bs.w[q] : 0.f;
+        we[ii][q] = (on && xt == xtc && yt == ytc) ? bt.w[q] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < DSEG; ++ii) {
+      float patch = 0.f, shift = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // explicit fused multiply-adds on both sides: identical inputs must give shift == patch exactly
+        patch = __fmaf_rn(wp[ii][q], (float)tp[ii][q], patch);
+        shift = __fmaf_rn(we[ii][q], (float)te[ii][q], shift);
       }
       dseg[ii] = shift - patch;
     }

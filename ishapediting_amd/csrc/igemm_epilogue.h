@@ -116,6 +116,11 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
   half8 gx[RPT];
   if (want_gb && has) {
     const int n_img = m0 / HW, cpg = a.N / 32;
+    // every load below is UNCONDITIONAL (without FiLM the two FiLM rows read gamma and are ignored by gn_bwd_term): written as
+    // `a.gb_film ? a.gb_emb[...] : 0.f` each of the eight iterations ended in an s_waitcnt vmcnt(0) -- the compiler closes every
+    // conditional block that holds a load with one -- i.e. eight dependent round trips in front of this epilogue's barrier (round 6)
+    const float* const ep = a.gb_film ? a.gb_emb + (long long)n_img * a.gb_emb_ld + n : a.gb_gamma + n;
+    const float* const eq = a.gb_film ? ep + a.N : a.gb_gamma + n;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int g = (n + c) / cpg;
@@ -123,8 +128,8 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmArgs& a, f32x4 
       g_rs[c] = a.gb_stats[(n_img * 32 + g) * 2 + 1];
       g_gam[c] = a.gb_gamma[n + c];
       g_bet[c] = a.gb_beta[n + c];
-      g_esc[c] = a.gb_film ? a.gb_emb[(long long)n_img * a.gb_emb_ld + n + c] : 0.f;
-      g_esh[c] = a.gb_film ? a.gb_emb[(long long)n_img * a.gb_emb_ld + a.N + n + c] : 0.f;
+      g_esc[c] = ep[c];
+      g_esh[c] = eq[c];
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k)

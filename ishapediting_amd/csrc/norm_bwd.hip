@@ -137,10 +137,23 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const long long* h_cs
       if (pix < npix) {
         const int n = h_N == 1 ? 0 : pix / HW, p = pix - n * HW;
         const int y = wpow2 ? p >> wsh : p / h_W, x = p - y * h_W;
-        load_upstream(a.g, a.gmode, n, y, x, h_H, h_W, h_C, c0, up[u]);
-        xv[u] = *reinterpret_cast<const half8*>(a.x + (long long)pix * h_C + c0);
-        if (a.add) load_upstream(a.add, a.gmode, n, y, x, h_H, h_W, h_C, c0, ad[u]);
-        if (a.add2) a2[u] = *reinterpret_cast<const half8*>(a.add2 + (long long)pix * h_C + c0);
+        if (a.gmode == GB_SAME) {
+          // round 6: the four vectors of a pixel as UNCONDITIONAL loads (a missing addend reads the gradient / the input again and
+          // is not used) -- `if (a.add) load` and `if (a.add2) load` each closed with an s_waitcnt vmcnt(0): three dependent round
+          // trips per pixel where one does
+          const long long o8 = (long long)pix * h_C + c0;
+          const half8 gv = *reinterpret_cast<const half8*>(a.g + o8);
+          xv[u] = *reinterpret_cast<const half8*>(a.x + o8);
+          const half8 av = *reinterpret_cast<const half8*>((a.add ? a.add : a.g) + o8);
+          a2[u] = *reinterpret_cast<const half8*>((a.add2 ? a.add2 : a.x) + o8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { up[u][i] = (float)gv[i]; ad[u][i] = (float)av[i]; }
+        } else {
+          load_upstream(a.g, a.gmode, n, y, x, h_H, h_W, h_C, c0, up[u]);
+          xv[u] = *reinterpret_cast<const half8*>(a.x + (long long)pix * h_C + c0);
+          if (a.add) load_upstream(a.add, a.gmode, n, y, x, h_H, h_W, h_C, c0, ad[u]);
+          if (a.add2) a2[u] = *reinterpret_cast<const half8*>(a.add2 + (long long)pix * h_C + c0);
+        }
       }
     }
 #pragma unroll

@@ -69,6 +69,24 @@ __device__ __forceinline__ void st_half(half_t* p, const float* v) {
     p[0] = (half_t)v[0];
   }
 }
+// Loads the COMPILER does not see as loads (inline asm): it inserts no s_waitcnt for them -- not at a use it hoisted, not at a block
+// boundary -- so they stay in flight across whatever is issued next; the caller waits with pf_wait() before the first use.
+// (vmcnt counts in issue order: any later compiler-inserted wait for a younger load also covers these.)
+// RULE: the wait must lie on EVERY path, with the destinations as its operands, before the registers can be re-allocated -- the
+// compiler believes the values arrived with the asm statement and frees the registers at their last use on each path.
+template <int VEC> struct PfVec;        // VEC consecutive floats / halfs in one register tuple
+template <> struct PfVec<2> {
+  typedef f32x2 f_t; typedef unsigned h_t;
+  static __device__ __forceinline__ f_t ldf(const float* p) { f_t v; asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); return v; }
+  static __device__ __forceinline__ h_t ldh(const half_t* p) { h_t v; asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory"); return v; }
+  static __device__ __forceinline__ float hget(const h_t& v, int i) { return (float)__builtin_bit_cast(half2v, v)[i]; }
+};
+template <> struct PfVec<4> {
+  typedef f32x4 f_t; typedef f32x2 h_t;
+  static __device__ __forceinline__ f_t ldf(const float* p) { f_t v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); return v; }
+  static __device__ __forceinline__ h_t ldh(const half_t* p) { h_t v; asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); return v; }
+  static __device__ __forceinline__ float hget(const h_t& v, int i) { return (float)__builtin_bit_cast(half4, v)[i]; }
+};
 template <int VEC>
 __device__ __forceinline__ void add_f32(const float* p, float* acc) {
   if constexpr (VEC == 8) {
@@ -266,6 +284,28 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(int h_parts, int h_C, in
     psc[i] = FILM ? a.emb[(long long)n * a.emb_ld + c_first + i] : 0.f;
     psh[i] = FILM ? a.emb[(long long)n * a.emb_ld + C + c_first + i] : 0.f;
   }
+  // Round 6: bias / bias2 / residual of a pending input's FIRST unit as inline-asm loads (PfVec above), requested here.  The source
+  // below asks for them "before the slices are waited for", but the ISA had an s_waitcnt vmcnt(0) at the end of the conditional
+  // blocks that hold those loads -- a full memory round trip in front of the slice loads of ~55 launches per guided step.
+  // Unconditional loads (a missing operand reads gamma, a valid address, and is not used), waited for behind the slices.
+  constexpr bool PF = VEC == 2;
+  typedef PfVec<2> pf;
+  typename pf::f_t r_b1{}, r_b2{};
+  typename pf::h_t r_res{};
+  if constexpr (PF) {
+    const int u_f = (int)threadIdx.x < nunits ? (int)threadIdx.x : nunits - 1;
+    const int pl_f = u_f / VPP, c_f = c0g + (u_f - pl_f * VPP) * VEC, p_f = p0 + pl_f;
+    const bool on = pend && c_f < a.Ca;
+    long long rrow = (long long)n * HW + p_f;
+    if (a.slab.res_ups) {
+      const int py = p_f / a.W, px = p_f - py * a.W;
+      rrow = (long long)n * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1);
+    }
+    r_b1 = pf::ldf((on && a.slab.bias) ? a.slab.bias + c_f : a.gamma + c_first);
+    r_b2 = pf::ldf((on && a.slab.bias2) ? a.slab.bias2 + c_f : a.gamma + c_first);
+    r_res = pf::ldh((on && a.slab.res) ? a.slab.res + rrow * a.slab.ldr + c_f : reinterpret_cast<const half_t*>(a.gamma + c_first));
+  }
+  auto pf_wait = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r_b1), "+v"(r_b2), "+v"(r_res)::"memory"); };
   double s = 0.0, q = 0.0;
   for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
     const int pl = u / VPP, cv = u - pl * VPP, c = c0g + cv * VEC;
@@ -276,26 +316,34 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(int h_parts, int h_C, in
       if (pend) {
         // bias / residual are fetched BEFORE the slices are waited for: one memory round trip instead of three in a row
         // (the kernel is latency-bound, tools/experiments/persist_chain.hip -DGN_STAMPS)
+        const bool pre = PF && u == (int)threadIdx.x;                    // requested above
         float bv[VEC], b2v[VEC], r[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { bv[i] = 0.f; b2v[i] = 0.f; r[i] = 0.f; }
-        if (a.slab.bias) {
+        if (!pre) {
+          if (a.slab.bias) {
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) bv[i] = a.slab.bias[c + i];
-        }
-        if (a.slab.bias2) {
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) b2v[i] = a.slab.bias2[c + i];
-        }
-        if (a.slab.res) {
-          long long rrow = row;
-          if (a.slab.res_ups) {
-            const int py = p / a.W, px = p - py * a.W;
-            rrow = (long long)n * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1);
+            for (int i = 0; i < VEC; ++i) bv[i] = a.slab.bias[c + i];
           }
-          ld_half<VEC>(a.slab.res + rrow * a.slab.ldr + c, r);
+          if (a.slab.bias2) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) b2v[i] = a.slab.bias2[c + i];
+          }
+          if (a.slab.res) {
+            long long rrow = row;
+            if (a.slab.res_ups) {
+              const int py = p / a.W, px = p - py * a.W;
+              rrow = (long long)n * (HW >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1);
+            }
+            ld_half<VEC>(a.slab.res + rrow * a.slab.ldr + c, r);
+          }
         }
         slab_sum<VEC>(a.slab, row, a.Ca, c, v);
+        if (pre) {
+          pf_wait();                                                     // issued before the slices: landed with them
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) { bv[i] = r_b1[i]; b2v[i] = r_b2[i]; r[i] = pf::hget(r_res, i); }
+        }
         if (a.slab.bias) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) v[i] += bv[i];
@@ -322,6 +370,7 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(int h_parts, int h_C, in
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { s += (double)v[i]; q += (double)v[i] * (double)v[i]; }
   }
+  if constexpr (PF) pf_wait();       // on EVERY path before the destinations can be re-allocated (PfVec, RULE)
   GN_STAMP(1);
   block_sum2(s, q, scratch);
   GN_STAMP(2);
@@ -457,12 +506,62 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(int h_parts, int h_C
   float f_dyh[VEC], f_xh[VEC], f_ad[VEC], f_a2[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { f_dyh[i] = 0.f; f_xh[i] = 0.f; f_ad[i] = 0.f; f_a2[i] = 0.f; }
+  // Round 6: everything the first unit needs besides the upstream gradient -- the saved GroupNorm input, gamma / beta / FiLM rows, the
+  // addends -- is requested BEFORE the pending slices are waited for.  The ISA had them behind the slice loads' s_waitcnt vmcnt(0)
+  // (loads return in order): two dependent memory round trips in a kernel that is nothing but latency (60 launches per guided step).
+  // The compiler cannot be talked into it (it hoists the loop-invariant products of gamma / FiLM above the loop and waits for them,
+  // and waits at the end of every conditional block that holds a load), so at VEC = 2 -- 58 of the 60 launches per guided step -- these
+  // loads are inline asm (PfVec above), unconditional (a thread without a unit reads the last unit's operands) and first touched
+  // behind pf_wait below, after the slices have been requested AND waited for.
+  constexpr bool PF = VEC == 2;      // VEC = 4 (2 launches per step) is at its 128-register cap: the extra live values spilled, and a spill of an in-flight destination is a wrong value
+  typedef PfVec<PF ? VEC : 2> pf;
+  const int u_first = (int)threadIdx.x < nunits ? (int)threadIdx.x : nunits - 1;
+  const int pl_f = u_first / VPP, c_f = c0g + (u_first - pl_f * VPP) * VEC, p_f = p0 + pl_f;
+  const bool add_same = a.gmode == GB_SAME;
+  typename pf::h_t r_x{}, r_ad{}, r_a2{};
+  typename pf::f_t r_gam{}, r_bet{}, r_esc{}, r_esh{};
+  if constexpr (PF) {
+    r_x = pf::ldh(a.x + ((long long)n * HW + p_f) * C + c_f);
+    r_gam = pf::ldf(a.gamma + c_f);
+    if (FILM || ACT) r_bet = pf::ldf(a.beta + c_f);
+    if (FILM) { r_esc = pf::ldf(a.emb + (long long)n * a.emb_ld + c_f); r_esh = pf::ldf(a.emb + (long long)n * a.emb_ld + C + c_f); }
+    // addends at the gradient's own resolution are one vector each; the pooled / upsampled forms (up and down blocks) add several
+    // values up and stay behind the loop
+    // (always loaded, from the saved input when there is no such addend: a conditional asm load would leave a register merge -- a
+    // copy of a destination that has not landed yet -- to the allocator's mercy)
+    const long long o_f = ((long long)n * HW + p_f) * C + c_f;
+    r_ad = pf::ldh((a.add && add_same) ? a.add + o_f : a.x + o_f);
+    r_a2 = pf::ldh(a.add2 ? a.add2 + o_f : a.x + o_f);
+  }
+  auto pf_wait = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r_x), "+v"(r_ad), "+v"(r_a2), "+v"(r_gam), "+v"(r_bet), "+v"(r_esc), "+v"(r_esh)::"memory");
+  };
   for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
     const int pl = u / VPP, cv = u - pl * VPP, c = c0g + cv * VEC;
     const int p = p0 + pl;
+    const bool first = u == (int)threadIdx.x;
     float up[VEC], xv[VEC];
     upstream<VEC>(a.g, a.slab, a.gmode, n, p, a.H, a.W, C, c, up);
-    ld_half<VEC>(a.x + ((long long)n * HW + p) * C + c, xv);
+    const bool pre = PF && first;                  // this unit's operands were requested above
+    float gm[VEC], bt[VEC], es[VEC], eh[VEC];
+    if constexpr (PF) {
+      if (pre) {
+        pf_wait();                                 // everything above has landed long ago (the slices were issued later): free
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { xv[i] = pf::hget(r_x, i); gm[i] = r_gam[i]; bt[i] = r_bet[i]; es[i] = r_esc[i]; eh[i] = r_esh[i]; }
+      } else {
+        ld_half<VEC>(a.x + ((long long)n * HW + p) * C + c, xv);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          gm[i] = a.gamma[c + i];
+          bt[i] = (FILM || ACT) ? a.beta[c + i] : 0.f;
+          es[i] = FILM ? a.emb[(long long)n * a.emb_ld + c + i] : 0.f;
+          eh[i] = FILM ? a.emb[(long long)n * a.emb_ld + C + c + i] : 0.f;
+        }
+      }
+    } else {
+      ld_half<VEC>(a.x + ((long long)n * HW + p) * C + c, xv);
+    }
     if (STAGE32) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) st32[pl * cpg + cv * VEC + i] = up[i];
@@ -472,18 +571,38 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(int h_parts, int h_C
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       float dyh, xh;
-      gn_bwd_term(up[i], xv[i], mu, rs, a.gamma[c + i], (FILM || ACT) ? a.beta[c + i] : 0.f,
-                  FILM ? a.emb[(long long)n * a.emb_ld + c + i] : 0.f, FILM ? a.emb[(long long)n * a.emb_ld + C + c + i] : 0.f,
-                  FILM, ACT, dyh, xh);
+      if constexpr (PF)
+        gn_bwd_term(up[i], xv[i], mu, rs, gm[i], bt[i], es[i], eh[i], FILM, ACT, dyh, xh);
+      else      // the operands straight from memory, as before round 6 (the VEC = 4 / 8 forms sit at their register cap)
+        gn_bwd_term(up[i], xv[i], mu, rs, a.gamma[c + i], (FILM || ACT) ? a.beta[c + i] : 0.f,
+                    FILM ? a.emb[(long long)n * a.emb_ld + c + i] : 0.f, FILM ? a.emb[(long long)n * a.emb_ld + C + c + i] : 0.f,
+                    FILM, ACT, dyh, xh);
       s1 += (double)dyh;
       s2 += (double)dyh * (double)xh;
-      if (u == (int)threadIdx.x) { f_dyh[i] = dyh; f_xh[i] = xh; }
+      if (first) { f_dyh[i] = dyh; f_xh[i] = xh; }
     }
   }
+  // EVERY thread passes a wait for its asm loads before their destination registers may be given to anything else: a thread
+  // without a unit never ran the loop's wait, and on its path the compiler considers those registers dead from here on -- a load
+  // that lands later would overwrite whatever was allocated there (seen: the lane index of block_sum2, i.e. garbage group sums).
+  if constexpr (PF) pf_wait();
   if ((int)threadIdx.x < nunits) {
-    const int pl = threadIdx.x / VPP, c = c0g + (threadIdx.x - pl * VPP) * VEC, p = p0 + pl;
-    if (a.add) addend<VEC>(a.add, a.gmode, n, p, a.H, a.W, C, c, f_ad);
-    if (a.add2) ld_half<VEC>(a.add2 + ((long long)n * HW + p) * C + c, f_a2);
+    if (a.add) {
+      if (PF && add_same) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) f_ad[i] = pf::hget(r_ad, i);
+      } else {
+        addend<VEC>(a.add, a.gmode, n, p_f, a.H, a.W, C, c_f, f_ad);
+      }
+    }
+    if (a.add2) {
+      if (PF) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) f_a2[i] = pf::hget(r_a2, i);
+      } else {
+        ld_half<VEC>(a.add2 + ((long long)n * HW + p_f) * C + c_f, f_a2);
+      }
+    }
   }
   block_sum2(s1, s2, scratch);
   group_rendezvous(s1, s2, a.rec + ((long long)n * 32 + g) * GN_REC_STRIDE, part, parts, scratch, a.status, a.spin_limit, xcd_local);
