@@ -47,16 +47,21 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(DdpmStepArgs a) {
     const f32x4 x = *reinterpret_cast<const f32x4*>(a.x + e);
     const f32x4 eps = *reinterpret_cast<const f32x4*>(a.model_out + n * 2 * per_img + r);
     const f32x4 v = *reinterpret_cast<const f32x4*>(a.model_out + n * 2 * per_img + per_img + r);
+    // every operand as an UNCONDITIONAL load (an absent one reads x again and is not used): `if (p) v = p[e]` closes with an
+    // s_waitcnt vmcnt(0) per block -- four dependent round trips through a kernel that is one streaming pass (round 6)
+    const f32x4 nz_l = *reinterpret_cast<const f32x4*>((a.noise ? a.noise : a.x) + e);
+    const f32x4 var_l = *reinterpret_cast<const f32x4*>((a.variance_in ? a.variance_in : a.x) + e);
+    const f32x4 gr_l = *reinterpret_cast<const f32x4*>((a.guided ? a.guide_grad : a.x) + e);
     f32x4 nz = {0.f, 0.f, 0.f, 0.f};
-    if (a.noise) nz = *reinterpret_cast<const f32x4*>(a.noise + e);
+    if (a.noise) nz = nz_l;
     else if (a.rng) {
       nz = step_noise4((unsigned long long)i, a.rng_seed, a.rng_offset);
       if (a.noise_out) *reinterpret_cast<f32x4*>(a.noise_out + e) = nz;
     }
     f32x4 var_in = {0.f, 0.f, 0.f, 0.f};
-    if (a.variance_in) var_in = *reinterpret_cast<const f32x4*>(a.variance_in + e);
+    if (a.variance_in) var_in = var_l;
     f32x4 gr = {0.f, 0.f, 0.f, 0.f};
-    if (a.guided) gr = *reinterpret_cast<const f32x4*>(a.guide_grad + e);
+    if (a.guided) gr = gr_l;
     f32x4 o_sample, o_x0, o_var, o_mean, o_guided;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

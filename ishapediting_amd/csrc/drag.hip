@@ -242,6 +242,12 @@ __global__ __launch_bounds__(256) void drag_gather_kernel(DragArgs a, unsigned* 
     float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int tex = (int)(i / a.ld), ch = (int)(i - (long long)tex * a.ld);
     const unsigned char t0 = a.touched[tex], t1 = a.touched[WW + tex], t2 = a.touched[2 * WW + tex];
+    // the mask term's operands, requested together with the footprint bytes (round 6: they used to be issued behind the footprint
+    // test and, plane by plane, inside conditional blocks -- each closed by an s_waitcnt vmcnt(0))
+    const half8 e8 = *reinterpret_cast<const half8*>(a.edit + i), o8 = *reinterpret_cast<const half8*>(a.orig + i);
+    uc8 cw[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) cw[p] = *reinterpret_cast<const uc8*>(a.chw + p * a.ld + ch);
     if ((t0 | t1 | t2) & 2) {                       // a target footprint covers this texel on some plane
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -257,11 +263,9 @@ __global__ __launch_bounds__(256) void drag_gather_kernel(DragArgs a, unsigned* 
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         if (!(tp[p] & 1)) {
-          const uc8 c8 = *reinterpret_cast<const uc8*>(a.chw + p * a.ld + ch);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) w[k] += c8[k];
+          for (int k = 0; k < 8; ++k) w[k] += cw[p][k];
         }
-      const half8 e8 = *reinterpret_cast<const half8*>(a.edit + i), o8 = *reinterpret_cast<const half8*>(a.orig + i);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float d = (float)e8[k] - (float)o8[k], wk = (float)w[k];
