@@ -1,4 +1,7 @@
 // Persistent-kernel prototype for the 8x8 level ("measure, not cite").
+// HISTORICAL (rounds 3-5): form (A) launches csrc/igemm_small3.hip, which round 6 removed from the library together with the other
+// measured-loser kernel families -- this file builds against the round-5 tree (git show 3dbab91:ishapediting_amd/csrc/igemm_small3.hip);
+// its results are in profiles/round3_persistent_chain.txt and the GN_STAMPS table in DESIGN.md.
 //
 // Chain of L layers on a 64-pixel x 1024-channel map at batch 1, each layer = what half a ResBlock of the middle block
 // does (guided_diffusion/unet.py:236-256):   x_l = x_{l-1} + conv3x3( SiLU( GroupNorm32(x_{l-1}) ) ) + bias
