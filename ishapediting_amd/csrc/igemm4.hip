@@ -669,6 +669,13 @@ int igemm4_launch_main(const IgemmArgs& a, bool big, hipStream_t s) {
     return launch4<128, 128, 16, IG4_BIG_W, IG4_BIG_X>(a, s);
   }
   if (igemm4_tall_tiles(a, big)) return launch4<128, 64, 64, IG4_SMALL_W, IG4_SMALL_X>(a, s);
+#ifdef IG4_TALL_PROBE      // harness only (tools/experiments/tall_probe.sh; profiles/round6_tall_tiles_sliced_launches.txt): 128 x 64 tiles on the 32^2 / 16^2 maps
+  if ((a.W == 32 || a.W == 16) && a.K2 == 0 && a.M % 128 == 0 && (a.H * a.W) % 128 == 0) {
+    const int st = 3 * ((3 * (a.Cin / 64) + a.ksplit - 1) / a.ksplit);
+    if (st >= 9 && st <= 12) return a.W == 32 ? launch4<128, 64, 32, IG4_W8_W, IG4_W8_X>(a, s) : launch4<128, 64, 16, IG4_W8_W, IG4_W8_X>(a, s);
+    return a.W == 32 ? launch4<128, 64, 32, IG4_SMALL_W, IG4_SMALL_X>(a, s) : launch4<128, 64, 16, IG4_SMALL_W, IG4_SMALL_X>(a, s);
+  }
+#endif
   if (igemm4_two_teams(a, big)) {
     if (a.W == 64) return launch4<64, 64, 64, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);
     if (a.W == 32) return launch4<64, 64, 32, IG4_TEAM_W, IG4_TEAM_X, 2>(a, s);
