@@ -147,6 +147,7 @@ __device__ __forceinline__ void slab_sum(const SlabSrc& s, long long row, int ld
 
 __device__ __forceinline__ float rh(float v) { return (float)(half_t)v; }
 
+constexpr int GN_SCRATCH_BYTES = 512;      // 64 doubles in front of the staging area: block_sum2's 2 x 16 wave partials, then the rendezvous' 4 x parts values
 // block-wide sums of two doubles (every thread gets them); `scratch` = 2 * 16 doubles of LDS
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch) {
   a = wave_sum_f64(a);                   // DPP + v_readlane (common.h): the butterfly of 64-bit __shfl_xor cost ~400 cycles more
@@ -194,7 +195,9 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
 __device__ __forceinline__ void group_rendezvous(double& a, double& b, unsigned long long* rec, int part, int parts,
                                                  double* scratch, unsigned* status, int spin_limit, bool xcd_local) {
   if (parts <= 1) return;
-  __syncthreads();
+  // (round 6: no barrier in front and none behind -- the poll results go to the SECOND 32 doubles of `scratch`, which nothing else in
+  // these kernels touches, so block_sum2's reads of the first 32 cannot collide with them; five barriers per launch became two)
+  double* const mine = scratch + 32;
   if (threadIdx.x < GN_REC_PER_PART) {
     const double d = (threadIdx.x & 2) ? b : a;
     const float hi = (float)d;
@@ -222,17 +225,16 @@ __device__ __forceinline__ void group_rendezvous(double& a, double& b, unsigned 
       __hip_atomic_store(status, (unsigned)ISHAP_DEV_GN_RENDEZVOUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       v = __builtin_nan("");
     }
-    scratch[threadIdx.x] = v;
+    mine[threadIdx.x] = v;
   }
   __syncthreads();
   double ta = 0.0, tb = 0.0;
   for (int p = 0; p < parts; ++p) {    // (hi + lo) is exact in double; parts add in part order
-    ta += scratch[GN_REC_PER_PART * p] + scratch[GN_REC_PER_PART * p + 1];
-    tb += scratch[GN_REC_PER_PART * p + 2] + scratch[GN_REC_PER_PART * p + 3];
+    ta += mine[GN_REC_PER_PART * p] + mine[GN_REC_PER_PART * p + 1];
+    tb += mine[GN_REC_PER_PART * p + 2] + mine[GN_REC_PER_PART * p + 3];
   }
   a = ta;
   b = tb;
-  __syncthreads();
 }
 
 // workgroup -> (group, part).  xcd_local: the parts of a group get linear ids 8 apart (equal `id & 7` = one XCD under round-robin
@@ -255,8 +257,8 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(int h_parts, int h_C, in
   // h_*: copies of a.parts, a.C, a.H * a.W, a.Ca as leading scalar parameters -- preloaded into SGPRs at dispatch (common.h,
   // IgemmHot), so that the index arithmetic (three integer divisions) runs UNDER the s_load of the argument block, not after it
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* scratch = reinterpret_cast<double*>(smem_raw);                 // 32 doubles (block_sum2: 2 x 16; rendezvous: 4 x parts)
-  half_t* st = reinterpret_cast<half_t*>(smem_raw + 256);                // [HW][cpg]
+  double* scratch = reinterpret_cast<double*>(smem_raw);                 // 64 doubles (block_sum2: 2 x 16; rendezvous: 4 x parts in the second half)
+  half_t* st = reinterpret_cast<half_t*>(smem_raw + GN_SCRATCH_BYTES);   // [HW][cpg]
   const bool xcd_local = h_parts < 0;                                    // the launcher passes -(parts [+ 64]) for the XCD-local dealing
   const int parts = xcd_local ? (-h_parts & 63) : h_parts;
   int g, part;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(1024) void gn_local_kernel(int h_parts, int h_C, in
     a.stats_out[(n * 32 + g) * 2] = mean;
     a.stats_out[(n * 32 + g) * 2 + 1] = rstd;
   }
-  __syncthreads();                                                     // staging complete (block_sum2 synchronised after the loop as well)
+  // (no barrier here: the staging writes all precede block_sum2's barrier)
 
   auto activate = [&](const float* x, int c, float* o) {
     const bool first = c == c_first;               // the prefetched operands (else: this thread's later units, from memory)
@@ -486,8 +488,8 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(int h_parts, int h_C
   // h_*: preloaded copies of a.parts, a.C, a.H * a.W (see gn_local_kernel)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* scratch = reinterpret_cast<double*>(smem_raw);
-  half_t* st16 = reinterpret_cast<half_t*>(smem_raw + 256);
-  float* st32 = reinterpret_cast<float*>(smem_raw + 256);
+  half_t* st16 = reinterpret_cast<half_t*>(smem_raw + GN_SCRATCH_BYTES);
+  float* st32 = reinterpret_cast<float*>(smem_raw + GN_SCRATCH_BYTES);
   const bool xcd_local = h_parts < 0;
   const int parts = xcd_local ? (-h_parts & 63) : h_parts;
   int g, part;
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_local_kernel(int h_parts, int h_C
   asm volatile("" ::"v"(warm));
   const double cnt = (double)HW * (double)cpg;
   const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt);
-  __syncthreads();
+  // (no barrier here: the staging writes all precede block_sum2's barrier, and a thread re-reads what it staged itself)
   for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
     const int pl = u / VPP, cv = u - pl * VPP, c = c0g + cv * VEC;
     const int p = p0 + pl;
@@ -689,7 +691,7 @@ int pick_parts(int N, int HW, int cpg, int unit, bool have_rec) {
     p *= 2;
   return p;
 }
-constexpr size_t LOCAL_LDS_CAP = 160 * 1024 - 256;
+constexpr size_t LOCAL_LDS_CAP = 160 * 1024 - GN_SCRATCH_BYTES;
 // polls before a rendezvous gives up; ISHAP_GN_SPIN_LIMIT exists so that a test can force the give-up path (1 poll)
 int spin_limit() {
   static const int v = [] { const char* e = getenv("ISHAP_GN_SPIN_LIMIT"); const int n = e ? atoi(e) : 0; return n > 0 ? n : GN_SPIN_LIMIT; }();
@@ -705,7 +707,7 @@ int xcd_deal(int parts) {          // 0: off; 1: XCD-local dealing + local copy;
 template <typename K>
 int set_lds(K kern, size_t smem) {
   (void)smem;
-  return ishap_set_max_lds((const void*)kern, (int)LOCAL_LDS_CAP + 256);
+  return ishap_set_max_lds((const void*)kern, (int)LOCAL_LDS_CAP + GN_SCRATCH_BYTES);
 }
 
 }  // namespace
@@ -733,7 +735,7 @@ int gn_local_launch(const GnLocalArgs& a, hipStream_t s) {
   const int PP = HW / b.parts;
   const int VEC = pick_vec(cpg, PP, a.slab.pending());
   const int T = pick_threads(PP * (cpg / VEC));
-  const size_t smem = 256 + (size_t)PP * cpg * sizeof(half_t);
+  const size_t smem = GN_SCRATCH_BYTES + (size_t)PP * cpg * sizeof(half_t);
   dim3 grid(32 * b.parts, a.N), blk(T);
 #define GL_LAUNCH(V, F, A, P)                                                            \
   do {                                                                                   \
@@ -775,8 +777,8 @@ int gn_bwd_local_launch(const GnBwdLocalArgs& a, hipStream_t s) {
   ISHAP_REQUIRE(b.status != nullptr, "device status word");
   b.parts = pick_parts(a.N, HW, cpg, 1, a.rec != nullptr);
   const int PP = HW / b.parts;
-  const size_t smem = 256 + (size_t)PP * cpg * (s32 ? sizeof(float) : sizeof(half_t));
-  ISHAP_REQUIRE(smem <= LOCAL_LDS_CAP + 256, "group does not fit in LDS");
+  const size_t smem = GN_SCRATCH_BYTES + (size_t)PP * cpg * (s32 ? sizeof(float) : sizeof(half_t));
+  ISHAP_REQUIRE(smem <= LOCAL_LDS_CAP + GN_SCRATCH_BYTES, "group does not fit in LDS");
   const int VEC = pick_vec(cpg, PP, a.slab.pending());
   const int T = pick_threads(PP * (cpg / VEC));
   dim3 grid(32 * b.parts, a.N), blk(T);
