@@ -174,7 +174,9 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
 // (Alternative measured in round 3: sums about a common pivot every part derives from the group's first element, one fp32
 // granule per sum -- the extra uniform loads of the pivot cost more than the two granules they save: 13 100 vs 11 850 cycles.
 // Also measured: block sum + rendezvous merged into one routine where wave 0 alone adds the wave partials, publishes, polls
-// and adds the parts by v_readlane (two barriers instead of five): 204 + 5 676 cycles against 1 456 + 3 332 -- slower.)
+// and adds the parts by v_readlane (two barriers instead of the five of that time): 204 + 5 676 cycles against 1 456 + 3 332 -- slower.
+// Round 6 got to two barriers the other way: every thread still adds the wave partials and the parts, but the poll results live in a
+// scratch area of their own -- see the comment in the routine.)
 // The totals are formed from the parts in part order in double: bitwise reproducible, no atomics.
 // rec = [parts][4] granules, zeroed before the launch (tag 0 = not yet written).  The launcher only uses parts > 1 when the
 // whole grid is resident at once; the spin is bounded all the same, and a give-up is an ERROR: it raises the process-wide
